@@ -1,0 +1,356 @@
+/*
+ * hrcore.h — C-ABI of libhrcore, the MI355X-native per-pass ray kernel.
+ *
+ * This is the drop-in boundary.  The reference talks to its
+ * ray engine through the OpenRL C API (3rdParty/OpenRL/rl.h:383-528) wrapped
+ * by Source/RLWrapper/*.h; this header declares the entry points a
+ * re-implemented PassGenerator / Scene / Mesh / Material / Light layer binds
+ * instead.  Every entry point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - extern "C", opaque handle, plain pointers and sizes, int status
+ *     (HR_OK == 0).  No exceptions cross the boundary.  After a non-zero
+ *     status hr_last_error() returns a human-readable message
+ *     (reference: RLFunc/checkError, Source/RLWrapper/Error.h:18-41).
+ *   - The caller owns every input array; the library copies at call time
+ *     (reference semantics: rlBufferData copies, Source/RLWrapper/Buffer.h:46-55).
+ *   - All calls on one ctx must come from one thread at a time (the
+ *     reference's "OpenRL thread", Source/HeatrayRenderer/PassGenerator.h:229-231).
+ *   - Matrices are column-major float[16] (glm::mat4 memory layout).
+ *   - The accumulation buffer is RGBA32F, row-major, row 0 = BOTTOM scanline
+ *     (OpenRL frame origin, Resources/shaders/perspective.rlsl:73), A = sample
+ *     count (Resources/shaders/perspective.rlsl:60).
+ *
+ * The same POD structs are the input format of the CPU oracle (oracle/), whose
+ * entry points mirror these with the prefix ora_ instead of hr_.
+ */
+#ifndef HRCORE_H
+#define HRCORE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HR_OK 0
+#define HR_ERR_INVALID 1   /* bad argument / bad state            */
+#define HR_ERR_DEVICE 2    /* HIP error (no device, OOM, fault)   */
+#define HR_ERR_UNSUPPORTED 3
+
+/* Source/HeatrayRenderer/Lights/ShaderLightingDefines.h:18-20 */
+#define HR_MAX_DIRECTIONAL_LIGHTS 5
+#define HR_MAX_POINT_LIGHTS 5
+#define HR_MAX_SPOT_LIGHTS 5
+/* Source/HeatrayRenderer/PassGenerator.h:193 */
+#define HR_NUM_RANDOM_SEQUENCES 16
+
+typedef struct hr_ctx hr_ctx;
+
+/* ------------------------------------------------------------------ context */
+
+typedef struct hr_ctx_desc {
+    int32_t device_id;  /* HIP device ordinal                                              */
+    int32_t rank;       /* pixel-tile shard owned by this ctx: tiles t with t % world==rank */
+    int32_t world;      /* number of shards (1 = whole frame)                              */
+    int32_t tile_size;  /* tile edge in pixels (0 -> 32), SURVEY §8e                        */
+    void *stream;       /* hipStream_t to launch on, or NULL for the null stream           */
+    uint32_t flags;     /* HR_CTX_*                                                        */
+} hr_ctx_desc;
+
+#define HR_CTX_COLLECT_STATS 1u /* count node visits / triangle tests per pass (slower) */
+
+/* replaces OpenRLCreateContext / OpenRLSetCurrentContext (PassGenerator.cpp:164-165) */
+int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out);
+/* replaces OpenRLDestroyContext (PassGenerator.cpp:432) */
+int hr_ctx_destroy(hr_ctx *ctx);
+const char *hr_last_error(const hr_ctx *ctx);
+/* change the stream later launches go to (e.g. torch's current stream) */
+int hr_ctx_set_stream(hr_ctx *ctx, void *stream);
+
+/* replaces the FBO texture + PixelPackBuffer (re)allocation and rlViewport
+ * (PassGenerator.cpp:174-196, 301-323). Clears the accumulation buffer. */
+int hr_frame_resize(hr_ctx *ctx, int32_t width, int32_t height);
+/* Use caller-owned device memory (width*height*4 floats) as the accumulation
+ * buffer, e.g. a torch tensor handed to RCCL.  NULL returns to internal memory. */
+int hr_frame_bind_external(hr_ctx *ctx, void *device_rgba);
+int hr_frame_device_ptr(hr_ctx *ctx, void **device_rgba);
+
+/* --------------------------------------------------------------- geometry */
+
+#define HR_TRIANGLES 0      /* RL_TRIANGLES      (Mesh.cpp:134-136) */
+#define HR_TRIANGLE_STRIP 1 /* RL_TRIANGLE_STRIP (Mesh.cpp:137-139) */
+
+/* One submesh == one RL primitive (Mesh.cpp:55-153).  Attribute pointers are
+ * planar float arrays addressed with a byte stride like rlVertexAttribBuffer
+ * (Mesh.cpp:104-132); NULL = attribute absent. */
+typedef struct hr_mesh_desc {
+    const float *positions;  /* 3 floats / vertex, required */
+    const float *normals;    /* 3 floats / vertex, required */
+    const float *uvs;        /* 2 floats / vertex           */
+    const float *tangents;   /* 3 floats / vertex           */
+    const float *bitangents; /* 3 floats / vertex           */
+    const float *colors;     /* 3 floats / vertex           */
+    int32_t position_stride; /* bytes; 0 -> tightly packed  */
+    int32_t normal_stride;
+    int32_t uv_stride;
+    int32_t tangent_stride;
+    int32_t bitangent_stride;
+    int32_t color_stride;
+    int32_t n_vertices;
+    const uint32_t *indices; /* RL_UNSIGNED_INT (Mesh.cpp:152) */
+    int32_t n_indices;       /* elementCount                   */
+    int32_t mode;            /* HR_TRIANGLES / HR_TRIANGLE_STRIP */
+    float world_from_entity[16]; /* localTransform * transform (Mesh.cpp:85,102) */
+    int32_t front_face_cw;   /* rlFrontFace(RL_CW) when det < 0 (Mesh.cpp:86-91) */
+    int32_t is_occluder;     /* RL_PRIMITIVE_IS_OCCLUDER (Mesh.cpp:95-100)       */
+    int32_t material_id;     /* row set with hr_material_set                     */
+} hr_mesh_desc;
+
+typedef int32_t hr_geom_id;
+
+/* replaces Buffer::create + rlVertexAttribBuffer + rlDrawElements (Mesh.cpp:29-152) */
+int hr_geom_add(hr_ctx *ctx, const hr_mesh_desc *desc, hr_geom_id *out);
+/* replaces Scene::removeMesh / primitive destruction (Scene.h:52) */
+int hr_geom_remove(hr_ctx *ctx, hr_geom_id id);
+/* replaces setMatrix4fv("worldFromEntity") (Scene.cpp:38-49) */
+int hr_geom_set_transform(hr_ctx *ctx, hr_geom_id id, const float world_from_entity[16]);
+/* replaces Scene::clearMeshesAndMaterials (Scene.h:58) */
+int hr_scene_clear(hr_ctx *ctx);
+/* Acceleration-structure build: what OpenRL does behind rlDrawElements /
+ * the next rlRenderFrame.  World transform of every
+ * vertex (vertex.rlsl:25-43), Morton codes, radix sort, LBVH, refit. */
+int hr_scene_commit(hr_ctx *ctx);
+
+typedef struct hr_scene_info {
+    uint64_t n_triangles;
+    uint64_t n_nodes;
+    float aabb_min[3];
+    float aabb_max[3];
+    float ray_epsilon; /* self-intersection t_min, 1e-4 * |aabb diagonal| */
+    float build_ms;
+} hr_scene_info;
+int hr_scene_get_info(hr_ctx *ctx, hr_scene_info *out);
+
+/* --------------------------------------------------------------- textures */
+
+/* values mirror the RL_* enums used in openrl::Texture::Descriptor / Sampler
+ * (Source/RLWrapper/Texture.h:26-55) */
+#define HR_TEX_U8 0  /* RL_UNSIGNED_BYTE */
+#define HR_TEX_F32 1 /* RL_FLOAT         */
+#define HR_WRAP_REPEAT 0
+#define HR_WRAP_CLAMP_TO_EDGE 1
+#define HR_FILTER_NEAREST 0
+#define HR_FILTER_LINEAR 1 /* also RL_LINEAR_MIPMAP_LINEAR: sampled at LOD 0 */
+
+typedef struct hr_texture_desc {
+    int32_t width, height;
+    int32_t channels; /* 1 (LUMINANCE), 3 (RGB), 4 (RGBA) */
+    int32_t dtype;    /* HR_TEX_U8 (normalised /255) or HR_TEX_F32 */
+    int32_t wrap_s, wrap_t;
+    int32_t filter;
+} hr_texture_desc;
+
+typedef int32_t hr_tex_id;
+#define HR_TEX_NONE (-1)
+
+/* replaces openrl::Texture::create (Texture.h:69-93); row 0 = bottom row (GL) */
+int hr_texture_create(hr_ctx *ctx, const hr_texture_desc *desc, const void *pixels, hr_tex_id *out);
+int hr_texture_destroy(hr_ctx *ctx, hr_tex_id id);
+
+/* --------------------------------------------------------------- materials */
+
+#define HR_MAT_PBR 0   /* physicallyBased.rlsl */
+#define HR_MAT_GLASS 1 /* glass.rlsl           */
+
+/* shader permutation #defines become flag bits
+ * (PhysicallyBasedMaterial.cpp:57-110, GlassMaterial.cpp:50-77) */
+#define HR_MF_HAS_BASE_COLOR_TEXTURE (1u << 0)
+#define HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE (1u << 1)
+#define HR_MF_HAS_EMISSIVE_TEXTURE (1u << 2)
+#define HR_MF_HAS_NORMALMAP (1u << 3)
+#define HR_MF_HAS_CLEARCOAT_TEXTURE (1u << 4)
+#define HR_MF_HAS_CLEARCOAT_ROUGHNESS_TEXTURE (1u << 5)
+#define HR_MF_HAS_CLEARCOAT_NORMALMAP (1u << 6)
+#define HR_MF_DOUBLE_SIDED (1u << 7)
+#define HR_MF_ALPHA_MASK (1u << 8)
+#define HR_MF_VERTEX_COLORS (1u << 9)
+
+/* One material row == the ShaderParams uniform block AFTER host-side baking
+ * (PhysicallyBasedMaterial.cpp:16-36,127-191; GlassMaterial.cpp:15-28,88-126). */
+typedef struct hr_material {
+    int32_t type;
+    uint32_t flags;
+    hr_tex_id base_color_texture;
+    hr_tex_id metallic_roughness_texture;
+    hr_tex_id emissive_texture;
+    hr_tex_id normalmap;
+    hr_tex_id clear_coat_texture;
+    hr_tex_id clear_coat_roughness_texture;
+    hr_tex_id clear_coat_normalmap;
+    hr_tex_id multiscatter_lut;
+    float base_color[3];
+    float emissive_color[3];
+    float metallic;
+    float roughness;
+    float specular_f0;
+    float roughness_alpha;
+    float clear_coat;
+    float clear_coat_roughness;
+    float clear_coat_roughness_alpha;
+    float ior;     /* glass */
+    float density; /* glass */
+} hr_material;
+
+/* replaces Buffer::modify on the "Material" uniform block
+ * (PhysicallyBasedMaterial.cpp:190, GlassMaterial.cpp:125) */
+int hr_material_set(hr_ctx *ctx, int32_t material_id, const hr_material *m);
+
+/* ------------------------------------------------------------------ lights */
+
+/* Packed light blocks, mirroring ShaderLightingDefines.h:33-64 and
+ * lightDefines.rlsl:16-47 (RL primitive handles dropped: a light is
+ * addressed by (type,index)).  Colours are radiometric, directional
+ * `directions` point TO the light, spot angles are cosines (x inner, y outer). */
+typedef struct hr_lights {
+    int32_t n_directional;
+    float directional_directions[HR_MAX_DIRECTIONAL_LIGHTS][3];
+    float directional_colors[HR_MAX_DIRECTIONAL_LIGHTS][3];
+    int32_t n_point;
+    float point_positions[HR_MAX_POINT_LIGHTS][3];
+    float point_colors[HR_MAX_POINT_LIGHTS][3];
+    int32_t n_spot;
+    float spot_positions[HR_MAX_SPOT_LIGHTS][3];
+    float spot_directions[HR_MAX_SPOT_LIGHTS][3];
+    float spot_colors[HR_MAX_SPOT_LIGHTS][3];
+    float spot_angles[HR_MAX_SPOT_LIGHTS][2];
+    int32_t env_enabled;        /* EnvironmentLight.lightPrimitive != rl_NullPrimitive */
+    hr_tex_id env_texture;      /* lat/long map                                        */
+    float env_exposure;         /* 2^exposureCompensation (EnvironmentLight.cpp:95)    */
+    float env_theta_rotation;   /* radians                                             */
+} hr_lights;
+
+/* replaces Lighting::update* buffer maps (Scene/Lighting.cpp:192-381) */
+int hr_lights_set(hr_ctx *ctx, const hr_lights *lights);
+
+/* --------------------------------------------------------------- QMC tables */
+
+#define HR_SAMPLE_RANDOM 0     /* PassGenerator.h:103 — host tables only (std:: distributions) */
+#define HR_SAMPLE_HALTON 1
+#define HR_SAMPLE_HAMMERSLEY 2
+#define HR_SAMPLE_BLUE_NOISE 3 /* host tables only (sequential best-candidate) */
+#define HR_SAMPLE_SOBOL 4
+
+#define HR_BOKEH_CIRCULAR 0 /* radialSobol, Random.h:268-289 */
+#define HR_BOKEH_PENTAGON 1 /* randomPolygonal: host tables only */
+#define HR_BOKEH_HEXAGON 2
+#define HR_BOKEH_OCTAGON 3
+
+/* Upload host-generated tables.  replaces the RandomSequences /
+ * RandomSequenceMetadata / ApertureSamples uniform blocks
+ * (PassGenerator.cpp:603-684).  seq_xy, aperture_xy: n_seq*len vec2. */
+int hr_sequences_set(hr_ctx *ctx, const float *seq_xy, const float *aperture_xy, int32_t n_seq, int32_t len);
+/* replaces the SequenceOffsets uniform block (PassGenerator.cpp:150-159); n vec2 */
+int hr_seq_offsets_set(hr_ctx *ctx, const float *offsets_xy, int32_t n);
+
+/* Device-side generators for the Owen-scrambled sequences
+ * (util::sobol / halton / hammersley / radialSobol, Random.h:85-289).
+ * out_xy (host, count vec2) may be NULL when only the device table is wanted. */
+int hr_qmc_generate(hr_ctx *ctx, int32_t mode, uint32_t sequence_index, uint32_t count, int32_t radial,
+                    float *out_xy);
+/* generateRandomSequences(P, mode, bokeh) entirely on device (PassGenerator.cpp:603-684);
+ * HR_ERR_UNSUPPORTED for the host-only modes above. */
+int hr_sequences_generate(hr_ctx *ctx, int32_t sample_mode, int32_t bokeh_shape, int32_t len);
+/* generateSequenceOffsets(W,H) on device: sobol(W*H points, sequence 0) (PassGenerator.cpp:150-159) */
+int hr_seq_offsets_generate(hr_ctx *ctx);
+/* generateMultiScatterTexture on device (MultiScatterUtil.cpp:91-139): 128x128 R32F, out may be NULL.
+ * Returns the texture id holding the LUT in *out_tex (may be NULL). */
+int hr_multiscatter_lut_generate(hr_ctx *ctx, float *out_128x128, hr_tex_id *out_tex);
+
+/* ------------------------------------------------------------------- pass */
+
+/* Per-pass uniforms: the frame-program uniforms set in
+ * PassGenerator::runRenderFrameJob (PassGenerator.cpp:349-369) plus the
+ * Globals block (PassGenerator.h:269-294 / globalData.rlsl:9-34). */
+typedef struct hr_pass_params {
+    int32_t sample_index;      /* Globals.sampleIndex                           */
+    int32_t max_ray_depth;     /* Globals.maxRayDepth                           */
+    float max_channel_value;   /* Globals.maxChannelValue                       */
+    float fov_tan;             /* tan(fovY/2), PassGenerator.cpp:341-357        */
+    float aspect_ratio;
+    float focus_distance;
+    float aperture_radius;
+    float view_matrix[16];     /* camera -> world, column-major                 */
+    int32_t interactive_mode;  /* 3x3 block mode (perspective.rlsl:42-57)       */
+    int32_t block_size[2];
+    int32_t current_block_pixel[2];
+    float max_sample_index;    /* float(maxRenderPasses)                        */
+    int32_t enable_visualizer; /* Globals.enableVisualizer                      */
+    int32_t visualizer_mode;   /* HR_VIS_* (one-hot show* flags of Globals)     */
+    int32_t enable_accumulator_visualizer;
+    int32_t show_nans;
+    int32_t show_inf;
+} hr_pass_params;
+
+/* one-hot show* flags of GlobalData (PassGenerator.h:275-289) as an enum */
+#define HR_VIS_NONE 0
+#define HR_VIS_GEOMETRIC_NORMALS 1
+#define HR_VIS_UVS 2
+#define HR_VIS_TANGENTS 3
+#define HR_VIS_BITANGENTS 4
+#define HR_VIS_NORMALMAP 5
+#define HR_VIS_FINAL_NORMALS 6
+#define HR_VIS_BASE_COLOR 7
+#define HR_VIS_ROUGHNESS 8
+#define HR_VIS_METALLIC 9
+#define HR_VIS_EMISSIVE 10
+#define HR_VIS_CLEARCOAT 11
+#define HR_VIS_CLEARCOAT_ROUGHNESS 12
+#define HR_VIS_CLEARCOAT_NORMALMAP 13
+#define HR_VIS_SHADER 14
+
+/* Device-side counters.  OpenRL exposes the same kind of statistics
+ * (rl.h:346-355: RL_RENDER_FRAME_TIME, RL_EMITTED_RAY_COUNT). */
+typedef struct hr_pass_stats {
+    float ms;               /* hipEvent time of the pass (0 unless requested)       */
+    uint64_t paths;         /* primary rays generated                                */
+    uint64_t rays_closest;  /* closest-hit traversals launched                       */
+    uint64_t rays_any;      /* occlusion traversals launched                         */
+    uint64_t shaded_hits;   /* material shader invocations                           */
+    uint64_t accumulates;   /* accumulate() calls with RGB payload                   */
+    uint64_t node_visits;   /* BVH nodes fetched   (HR_CTX_COLLECT_STATS only)       */
+    uint64_t tri_tests;     /* triangle tests      (HR_CTX_COLLECT_STATS only)       */
+} hr_pass_stats;
+
+/* replaces rlClear(RL_COLOR_BUFFER_BIT) (PassGenerator.cpp:439) */
+int hr_clear(hr_ctx *ctx);
+/* replaces rlRenderFrame() (PassGenerator.cpp:386): one sample per owned pixel.
+ * Asynchronous on the ctx stream; stats (optional) are cumulative since the last
+ * hr_clear and are fetched with hr_get_stats. */
+int hr_render_pass(hr_ctx *ctx, const hr_pass_params *params);
+/* synchronises the stream, then copies the counters */
+int hr_get_stats(hr_ctx *ctx, hr_pass_stats *out);
+/* replaces PixelPackBuffer::setPixelData + mapPixelData (PixelPackBuffer.h:39-60):
+ * synchronous copy to a pinned host buffer owned by the ctx; the pointer stays
+ * valid until the next hr_readback / hr_frame_resize / hr_ctx_destroy. */
+int hr_readback(hr_ctx *ctx, const float **rgba, int32_t *width, int32_t *height);
+int hr_synchronize(hr_ctx *ctx);
+
+/* ------------------------------------------------------------------ debug */
+
+typedef struct hr_hit {
+    int32_t prim; /* global triangle index in submission order, -1 = miss */
+    float t, u, v;
+} hr_hit;
+
+/* Trace n caller-supplied rays (closest hit; any_hit != 0 -> occlusion query,
+ * prim = 0 blocked / -1 clear).  Used by the parity tests of the traversal
+ * against the oracle's brute-force intersector. */
+int hr_debug_trace(hr_ctx *ctx, int32_t n, const float *origins_xyz, const float *dirs_xyz, const float *tmax,
+                   const int32_t *skip_prim, int32_t any_hit, hr_hit *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRCORE_H */

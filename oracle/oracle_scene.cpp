@@ -1,0 +1,139 @@
+// oracle_scene.cpp — TEST INFRASTRUCTURE (CPU oracle).  Never linked into the product.
+//
+// Scene assembly: what OpenRL does with the buffers handed over by
+// Mesh::Mesh (/root/reference/Source/HeatrayRenderer/Scene/Mesh.cpp:29-153) and the
+// vertex shader (Resources/shaders/vertex.rlsl:25-43), plus texture sampling
+// (closed inside OpenRL; bilinear at LOD 0 is this oracle's stated assumption,
+// SURVEY §8a row a6).
+#include "oracle_internal.h"
+
+#include <cmath>
+
+namespace ora {
+
+static inline int wrapIndex(int i, int n, int mode)
+{
+    if (mode == HR_WRAP_CLAMP_TO_EDGE) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+    int m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+static inline vec4 texel(const Texture &t, int x, int y)
+{
+    const float *p = &t.px[((size_t)y * t.w + x) * t.c];
+    if (t.c == 1) return vec4{p[0], p[0], p[0], 1.0f}; // RL_LUMINANCE
+    if (t.c == 3) return vec4{p[0], p[1], p[2], 1.0f};
+    return vec4{p[0], p[1], p[2], p[3]};
+}
+
+// texture2D at LOD 0.  GL texel addressing: texel centres at (i + 0.5) / size.
+vec4 sampleTexture(const Texture &t, float u, float v)
+{
+    if (t.filter == HR_FILTER_NEAREST) {
+        int x = wrapIndex((int)floorf(u * (float)t.w), t.w, t.wrapS);
+        int y = wrapIndex((int)floorf(v * (float)t.h), t.h, t.wrapT);
+        return texel(t, x, y);
+    }
+    float x = u * (float)t.w - 0.5f;
+    float y = v * (float)t.h - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = wrapIndex((int)x0f, t.w, t.wrapS), x1 = wrapIndex((int)x0f + 1, t.w, t.wrapS);
+    int y0 = wrapIndex((int)y0f, t.h, t.wrapT), y1 = wrapIndex((int)y0f + 1, t.h, t.wrapT);
+    vec4 c00 = texel(t, x0, y0), c10 = texel(t, x1, y0), c01 = texel(t, x0, y1), c11 = texel(t, x1, y1);
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    vec4 r;
+    r.x = (c00.x * gx + c10.x * fx) * gy + (c01.x * gx + c11.x * fx) * fy;
+    r.y = (c00.y * gx + c10.y * fx) * gy + (c01.y * gx + c11.y * fx) * fy;
+    r.z = (c00.z * gx + c10.z * fx) * gy + (c01.z * gx + c11.z * fx) * fy;
+    r.w = (c00.w * gx + c10.w * fx) * gy + (c01.w * gx + c11.w * fx) * fy;
+    return r;
+}
+
+static inline vec3 fetch3(const std::vector<float> &a, uint32_t i) { return vec3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+
+void commitScene(Context &ctx)
+{
+    ctx.tris.clear();
+    ctx.attrs.clear();
+    for (const Geom &g : ctx.geoms) {
+        if (!g.alive) continue;
+        const bool strip = (g.mode == HR_TRIANGLE_STRIP);
+        const size_t nTri = strip ? (g.idx.size() >= 3 ? g.idx.size() - 2 : 0) : g.idx.size() / 3;
+        for (size_t t = 0; t < nTri; ++t) {
+            uint32_t i0, i1, i2;
+            if (strip) { // RL_TRIANGLE_STRIP, GL ordering: odd triangles swap the first two vertices
+                i0 = g.idx[t], i1 = g.idx[t + 1], i2 = g.idx[t + 2];
+                if (t & 1) {
+                    uint32_t s = i0;
+                    i0 = i1;
+                    i1 = s;
+                }
+            } else {
+                i0 = g.idx[3 * t], i1 = g.idx[3 * t + 1], i2 = g.idx[3 * t + 2];
+            }
+            const uint32_t id[3] = {i0, i1, i2};
+            // vertex.rlsl:27 — rl_Position = worldFromEntity * vec4(position, 1)
+            vec3 p[3];
+            for (int k = 0; k < 3; ++k) p[k] = xformPoint(g.world, fetch3(g.pos, id[k]));
+            Tri tri;
+            tri.v0 = p[0];
+            tri.e1 = p[1] - p[0];
+            tri.e2 = p[2] - p[0];
+            TriAttr a{};
+            a.material = g.material;
+            a.flags = (g.frontFaceCW ? TF_FRONT_CW : 0u) | (g.isOccluder ? 0u : TF_NON_OCCLUDER);
+            for (int k = 0; k < 3; ++k) {
+                // vertex.rlsl:28-29 — normal = mat3(worldFromEntity) * normalAttribute (no inverse-transpose)
+                a.n[k] = xformVector(g.world, fetch3(g.nrm, id[k]));
+                if (!g.uv.empty()) a.uv[k] = vec2{g.uv[2 * id[k]], g.uv[2 * id[k] + 1]};
+                if (!g.tan.empty() && !g.bit.empty()) { // vertex.rlsl:35-38
+                    a.tan[k] = xformVector(g.world, fetch3(g.tan, id[k]));
+                    a.bit[k] = xformVector(g.world, fetch3(g.bit, id[k]));
+                }
+                if (!g.col.empty()) a.col[k] = fetch3(g.col, id[k]); // vertex.rlsl:40-42
+            }
+            if (!g.uv.empty()) a.flags |= TF_HAS_UV;
+            if (!g.tan.empty() && !g.bit.empty()) a.flags |= TF_HAS_TANGENTS;
+            if (!g.col.empty()) a.flags |= TF_HAS_COLORS;
+            ctx.tris.push_back(tri);
+            ctx.attrs.push_back(a);
+        }
+    }
+    // Scene bounds over every triangle vertex; self-intersection epsilon.
+    vec3 lo(INFINITY), hi(-INFINITY);
+    for (const Tri &t : ctx.tris) {
+        const vec3 p[3] = {t.v0, t.v0 + t.e1, t.v0 + t.e2};
+        for (int k = 0; k < 3; ++k) {
+            lo = min3(lo, p[k]);
+            hi = max3(hi, p[k]);
+        }
+    }
+    if (ctx.tris.empty()) lo = hi = vec3(0.0f);
+    ctx.aabbLo[0] = lo.x, ctx.aabbLo[1] = lo.y, ctx.aabbLo[2] = lo.z;
+    ctx.aabbHi[0] = hi.x, ctx.aabbHi[1] = hi.y, ctx.aabbHi[2] = hi.z;
+    ctx.rayEps = 1e-4f * length(hi - lo);
+    buildLBVH(ctx.tris, ctx.bvh);
+    ctx.committed = true;
+}
+
+// physicallyBased.rlsl:57-91 as seen by an occlusion ray on a non-occluder (alpha-masked)
+// primitive: alpha < 1 lets the ray continue, otherwise the ray is shadowed.
+bool alphaPasses(const Context &ctx, int prim, float u, float v)
+{
+    const TriAttr &a = ctx.attrs[prim];
+    if (a.material < 0 || a.material >= (int)ctx.materials.size()) return false;
+    const hr_material &m = ctx.materials[a.material];
+    if (m.type != HR_MAT_PBR || !(m.flags & HR_MF_ALPHA_MASK)) return false;
+    float alpha = 1.0f;
+    if ((m.flags & HR_MF_HAS_BASE_COLOR_TEXTURE) && m.base_color_texture >= 0 &&
+        m.base_color_texture < (int)ctx.textures.size() && ctx.textures[m.base_color_texture].alive) {
+        float w = 1.0f - u - v;
+        float tu = a.uv[0].x * w + a.uv[1].x * u + a.uv[2].x * v;
+        float tv = a.uv[0].y * w + a.uv[1].y * u + a.uv[2].y * v;
+        alpha = sampleTexture(ctx.textures[m.base_color_texture], tu, tv).w;
+    }
+    return alpha < 1.0f;
+}
+
+} // namespace ora

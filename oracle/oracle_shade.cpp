@@ -1,0 +1,938 @@
+// oracle_shade.cpp — TEST INFRASTRUCTURE (CPU oracle).  Never linked into the product.
+//
+// Scalar restatement of the RLSL shaders OpenRL runs inside rlRenderFrame()
+// (/root/reference/Source/HeatrayRenderer/PassGenerator.cpp:386).  Every function cites
+// the shader text it follows (paths relative to /root/reference/Resources/shaders).
+// One path per owned pixel per pass; per pixel the framebuffer adds happen in the
+// order  A+=1, then for each bounce: emissive, NEE light, (miss) environment —
+// the order the HIP wavefront loop reproduces.
+#include "oracle_internal.h"
+
+#include <cmath>
+#include <omp.h>
+
+namespace ora {
+
+enum MissKind { MISS_NONE = 0, MISS_ENV = 1, MISS_DIR = 2, MISS_POINT = 3, MISS_SPOT = 4 };
+// lightDefines.rlsl:13-16
+enum { LIGHT_TYPE_DIRECTIONAL = 1, LIGHT_TYPE_POINT = 2, LIGHT_TYPE_SPOT = 3, LIGHT_TYPE_ENVIRONMENT = 4 };
+
+// rayAttributes.rlsl:8-11 + the built-in ray fields the shaders touch
+struct Ray {
+    vec3 o, d;
+    float maxT = INFINITY;
+    vec3 weight;
+    int sequenceID = 0, sequenceIndexOffset = 0;
+    float extraT = 0.0f;
+    int depth = 0;
+    bool occlusionTest = false;
+    int missKind = MISS_NONE, missIdx = 0; // rl_OutRay.defaultPrimitive
+    int srcPrim = -1;
+    bool valid = false;
+};
+
+struct Shader {
+    Context &ctx;
+    const hr_pass_params &pp;
+    float *px; // RGBA of the pixel being shaded
+    hr_pass_stats &st;
+    TraceCounters tc;
+
+    Shader(Context &c, const hr_pass_params &p, float *pixel, hr_pass_stats &s) : ctx(c), pp(p), px(pixel), st(s) {}
+
+    // ---- sequence.rlsl:18-28 ----
+    vec2 getSequenceValue(int sequenceIndex, int sampleIndex) const
+    {
+        int ws = sequenceIndex % ctx.nSeq;
+        int wv = sampleIndex % ctx.seqLen;
+        return ctx.seq[(size_t)ws * ctx.seqLen + wv];
+    }
+
+    // ---- accumulator.rlsl:12-28 ----
+    void accumulate3(vec3 c)
+    {
+        px[0] = px[0] + c.x;
+        px[1] = px[1] + c.y;
+        px[2] = px[2] + c.z;
+        st.accumulates++;
+    }
+    void accumulate4(vec3 c, float a) // accumulate(vec4) used by the debug visualisers
+    {
+        accumulate3(c);
+        px[3] = px[3] + a;
+    }
+    void performAccumulate(vec3 color)
+    {
+        vec3 value(0.0f);
+        if (pp.enable_accumulator_visualizer == 1) {
+            if (pp.show_nans == 1) {
+                bool any = (color.x != color.x) || (color.y != color.y) || (color.z != color.z);
+                value = any ? vec3(100.0f) : (min3(color, vec3(1.0f)) * 0.1f);
+            } else if (pp.show_inf == 1) {
+                bool any = std::isinf(color.x) || std::isinf(color.y) || std::isinf(color.z);
+                value = any ? vec3(100.0f) : (min3(color, vec3(1.0f)) * 0.1f);
+            }
+        } else {
+            value = min3(vec3(pp.max_channel_value), color);
+        }
+        accumulate3(value);
+    }
+
+    vec4 tex(int id, vec2 uv) const
+    {
+        if (id < 0 || id >= (int)ctx.textures.size() || !ctx.textures[id].alive) return vec4{1.0f, 1.0f, 1.0f, 1.0f}; // dummy white texel (Texture.h:188-203)
+        return sampleTexture(ctx.textures[id], uv.x, uv.y);
+    }
+
+    // ---- light shaders run when an occlusion ray reaches its light / a ray misses ----
+    // environmentLight.rlsl:19-34
+    void environmentLight(vec3 dir, vec3 weight)
+    {
+        float theta = atan2_(dir.x, -dir.z) + ctx.lights.env_theta_rotation;
+        if (theta > kTwoPI) theta = theta - kTwoPI;
+        float phi = atan2_(dir.y, sqrtf(dir.x * dir.x + dir.z * dir.z));
+        float u = (theta / kTwoPI) + 0.5f;
+        float v = (-phi * kOneOverPI) + 0.5f;
+        vec4 t = vec4{0.0f, 0.0f, 0.0f, 0.0f};
+        int id = ctx.lights.env_texture;
+        if (id >= 0 && id < (int)ctx.textures.size() && ctx.textures[id].alive) t = sampleTexture(ctx.textures[id], u, 1.0f - v);
+        vec3 sample = vec3(t.x, t.y, t.z) * ctx.lights.env_exposure;
+        performAccumulate(weight * sample);
+    }
+    // directionalLight.rlsl:20-26, pointLight.rlsl:20-29, spotLight.rlsl:20-36
+    void lightShader(const Ray &r, float intersectionT)
+    {
+        const hr_lights &L = ctx.lights;
+        switch (r.missKind) {
+        case MISS_ENV:
+            environmentLight(r.d, r.weight);
+            break;
+        case MISS_DIR: {
+            const float *c = L.directional_colors[r.missIdx];
+            performAccumulate(r.weight * vec3(c[0], c[1], c[2]));
+            break;
+        }
+        case MISS_POINT: {
+            float s = intersectionT + r.extraT;
+            float attenuation = 1.0f / (s * s);
+            const float *c = L.point_colors[r.missIdx];
+            performAccumulate(r.weight * vec3(c[0], c[1], c[2]) * attenuation);
+            break;
+        }
+        case MISS_SPOT: {
+            const float *sd = L.spot_directions[r.missIdx];
+            float rayAngle = dot(-r.d, vec3(sd[0], sd[1], sd[2]));
+            if (rayAngle >= 0.0f) {
+                float s = intersectionT + r.extraT;
+                float attenuation = 1.0f / (s * s);
+                const float *c = L.spot_colors[r.missIdx];
+                vec3 result = r.weight * vec3(c[0], c[1], c[2]) * attenuation;
+                result = result * (1.0f - smoothstep(L.spot_angles[r.missIdx][0], L.spot_angles[r.missIdx][1], rayAngle));
+                performAccumulate(result);
+            }
+            break;
+        }
+        default:
+            break;
+        }
+    }
+
+    // ---- utility.rlsl ----
+    static float square(float x) { return x * x; }
+    static float getSign(float x) { return x < 0.0f ? -1.0f : 1.0f; }               // :35-38
+    static float pow5(float x) { return x * square(x) * square(x); }                // :141-144
+    static float greaterThanZero(float f) { return fmax_(1e-5f, f); }               // :153-156
+    static float luminosity(vec3 c) { return dot(c, vec3(0.33f, 0.59f, 0.11f)); }   // :163-166
+    static mat3 orthonormalFrame(vec3 N)                                            // :43-60
+    {
+        vec3 lh(N.x, N.z, N.y);
+        float s = getSign(lh.z);
+        float a = -1.0f / (s + lh.z);
+        float b = lh.x * lh.y * a;
+        vec3 X(1.0f + s * lh.x * lh.x * a, s * b, -s * lh.x);
+        vec3 Z(b, s + lh.y * lh.y * a, -lh.y);
+        mat3 m;
+        m.c0 = vec3(X.x, X.z, X.y);
+        m.c1 = N;
+        m.c2 = vec3(Z.x, Z.z, Z.y);
+        return m;
+    }
+    static vec3 cosineWeightedSample(float u1, float u2) // :64-75
+    {
+        float theta = sqrtf(u1);
+        float phi = kTwoPI * u2;
+        float s, c;
+        sincos_(phi, &s, &c);
+        float x = theta * c;
+        float y = sqrtf(fmax_(0.0f, 1.0f - u1));
+        float z = theta * s;
+        return normalize(vec3(x, y, z));
+    }
+    static vec3 sampleVisibleGGX(vec3 localSpaceV, float u1, float u2, float roughnessAlpha) // :109-139
+    {
+        vec3 zUpV(localSpaceV.x, localSpaceV.z, localSpaceV.y);
+        vec3 Vh = normalize(vec3(zUpV.x * roughnessAlpha, zUpV.y * roughnessAlpha, zUpV.z));
+        float lengthSquared = (Vh.x * Vh.x) + (Vh.y * Vh.y);
+        vec3 T1 = (lengthSquared > 0.0f) ? vec3(-Vh.y, Vh.x, 0.0f) * inversesqrt(lengthSquared) : vec3(1.0f, 0.0f, 0.0f);
+        vec3 T2 = cross(Vh, T1);
+        float r = sqrtf(u1);
+        float phi = kTwoPI * u2;
+        float sn, cs;
+        sincos_(phi, &sn, &cs);
+        float t1 = r * cs;
+        float t2 = r * sn;
+        float s = 0.5f * (1.0f + Vh.z);
+        float t1Squared = square(t1);
+        t2 = (1.0f - s) * sqrtf(1.0f - t1Squared) + (s * t2);
+        vec3 Nh = (t1 * T1) + (t2 * T2) + sqrtf(fmax_(0.0f, 1.0f - t1Squared - square(t2))) * Vh;
+        vec3 zUp = normalize(vec3(roughnessAlpha * Nh.x, roughnessAlpha * Nh.y, fmax_(0.0f, Nh.z)));
+        return vec3(zUp.x, zUp.z, zUp.y);
+    }
+
+    // ---- brdfs.rlsl ----
+    static vec3 F_Schlick(vec3 Cspec, float cosTheta) { return Cspec + (vec3(1.0f) - Cspec) * pow5(1.0f - cosTheta); } // :46-50
+    static float F_Schlick(float f0, float cosTheta) { return f0 + (1.0f - f0) * pow5(1.0f - cosTheta); }             // :53-57
+    static float F_Fresnel(float eta, float cosThetaI)                                                                // :59-71
+    {
+        float sinThetaT2 = square(eta) * (1.0f - square(cosThetaI));
+        if (sinThetaT2 < 1.0f) {
+            float cosThetaT = sqrtf(1.0f - sinThetaT2);
+            float perpendicular = square((eta * cosThetaI - cosThetaT) / (eta * cosThetaI + cosThetaT));
+            float parallel = square((cosThetaI - eta * cosThetaT) / (cosThetaI + eta * cosThetaT));
+            return 0.5f * (perpendicular + parallel);
+        }
+        return 1.0f;
+    }
+    static float D_GGX(float NdotH, float roughnessAlpha) // :73-78
+    {
+        float alpha2 = square(roughnessAlpha);
+        float denominator = square(square(NdotH) * (alpha2 - 1.0f) + 1.0f);
+        return kOneOverPI * (alpha2 / greaterThanZero(denominator));
+    }
+    static float G1_Smith_GGX(float NdotI, float roughnessAlpha) // :88-93
+    {
+        float alpha2 = square(roughnessAlpha);
+        float denom = sqrtf(alpha2 + (1.0f - alpha2) * greaterThanZero(square(NdotI))) + NdotI;
+        return (2.0f * NdotI) / greaterThanZero(denom);
+    }
+    static float G2_Smith_GGX(float NdotO, float NdotI, float roughnessAlpha) // :95-98
+    {
+        return G1_Smith_GGX(NdotO, roughnessAlpha) * G1_Smith_GGX(NdotI, roughnessAlpha);
+    }
+
+    // ---- lightSampling.rlsl:11-161 ----
+    struct LightSample {
+        vec3 dir;
+        int missKind = MISS_NONE, missIdx = 0;
+        float probability = 0.0f;
+        float maxDistance = INFINITY;
+        int type = 0;
+    };
+    LightSample computeLightSample(vec3 N, float lightProbability, vec3 P) const
+    {
+        const hr_lights &L = ctx.lights;
+        LightSample out;
+        float probabilitySum = 0.0f;
+        float directional[HR_MAX_DIRECTIONAL_LIGHTS] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < HR_MAX_DIRECTIONAL_LIGHTS; ++i) {
+            if (i < L.n_directional) {
+                const float *d = L.directional_directions[i], *c = L.directional_colors[i];
+                directional[i] = saturate(dot(N, vec3(d[0], d[1], d[2]))) * luminosity(vec3(c[0], c[1], c[2]));
+                probabilitySum += directional[i];
+            }
+        }
+        float point[HR_MAX_POINT_LIGHTS] = {0, 0, 0, 0, 0};
+        vec3 pointDirs[HR_MAX_POINT_LIGHTS];
+        for (int i = 0; i < HR_MAX_POINT_LIGHTS; ++i) {
+            if (i < L.n_point) {
+                const float *p = L.point_positions[i], *c = L.point_colors[i];
+                pointDirs[i] = normalize(vec3(p[0], p[1], p[2]) - P);
+                point[i] = saturate(dot(N, pointDirs[i])) * luminosity(vec3(c[0], c[1], c[2]));
+                probabilitySum += point[i];
+            }
+        }
+        float spot[HR_MAX_SPOT_LIGHTS] = {0, 0, 0, 0, 0};
+        vec3 spotDirs[HR_MAX_SPOT_LIGHTS];
+        for (int i = 0; i < HR_MAX_SPOT_LIGHTS; ++i) {
+            if (i < L.n_spot) {
+                const float *p = L.spot_positions[i], *c = L.spot_colors[i], *sd = L.spot_directions[i];
+                spotDirs[i] = normalize(vec3(p[0], p[1], p[2]) - P);
+                float rayAngle = dot(vec3(sd[0], sd[1], sd[2]), -spotDirs[i]);
+                spot[i] = saturate(dot(N, spotDirs[i])) * luminosity(vec3(c[0], c[1], c[2])) * ((rayAngle > 0.0f) ? 1.0f : 0.0f) *
+                          ((rayAngle < L.spot_angles[i][1]) ? 0.0f : 1.0f) *
+                          (1.0f - smoothstep(L.spot_angles[i][0], L.spot_angles[i][1], rayAngle));
+                probabilitySum += spot[i];
+            }
+        }
+        float environment = 0.0f;
+        if (L.env_enabled) {
+            environment = 50.0f * L.env_exposure;
+            probabilitySum += environment;
+        }
+        float norm = 1.0f / greaterThanZero(probabilitySum);
+        environment *= norm;
+        for (int i = 0; i < HR_MAX_DIRECTIONAL_LIGHTS; ++i) directional[i] *= norm;
+        for (int i = 0; i < HR_MAX_POINT_LIGHTS; ++i) point[i] *= norm;
+        for (int i = 0; i < HR_MAX_SPOT_LIGHTS; ++i) spot[i] *= norm;
+
+        float currentProbability = 0.0f;
+        for (int i = 0; i < HR_MAX_DIRECTIONAL_LIGHTS; ++i) {
+            if (i < L.n_directional) {
+                currentProbability += directional[i];
+                if (directional[i] > 0.0f && lightProbability <= currentProbability) {
+                    const float *d = L.directional_directions[i];
+                    out.dir = vec3(d[0], d[1], d[2]);
+                    out.missKind = MISS_DIR, out.missIdx = i;
+                    out.probability = directional[i];
+                    out.type = LIGHT_TYPE_DIRECTIONAL;
+                    return out;
+                }
+            }
+        }
+        for (int i = 0; i < HR_MAX_POINT_LIGHTS; ++i) {
+            if (i < L.n_point) {
+                currentProbability += point[i];
+                if (point[i] > 0.0f && lightProbability <= currentProbability) {
+                    const float *p = L.point_positions[i];
+                    out.dir = pointDirs[i];
+                    out.missKind = MISS_POINT, out.missIdx = i;
+                    out.probability = point[i];
+                    out.maxDistance = length(vec3(p[0], p[1], p[2]) - P);
+                    out.type = LIGHT_TYPE_POINT;
+                    return out;
+                }
+            }
+        }
+        for (int i = 0; i < HR_MAX_SPOT_LIGHTS; ++i) {
+            if (i < L.n_spot) {
+                currentProbability += spot[i];
+                if (spot[i] > 0.0f && lightProbability <= currentProbability) {
+                    const float *p = L.spot_positions[i];
+                    out.dir = spotDirs[i];
+                    out.missKind = MISS_SPOT, out.missIdx = i;
+                    out.probability = spot[i];
+                    out.maxDistance = length(vec3(p[0], p[1], p[2]) - P);
+                    out.type = LIGHT_TYPE_SPOT;
+                    return out;
+                }
+            }
+        }
+        out.type = LIGHT_TYPE_ENVIRONMENT;
+        out.probability = environment;
+        return out;
+    }
+
+    // createRay(): the child inherits every attribute of rl_InRay, starts at the hit point,
+    // depth + 1 (SURVEY §8a a6 [assumed]).
+    static Ray createRay(const Ray &in, vec3 P, int prim)
+    {
+        Ray r = in;
+        r.o = P;
+        r.depth = in.depth + 1;
+        r.srcPrim = prim;
+        r.valid = true;
+        return r;
+    }
+    // An "environment" branch with the environment light removed would emit a second
+    // non-occlusion ray (lightSampling.rlsl:157-160 + microfacet.rlsl:47); it can only
+    // happen for a sample value of exactly 0 and is dropped.
+    void emit(Ray r, Ray &nee, Ray &next)
+    {
+        if (r.occlusionTest)
+            nee = r;
+        else
+            next = r;
+    }
+
+    // ---- microfacet.rlsl ----
+    vec3 computeMultiscattering(int lut, vec3 Cspec, float NdotI, float roughness) const // :17-23
+    {
+        float ms = 0.0f;
+        if (lut >= 0 && lut < (int)ctx.textures.size() && ctx.textures[lut].alive) ms = sampleTexture(ctx.textures[lut], NdotI, roughness).x;
+        return vec3(1.0f) + Cspec * ms;
+    }
+    void indirectDiffuseSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 Cdiff, float sampleProbability, float optionalLightSampleProbability,
+                               vec2 rand, const mat3 &frame, int missKind, Ray &nee, Ray &next) // :25-50
+    {
+        vec3 dir = cosineWeightedSample(rand.x, rand.y);
+        vec3 O = mul(frame, dir);
+        float NdotO = dot(N, O);
+        if (NdotO > 0.0f) {
+            vec3 reflectance = Cdiff;
+            reflectance = reflectance * in.weight;
+            reflectance = reflectance / sampleProbability;
+            reflectance = reflectance / optionalLightSampleProbability;
+            if (dot(reflectance, reflectance) > 1e-5f) {
+                Ray r = createRay(in, P, prim);
+                r.d = O;
+                r.weight = reflectance;
+                r.occlusionTest = (missKind != MISS_NONE);
+                r.missKind = missKind, r.missIdx = 0;
+                r.extraT = 0.0f;
+                if (missKind == MISS_ENV && !ctx.lights.env_enabled) return;
+                emit(r, nee, next);
+            }
+        }
+    }
+    void directDiffuseSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 Cdiff, float sampleProbability, float lightProbability, vec2 rand,
+                             const mat3 &frame, Ray &nee, Ray &next) // :52-98
+    {
+        LightSample ls = computeLightSample(N, lightProbability, P);
+        if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
+            float NdotO = dot(N, ls.dir);
+            if (NdotO > 0.0f) {
+                NdotO = saturate(NdotO);
+                vec3 diffuse = (Cdiff / kPI) * NdotO;
+                vec3 reflectance = diffuse;
+                reflectance = reflectance * in.weight;
+                reflectance = reflectance / sampleProbability;
+                reflectance = reflectance / ls.probability;
+                if (dot(reflectance, reflectance) > 1e-5f) {
+                    Ray r = createRay(in, P, prim);
+                    r.d = ls.dir;
+                    r.weight = reflectance;
+                    r.occlusionTest = true;
+                    r.missKind = ls.missKind, r.missIdx = ls.missIdx;
+                    r.extraT = 0.0f;
+                    if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
+                    emit(r, nee, next);
+                }
+            }
+        } else if (ls.probability > 0.0f) {
+            indirectDiffuseSample(in, P, prim, N, Cdiff, sampleProbability, ls.probability, rand, frame, MISS_ENV, nee, next);
+        }
+    }
+    void indirectSpecularSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut,
+                                float roughness, float sampleProbability, float optionalLightSampleProbability, vec2 rand, const mat3 &frame,
+                                int missKind, Ray &nee, Ray &next) // :100-151
+    {
+        vec3 localSpaceI = mulT(frame, I);
+        vec3 H = mul(frame, sampleVisibleGGX(localSpaceI, rand.x, rand.y, roughnessAlpha));
+        float IdotH = saturate(dot(I, H));
+        vec3 O = normalize(2.0f * IdotH * H - I);
+        float NdotO = dot(N, O);
+        if (NdotO > 0.0f) {
+            NdotO = saturate(NdotO);
+            vec3 F = F_Schlick(Cspec, IdotH);
+            float G2 = G2_Smith_GGX(NdotI, NdotO, roughnessAlpha);
+            float G1 = G1_Smith_GGX(NdotI, roughnessAlpha);
+            vec3 specular = (F * G2) / greaterThanZero(G1);
+            specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+            vec3 reflectance = specular;
+            reflectance = reflectance * in.weight;
+            reflectance = reflectance / sampleProbability;
+            reflectance = reflectance / optionalLightSampleProbability;
+            if (dot(reflectance, reflectance) > 1e-5f) {
+                Ray r = createRay(in, P, prim);
+                r.d = O;
+                r.weight = reflectance;
+                r.occlusionTest = (missKind != MISS_NONE);
+                r.missKind = missKind, r.missIdx = 0;
+                r.extraT = 0.0f;
+                if (missKind == MISS_ENV && !ctx.lights.env_enabled) return;
+                emit(r, nee, next);
+            }
+        }
+    }
+    void directSpecularSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut,
+                              float roughness, float sampleProbability, float lightProbability, vec2 rand, const mat3 &frame, Ray &nee,
+                              Ray &next) // :153-220
+    {
+        LightSample ls = computeLightSample(N, lightProbability, P);
+        if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
+            float NdotO = dot(N, ls.dir);
+            if (NdotO > 0.0f) {
+                NdotO = saturate(NdotO);
+                vec3 H = normalize(I + ls.dir);
+                float NdotH = saturate(dot(N, H));
+                float IdotH = saturate(dot(I, H));
+                float D = D_GGX(NdotH, roughnessAlpha);
+                vec3 F = F_Schlick(Cspec, IdotH);
+                float G = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha);
+                vec3 specular = (D * F * G) / greaterThanZero(4.0f * NdotI);
+                specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+                vec3 reflectance = specular;
+                reflectance = reflectance * in.weight;
+                reflectance = reflectance / sampleProbability;
+                reflectance = reflectance / ls.probability;
+                if (dot(reflectance, reflectance) > 1e-5f) {
+                    Ray r = createRay(in, P, prim);
+                    r.d = ls.dir;
+                    r.weight = reflectance;
+                    r.occlusionTest = true;
+                    r.missKind = ls.missKind, r.missIdx = ls.missIdx;
+                    r.extraT = 0.0f;
+                    if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
+                    emit(r, nee, next);
+                }
+            }
+        } else if (ls.probability > 0.0f) {
+            indirectSpecularSample(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame,
+                                   MISS_ENV, nee, next);
+        }
+    }
+
+    // Barycentric interpolation of a varying: a0*(1-u-v) + a1*u + a2*v
+    static vec3 lerp3(const vec3 *a, float w, float u, float v) { return a[0] * w + a[1] * u + a[2] * v; }
+
+    struct Surface {
+        vec3 P, normal, tangent, bitangent, color;
+        vec2 uv;
+        bool frontFacing;
+    };
+    Surface surface(const Ray &in, const Hit &h) const
+    {
+        const TriAttr &a = ctx.attrs[h.prim];
+        const Tri &tr = ctx.tris[h.prim];
+        Surface s;
+        float w = 1.0f - h.u - h.v;
+        s.P = in.o + in.d * h.t; // rl_IntersectionPoint
+        s.normal = lerp3(a.n, w, h.u, h.v);
+        s.uv = vec2{a.uv[0].x * w + a.uv[1].x * h.u + a.uv[2].x * h.v, a.uv[0].y * w + a.uv[1].y * h.u + a.uv[2].y * h.v};
+        s.tangent = lerp3(a.tan, w, h.u, h.v);
+        s.bitangent = lerp3(a.bit, w, h.u, h.v);
+        s.color = lerp3(a.col, w, h.u, h.v);
+        // rl_FrontFacing: counter-clockwise winding seen from the ray origin, flipped for
+        // primitives submitted with rlFrontFace(RL_CW) (Mesh.cpp:86-91).  det of
+        // Möller–Trumbore = -dot(d, cross(e1, e2)).
+        float det = dot(tr.e1, cross(in.d, tr.e2));
+        bool ccwFront = det > 0.0f;
+        s.frontFacing = (a.flags & TF_FRONT_CW) ? !ccwFront : ccwFront;
+        return s;
+    }
+
+    // ---- physicallyBased.rlsl:55-331 ----
+    void physicallyBased(const Ray &inRay, const Hit &h, const hr_material &M, Ray &nee, Ray &next)
+    {
+        Ray in = inRay;
+        const TriAttr &attr = ctx.attrs[h.prim];
+        Surface sf = surface(in, h);
+        const uint32_t F = M.flags;
+        const bool hasTextures = (F & (HR_MF_HAS_BASE_COLOR_TEXTURE | HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE | HR_MF_HAS_EMISSIVE_TEXTURE |
+                                       HR_MF_HAS_NORMALMAP | HR_MF_HAS_CLEARCOAT_TEXTURE | HR_MF_HAS_CLEARCOAT_ROUGHNESS_TEXTURE |
+                                       HR_MF_HAS_CLEARCOAT_NORMALMAP)) != 0;
+        const bool useTangentSpace = (F & (HR_MF_HAS_NORMALMAP | HR_MF_HAS_CLEARCOAT_NORMALMAP)) != 0;
+        vec3 baseColor(M.base_color[0], M.base_color[1], M.base_color[2]);
+        float alpha = 1.0f;
+        if (F & HR_MF_HAS_BASE_COLOR_TEXTURE) { // :59-65
+            vec4 s = tex(M.base_color_texture, sf.uv);
+            baseColor = baseColor * vec3(s.x, s.y, s.z);
+            alpha = s.w;
+        }
+        if ((F & HR_MF_VERTEX_COLORS) && (attr.flags & TF_HAS_COLORS)) baseColor = baseColor * sf.color; // :66-68
+        if (F & HR_MF_ALPHA_MASK) { // :70-91 (occlusion rays are resolved inside traceOccluded)
+            if (alpha < 1.0f) {
+                next = createRay(in, sf.P, h.prim);
+                return;
+            }
+        }
+        vec3 N = normalize(sf.normal); // :93
+        if (F & HR_MF_DOUBLE_SIDED) { // :95-108
+            if (!sf.frontFacing) N = -N;
+        } else if (!sf.frontFacing) {
+            next = createRay(in, sf.P, h.prim);
+            return;
+        }
+        vec3 clearCoatN = N;
+        if (F & HR_MF_HAS_NORMALMAP) { // :112-118
+            mat3 nt{normalize(sf.tangent), normalize(sf.bitangent), N};
+            vec4 s = tex(M.normalmap, sf.uv);
+            vec3 normalTS = vec3(s.x, s.y, s.z) * 2.0f - vec3(1.0f);
+            N = normalize(mul(nt, normalTS));
+        }
+        if (F & HR_MF_HAS_CLEARCOAT_NORMALMAP) { // :120-126
+            mat3 nt{normalize(sf.tangent), normalize(sf.bitangent), clearCoatN};
+            vec4 s = tex(M.clear_coat_normalmap, sf.uv);
+            vec3 normalTS = vec3(s.x, s.y, s.z) * 2.0f - vec3(1.0f);
+            clearCoatN = normalize(mul(nt, normalTS));
+        }
+        mat3 frame = orthonormalFrame(N); // :128
+        vec3 V = -in.d;
+        float NdotV = saturate(dot(N, V));
+        float metallic = M.metallic, roughness = M.roughness, roughnessAlpha = M.roughness_alpha;
+        if (F & HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE) { // :135-140  (.bg swizzle: r <- blue, g <- green)
+            vec4 s = tex(M.metallic_roughness_texture, sf.uv);
+            metallic = metallic * s.z;
+            roughness = roughness * s.y;
+            roughnessAlpha = roughness * roughness;
+        }
+        float clearCoat = M.clear_coat, clearCoatRoughness = M.clear_coat_roughness, clearCoatRoughnessAlpha = M.clear_coat_roughness_alpha;
+        if (F & HR_MF_HAS_CLEARCOAT_TEXTURE) clearCoat = clearCoat * tex(M.clear_coat_texture, sf.uv).x; // :145-147
+        if (F & HR_MF_HAS_CLEARCOAT_ROUGHNESS_TEXTURE) { // :148-151
+            clearCoatRoughness = clearCoatRoughness * tex(M.clear_coat_roughness_texture, sf.uv).x;
+            clearCoatRoughnessAlpha = clearCoatRoughness * clearCoatRoughness;
+        }
+        vec3 emissive(M.emissive_color[0], M.emissive_color[1], M.emissive_color[2]);
+        if (F & HR_MF_HAS_EMISSIVE_TEXTURE) { // :154-156
+            vec4 s = tex(M.emissive_texture, sf.uv);
+            emissive = vec3(s.x, s.y, s.z);
+        }
+        if (pp.enable_visualizer == 1) { // :158-203
+            switch (pp.visualizer_mode) {
+            case HR_VIS_GEOMETRIC_NORMALS: accumulate4((sf.normal + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_UVS: if (hasTextures) accumulate4(vec3(sf.uv.x, sf.uv.y, 0.0f), 1.0f); break;
+            case HR_VIS_TANGENTS: if (hasTextures && useTangentSpace) accumulate4((sf.tangent + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_BITANGENTS: if (hasTextures && useTangentSpace) accumulate4((sf.bitangent + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_NORMALMAP:
+                if (F & HR_MF_HAS_NORMALMAP) {
+                    vec4 s = tex(M.normalmap, sf.uv);
+                    accumulate4(vec3(s.x, s.y, s.z), 1.0f);
+                }
+                break;
+            case HR_VIS_FINAL_NORMALS: accumulate4((N + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_BASE_COLOR: accumulate4(baseColor, 1.0f); break;
+            case HR_VIS_EMISSIVE: accumulate4(emissive, 1.0f); break;
+            case HR_VIS_ROUGHNESS: accumulate4(vec3(roughness), 1.0f); break;
+            case HR_VIS_METALLIC: accumulate4(vec3(metallic), 1.0f); break;
+            case HR_VIS_CLEARCOAT: accumulate4(vec3(clearCoat), 1.0f); break;
+            case HR_VIS_CLEARCOAT_ROUGHNESS: accumulate4(vec3(clearCoatRoughness), 1.0f); break;
+            case HR_VIS_SHADER: accumulate4(vec3(1.0f, 0.0f, 0.0f), 1.0f); break;
+            case HR_VIS_CLEARCOAT_NORMALMAP:
+                if (F & HR_MF_HAS_CLEARCOAT_NORMALMAP) {
+                    vec4 s = tex(M.clear_coat_normalmap, sf.uv);
+                    accumulate4(vec3(s.x, s.y, s.z), 1.0f);
+                }
+                break;
+            default: break;
+            }
+            return;
+        }
+        performAccumulate(in.weight * emissive); // :205
+        float clearCoatNdotV = saturate(dot(clearCoatN, V));
+        float clearCoatF = F_Schlick(0.04f, clearCoatNdotV); // :210
+        float clearCoatScale = clearCoatF * clearCoat;
+        float clearCoatBottomLayerScale = 1.0f - clearCoatScale;
+        vec3 Cdiff = (baseColor * (1.0f - metallic)) * clearCoatBottomLayerScale;                            // :214
+        vec3 Cspec = mix(vec3(M.specular_f0), baseColor, vec3(metallic)) * clearCoatBottomLayerScale;        // :220
+        float diffuseLuminance = luminosity(Cdiff);
+        float specularLuminance = luminosity(Cspec);
+        float probabilityNormalization = 1.0f / greaterThanZero(diffuseLuminance + specularLuminance + clearCoatScale);
+        float diffuseProbability = diffuseLuminance * probabilityNormalization;
+        float specularProbability = specularLuminance * probabilityNormalization;
+        float clearCoatProbability = clearCoatScale * probabilityNormalization;
+        // clearCoatFrame (:230-233) is computed but never used by the shader.
+
+        const int si = pp.sample_index + in.sequenceIndexOffset;
+        { // direct lighting :236-273
+            vec2 rand = getSequenceValue(in.sequenceID + in.depth, si);
+            vec2 probability = getSequenceValue(in.sequenceID + in.depth + 1, si);
+            if (probability.x <= diffuseProbability) {
+                directDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next);
+            } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
+                directSpecularSample(in, sf.P, h.prim, clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
+                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next);
+            } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
+                directSpecularSample(in, sf.P, h.prim, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
+                                     probability.y, rand, frame, nee, next);
+            }
+        }
+        if (in.depth < pp.max_ray_depth) { // :277-330
+            if (in.depth > 3) {
+                vec2 rand = getSequenceValue(in.sequenceID + in.depth + 2, si);
+                float probability = fmax_(in.weight.x, fmax_(in.weight.y, in.weight.z));
+                if (rand.x >= probability) return;
+                in.weight = in.weight / probability;
+            }
+            vec2 rand = getSequenceValue(in.sequenceID + in.depth + 3, si);
+            vec2 probability = getSequenceValue(in.sequenceID + in.depth + 4, si);
+            Ray dummyNee; // indirect samples use rl_NullPrimitive: never an occlusion ray
+            if (probability.x <= diffuseProbability) {
+                indirectDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, 1.0f, rand, frame, MISS_NONE, dummyNee, next);
+            } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
+                indirectSpecularSample(in, sf.P, h.prim, clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha,
+                                       M.multiscatter_lut, clearCoatRoughness, clearCoatProbability, 1.0f, rand, frame, MISS_NONE, dummyNee, next);
+            } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
+                indirectSpecularSample(in, sf.P, h.prim, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
+                                       1.0f, rand, frame, MISS_NONE, dummyNee, next);
+            }
+        }
+    }
+
+    // ---- glass.rlsl ----
+    void indirectSpecularGlassSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 weight, vec3 baseColor,
+                                     float roughnessAlpha, float materialRoughnessAlpha, float optionalLightSampleProbability, vec2 rand,
+                                     const mat3 &frame, int missKind, Ray &nee, Ray &next) // :47-81
+    {
+        vec3 localSpaceI = mulT(frame, I);
+        vec3 H = mul(frame, sampleVisibleGGX(localSpaceI, rand.x, rand.y, roughnessAlpha));
+        float IdotH = saturate(dot(I, H));
+        vec3 O = normalize(2.0f * IdotH * H - I);
+        float NdotO = dot(N, O);
+        if (NdotO > 0.0f) {
+            NdotO = saturate(NdotO);
+            float NdotH = saturate(dot(N, H));
+            float G = G2_Smith_GGX(NdotO, NdotI, materialRoughnessAlpha); // :63 uses Material.roughnessAlpha
+            vec3 reflectance = baseColor * ((G * IdotH) / (NdotH * NdotI));
+            reflectance = reflectance * weight;
+            reflectance = reflectance / optionalLightSampleProbability;
+            if (dot(reflectance, reflectance) > 1e-5f) {
+                Ray r = createRay(in, P, prim);
+                r.d = O;
+                r.weight = reflectance;
+                r.occlusionTest = (missKind != MISS_NONE);
+                r.missKind = missKind, r.missIdx = 0;
+                r.extraT = 0.0f;
+                if (missKind == MISS_ENV && !ctx.lights.env_enabled) return;
+                emit(r, nee, next);
+            }
+        }
+    }
+    void directSpecularGlassSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 weight, vec3 baseColor, float roughnessAlpha,
+                                   float materialRoughnessAlpha, float lightProbability, vec2 rand, const mat3 &frame, Ray &nee,
+                                   Ray &next) // :83-129
+    {
+        LightSample ls = computeLightSample(N, lightProbability, P);
+        if (ls.type != LIGHT_TYPE_ENVIRONMENT) {
+            float NdotO = dot(N, ls.dir);
+            if (NdotO > 0.0f) {
+                NdotO = saturate(NdotO);
+                vec3 H = normalize(I + ls.dir);
+                float NdotH = saturate(dot(N, H));
+                float D = D_GGX(NdotH, roughnessAlpha);
+                float G = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha);
+                float specular = (D * G) / greaterThanZero(4.0f * NdotI);
+                vec3 reflectance = specular * baseColor;
+                reflectance = reflectance * weight;
+                reflectance = reflectance / ls.probability;
+                if (dot(reflectance, reflectance) > 1e-5f) {
+                    Ray r = createRay(in, P, prim);
+                    r.d = ls.dir;
+                    r.weight = reflectance;
+                    r.occlusionTest = true;
+                    r.missKind = ls.missKind, r.missIdx = ls.missIdx;
+                    r.extraT = 0.0f;
+                    if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
+                    emit(r, nee, next);
+                }
+            }
+        } else if (ls.probability > 0.0f) {
+            indirectSpecularGlassSample(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, ls.probability, rand,
+                                        frame, MISS_ENV, nee, next);
+        }
+    }
+    void glass(const Ray &in, const Hit &h, const hr_material &M, Ray &nee, Ray &next) // :138-280
+    {
+        const TriAttr &attr = ctx.attrs[h.prim];
+        Surface sf = surface(in, h);
+        const uint32_t F = M.flags;
+        const bool hasTextures = (F & (HR_MF_HAS_BASE_COLOR_TEXTURE | HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE | HR_MF_HAS_NORMALMAP)) != 0;
+        const bool useTangentSpace = (F & HR_MF_HAS_NORMALMAP) != 0;
+        vec3 N = normalize(sf.normal);
+        float nIn = 1.0f;
+        float nOut = M.ior;
+        vec3 weight = in.weight;
+        if (F & HR_MF_HAS_NORMALMAP) { // :145-151
+            mat3 nt{normalize(sf.tangent), normalize(sf.bitangent), N};
+            vec4 s = tex(M.normalmap, sf.uv);
+            vec3 normalTS = vec3(s.x, s.y, s.z) * 2.0f - vec3(1.0f);
+            N = normalize(mul(nt, normalTS));
+        }
+        vec3 baseColor(M.base_color[0], M.base_color[1], M.base_color[2]);
+        if (F & HR_MF_HAS_BASE_COLOR_TEXTURE) { // :154-156
+            vec4 s = tex(M.base_color_texture, sf.uv);
+            baseColor = baseColor * vec3(s.x, s.y, s.z);
+        }
+        if ((F & HR_MF_VERTEX_COLORS) && (attr.flags & TF_HAS_COLORS)) baseColor = baseColor * sf.color;
+        if (!sf.frontFacing) { // :161-167, beersLaw :131-136
+            N = -N;
+            nIn = M.ior;
+            nOut = 1.0f;
+            vec3 absorption = vec3(1.0f) - baseColor;
+            float rayLength = h.t;
+            vec3 e = absorption * M.density * -rayLength;
+            weight = in.weight * vec3(exp_(e.x), exp_(e.y), exp_(e.z));
+        }
+        float roughness = M.roughness, roughnessAlpha = M.roughness_alpha;
+        if (F & HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE) { // :171-176
+            vec4 s = tex(M.metallic_roughness_texture, sf.uv);
+            roughness = roughness * s.y;
+            roughnessAlpha = roughness * roughness;
+        }
+        if (pp.enable_visualizer == 1) { // :179-210
+            switch (pp.visualizer_mode) {
+            case HR_VIS_GEOMETRIC_NORMALS: accumulate4((sf.normal + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_FINAL_NORMALS: accumulate4((N + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_BASE_COLOR: accumulate4(baseColor, 1.0f); break;
+            case HR_VIS_ROUGHNESS: accumulate4(vec3(roughness), 1.0f); break;
+            case HR_VIS_SHADER: accumulate4(vec3(0.0f, 1.0f, 0.0f), 1.0f); break;
+            case HR_VIS_UVS: if (hasTextures) accumulate4(vec3(sf.uv.x, sf.uv.y, 0.0f), 1.0f); break;
+            case HR_VIS_TANGENTS: if (hasTextures && useTangentSpace) accumulate4((sf.tangent + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_BITANGENTS: if (hasTextures && useTangentSpace) accumulate4((sf.bitangent + vec3(1.0f)) * 0.5f, 1.0f); break;
+            case HR_VIS_NORMALMAP:
+                if (F & HR_MF_HAS_NORMALMAP) {
+                    vec4 s = tex(M.normalmap, sf.uv);
+                    accumulate4(vec3(s.x, s.y, s.z), 1.0f);
+                }
+                break;
+            default: break;
+            }
+            return;
+        }
+        mat3 frame = orthonormalFrame(N); // :212
+        vec3 I = -in.d;
+        float eta = nIn / nOut;
+        vec3 localSpaceI = mulT(frame, I);
+        const int si = pp.sample_index + in.sequenceIndexOffset;
+        vec2 rand = getSequenceValue(in.sequenceID + in.depth, si);
+        vec3 H = mul(frame, sampleVisibleGGX(localSpaceI, rand.x, rand.y, roughnessAlpha));
+        float HdotI = saturate(dot(H, I));
+        vec2 refractProbability = getSequenceValue(in.sequenceID + in.depth + 1, si);
+        float Fr = F_Fresnel(eta, HdotI);
+        float NdotI = saturate(dot(N, I));
+        if (!sf.frontFacing) refractProbability = vec2{refractProbability.x, 0.0f}; // :227-231
+        if (refractProbability.y < (1.0f - Fr)) { // :234-256
+            vec3 O = normalize(refract(-I, H, eta));
+            float NdotO = fabsf(dot(N, O));
+            float G2 = G2_Smith_GGX(NdotI, NdotO, roughnessAlpha);
+            float G1 = G1_Smith_GGX(NdotI, roughnessAlpha);
+            vec3 transmission = baseColor * G2 / greaterThanZero(G1);
+            transmission = transmission * weight;
+            if (dot(transmission, transmission) > 1e-5f && in.depth < pp.max_ray_depth) {
+                Ray r = createRay(in, sf.P, h.prim);
+                r.d = O;
+                r.weight = transmission;
+                r.occlusionTest = false;
+                r.extraT = 0.0f;
+                r.missKind = ctx.lights.env_enabled ? MISS_ENV : MISS_NONE;
+                r.missIdx = 0;
+                next = r;
+            }
+        } else { // :257-279
+            {
+                rand = getSequenceValue(in.sequenceID + in.depth + 2, si);
+                directSpecularGlassSample(in, sf.P, h.prim, N, I, NdotI, weight, baseColor, roughnessAlpha, M.roughness_alpha, refractProbability.x,
+                                          rand, frame, nee, next);
+            }
+            if (in.depth < pp.max_ray_depth) {
+                if (in.depth > 3) {
+                    vec2 rr = getSequenceValue(in.sequenceID + in.depth + 3, si);
+                    float probability = fmax_(weight.x, fmax_(weight.y, weight.z));
+                    if (rr.x >= probability) return;
+                    weight = weight / probability;
+                }
+                rand = getSequenceValue(in.sequenceID + in.depth + 4, si);
+                Ray dummyNee;
+                indirectSpecularGlassSample(in, sf.P, h.prim, N, I, NdotI, weight, baseColor, roughnessAlpha, M.roughness_alpha, 1.0f, rand, frame,
+                                            MISS_NONE, dummyNee, next);
+            }
+        }
+    }
+
+    // ---- perspective.rlsl:39-93 (frame shader) ----
+    static float random(float sx, float sy) { return fract(sin_(sx * 12.9898f + sy * 78.233f) * 43758.5453123f); } // utility.rlsl:15-18
+    bool generatePrimary(int x, int y, Ray &out)
+    {
+        const float W = (float)ctx.W, H = (float)ctx.H;
+        const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
+        if (pp.interactive_mode != 0) { // :42-57 — the 3x3 block texture is shuffled with std::random_device in
+            // the reference (PassGenerator.cpp:276-278); this build defines the identity
+            // layout texel(i,j) = (i,j), sampled with RL_NEAREST/RL_REPEAT.
+            const int bsx = pp.block_size[0], bsy = pp.block_size[1];
+            const int bix = (int)(fcx - 0.5f) / bsx, biy = (int)(fcy - 0.5f) / bsy;
+            float randX = random((float)bix, (float)biy);
+            float randY = random((float)biy, (float)bix);
+            float su = (1.0f / (float)bsx) * (float)pp.current_block_pixel[0] + randX;
+            float sv = (1.0f / (float)bsy) * (float)pp.current_block_pixel[1] + randY;
+            int tx = (int)floorf(su * (float)bsx) % bsx, ty = (int)floorf(sv * (float)bsy) % bsy;
+            // texel (tx,ty) of the row-major coords list holds vec3(row=ty... ) : identity layout -> (ty, tx)
+            int sampleX = ty, sampleY = tx;
+            int thisX = (int)(fcx - 0.5f) % bsx, thisY = (int)(fcy - 0.5f) % bsy;
+            if (thisX != sampleX || thisY != sampleY) return false;
+        }
+        px[3] = px[3] + 1.0f; // :60 accumulate(vec4(0,0,0,1))
+        int sequenceID = (int)floorf(random(fcx / W, fcy / H) * (float)ctx.nSeq); // :62
+        // :64 — row stride is the frame HEIGHT and the coords are pixel centres;
+        // the reference reads out of bounds on square/tall frames, defined here as wrap modulo W*H.
+        int offIdx = (int)(fcy * H + fcx);
+        offIdx = offIdx % (int)ctx.seqOffsets.size();
+        float rnd = ctx.seqOffsets[offIdx].x;
+        int sequenceIndex = (int)floorf(rnd * pp.max_sample_index); // :65
+        vec2 sampleOffset = getSequenceValue(sequenceID, pp.sample_index + sequenceIndex);
+        float spx = (fcx - 0.5f) + sampleOffset.x, spy = (fcy - 0.5f) + sampleOffset.y;
+        float u = spx / W, v = spy / H;
+        float cx = (2.0f * u - 1.0f) * pp.aspect_ratio * pp.fov_tan;  // :72
+        float cy = (1.0f - 2.0f * v) * pp.fov_tan * -1.0f;            // :73
+        vec3 dirCameraSpace = normalize(vec3(cx, cy, -1.0f));
+        vec3 focalPoint = pp.focus_distance * dirCameraSpace; // :77
+        // :78 — the aperture index ignores sequenceIndex and is not wrapped in the reference; wrapped here.
+        int apIdx = (sequenceID * ctx.seqLen + pp.sample_index) % (ctx.nSeq * ctx.seqLen);
+        vec2 ap = ctx.aperture[apIdx];
+        float ax = ((ap.x * 2.0f) - 1.0f) * pp.aperture_radius, ay = ((ap.y * 2.0f) - 1.0f) * pp.aperture_radius;
+        vec3 origin(ax, ay, 0.0f);
+        vec3 dir = focalPoint - origin;
+        out = Ray();
+        out.o = xformPoint(pp.view_matrix, origin);               // :84
+        out.d = normalize(xformVector(pp.view_matrix, dir));      // :85 (OpenRL normalises emitted directions)
+        out.missKind = ctx.lights.env_enabled ? MISS_ENV : MISS_NONE;
+        out.weight = vec3(1.0f);
+        out.sequenceID = sequenceID;
+        out.sequenceIndexOffset = sequenceIndex;
+        out.extraT = 0.0f;
+        out.depth = 0;
+        out.valid = true;
+        return true;
+    }
+
+    void tracePath(int x, int y)
+    {
+        Ray ray;
+        if (!generatePrimary(x, y, ray)) return;
+        st.paths++;
+        while (ray.valid) {
+            st.rays_closest++;
+            Hit h = traceClosest(ctx, ray.o, ray.d, ctx.rayEps, ray.maxT, ray.srcPrim, &tc, ctx.brute);
+            if (h.prim < 0) {
+                // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
+                if (ray.missKind == MISS_ENV) environmentLight(ray.d, ray.weight);
+                break;
+            }
+            Ray nee, next;
+            const int mid = ctx.attrs[h.prim].material;
+            if (mid >= 0 && mid < (int)ctx.materials.size()) {
+                st.shaded_hits++;
+                const hr_material &M = ctx.materials[mid];
+                if (M.type == HR_MAT_GLASS)
+                    glass(ray, h, M, nee, next);
+                else
+                    physicallyBased(ray, h, M, nee, next);
+            }
+            if (nee.valid) {
+                st.rays_any++;
+                if (!traceOccluded(ctx, nee.o, nee.d, ctx.rayEps, nee.maxT, nee.srcPrim, &tc, ctx.brute)) lightShader(nee, nee.maxT);
+            }
+            ray = next;
+        }
+    }
+};
+
+void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
+{
+    const int W = ctx.W, H = ctx.H, tile = ctx.tile > 0 ? ctx.tile : 32;
+    const int tilesX = (W + tile - 1) / tile;
+    if (nThreads <= 0) nThreads = omp_get_max_threads();
+    std::vector<hr_pass_stats> stats(nThreads);
+    std::vector<TraceCounters> tcs(nThreads);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nThreads)
+    for (int y = 0; y < H; ++y) {
+        const int tid = omp_get_thread_num();
+        for (int x = 0; x < W; ++x) {
+            const int t = (y / tile) * tilesX + (x / tile);
+            if (t % ctx.world != ctx.rank) continue;
+            Shader sh(ctx, pp, &ctx.fb[((size_t)y * W + x) * 4], stats[tid]);
+            sh.tracePath(x, y);
+            tcs[tid].nodeVisits += sh.tc.nodeVisits;
+            tcs[tid].triTests += sh.tc.triTests;
+        }
+    }
+    for (int i = 0; i < nThreads; ++i) {
+        ctx.stats.paths += stats[i].paths;
+        ctx.stats.rays_closest += stats[i].rays_closest;
+        ctx.stats.rays_any += stats[i].rays_any;
+        ctx.stats.shaded_hits += stats[i].shaded_hits;
+        ctx.stats.accumulates += stats[i].accumulates;
+        ctx.stats.node_visits += tcs[i].nodeVisits;
+        ctx.stats.tri_tests += tcs[i].triTests;
+    }
+}
+
+} // namespace ora
