@@ -1,0 +1,570 @@
+// hr_build.hip — scene assembly and LBVH construction on the GPU, plus the sample-table generators.
+//
+// Replaces what OpenRL does with the buffers of rlDrawElements (/root/reference/Source/HeatrayRenderer/
+// Scene/Mesh.cpp:29-153, Resources/shaders/vertex.rlsl:25-43) — SURVEY §8a row a6 — and the host-side table
+// generators (Source/Utility/Random.h:85-289, Source/HeatrayRenderer/Materials/MultiScatterUtil.cpp:20-139).
+//
+//   assemble : one thread per triangle: world transform, edge form, shading attributes, scene bounds
+//   morton   : 30-bit Morton code of the triangle-AABB centre, normalised by the scene bounds
+//   sort     : LSD radix sort, 4 x 8-bit digits, stable (histogram / scan / ballot-ranked scatter)
+//   karras   : binary radix tree over the sorted (key, index) pairs
+//   refit    : bottom-up boxes in kernel-ordered rounds (no inter-workgroup hand-off inside a launch,
+//              so no reliance on cross-XCD visibility)
+//   emit     : subtrees of <= 4 triangles collapse into leaves; 64-byte two-box nodes
+#include "hr_kernels.h"
+
+#include <vector>
+
+namespace hr {
+
+static const int kLeafMax = 4;
+
+#define HR_CHECK(expr)                  \
+    do {                                \
+        hipError_t e_ = (expr);         \
+        if (e_ != hipSuccess) return 1; \
+    } while (0)
+
+HRD uint32_t orderedFromFloat(float f)
+{
+    uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+HRD v3 fetch3(const float *a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+
+// ------------------------------------------------------------------------------------- assemble
+__global__ __launch_bounds__(256) void k_assemble(const GeomDev *__restrict__ geoms, int nGeoms, uint32_t nTris, Tri *__restrict__ tris,
+                                                  TriAttr *__restrict__ attrs, TriAttrExt *__restrict__ ext, uint32_t *__restrict__ bounds)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    v3 lo(__builtin_inff()), hi(-__builtin_inff());
+    if (t < nTris) {
+        int a = 0, b = nGeoms - 1; // last geometry with triOffset <= t
+        while (a < b) {
+            int m = (a + b + 1) >> 1;
+            if (geoms[m].triOffset <= t)
+                a = m;
+            else
+                b = m - 1;
+        }
+        const GeomDev &g = geoms[a];
+        const uint32_t lt = t - g.triOffset;
+        uint32_t i0, i1, i2;
+        if (g.strip) { // GL strip ordering: odd triangles swap the first two vertices
+            i0 = g.idx[lt], i1 = g.idx[lt + 1], i2 = g.idx[lt + 2];
+            if (lt & 1u) {
+                uint32_t s = i0;
+                i0 = i1;
+                i1 = s;
+            }
+        } else {
+            i0 = g.idx[3 * lt], i1 = g.idx[3 * lt + 1], i2 = g.idx[3 * lt + 2];
+        }
+        const uint32_t id[3] = {i0, i1, i2};
+        // vertex.rlsl:27 — rl_Position = worldFromEntity * vec4(position, 1)
+        const v3 p0 = xformPoint(g.world, fetch3(g.pos, i0)), p1 = xformPoint(g.world, fetch3(g.pos, i1)),
+                 p2 = xformPoint(g.world, fetch3(g.pos, i2));
+        const v3 e1 = p1 - p0, e2 = p2 - p0;
+        Tri tr;
+        tr.p = make_float4(p0.x, p0.y, p0.z, e1.x);
+        tr.q = make_float4(e1.y, e1.z, e2.x, e2.y);
+        tr.r = make_float4(e2.z, __uint_as_float(t), __uint_as_float(g.flags), 0.0f);
+        tris[t] = tr;
+        TriAttr at;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            // vertex.rlsl:28-29 — normal = mat3(worldFromEntity) * normalAttribute
+            const v3 n = xformVector(g.world, fetch3(g.nrm, id[k]));
+            at.n[3 * k] = n.x, at.n[3 * k + 1] = n.y, at.n[3 * k + 2] = n.z;
+            at.uv[2 * k] = g.uv ? g.uv[2 * id[k]] : 0.0f;
+            at.uv[2 * k + 1] = g.uv ? g.uv[2 * id[k] + 1] : 0.0f;
+        }
+        at.matflags = (g.material & kMatMask) | (g.flags << 24);
+        attrs[t] = at;
+        if (ext) {
+            TriAttrExt e;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v3 tn(0.0f), bt(0.0f), cl(0.0f);
+                if (g.tan && g.bit) { // vertex.rlsl:35-38
+                    tn = xformVector(g.world, fetch3(g.tan, id[k]));
+                    bt = xformVector(g.world, fetch3(g.bit, id[k]));
+                }
+                if (g.col) cl = fetch3(g.col, id[k]); // vertex.rlsl:40-42
+                e.tan[3 * k] = tn.x, e.tan[3 * k + 1] = tn.y, e.tan[3 * k + 2] = tn.z;
+                e.bit[3 * k] = bt.x, e.bit[3 * k + 1] = bt.y, e.bit[3 * k + 2] = bt.z;
+                e.col[3 * k] = cl.x, e.col[3 * k + 1] = cl.y, e.col[3 * k + 2] = cl.z;
+            }
+            e.pad = 0.0f;
+            ext[t] = e;
+        }
+        // bounds over v0, v0+e1, v0+e2 (the vertices the intersector sees)
+        const v3 q1 = p0 + e1, q2 = p0 + e2;
+        lo = min3(min3(p0, q1), q2);
+        hi = max3(max3(p0, q1), q2);
+    }
+    // wave reduction, then one atomic per wave and component
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo.x = fmin_(lo.x, __shfl_xor(lo.x, o)), lo.y = fmin_(lo.y, __shfl_xor(lo.y, o)), lo.z = fmin_(lo.z, __shfl_xor(lo.z, o));
+        hi.x = fmax_(hi.x, __shfl_xor(hi.x, o)), hi.y = fmax_(hi.y, __shfl_xor(hi.y, o)), hi.z = fmax_(hi.z, __shfl_xor(hi.z, o));
+    }
+    if ((threadIdx.x & 63) == 0 && lo.x <= hi.x) {
+        atomicMin(&bounds[0], orderedFromFloat(lo.x)), atomicMin(&bounds[1], orderedFromFloat(lo.y)), atomicMin(&bounds[2], orderedFromFloat(lo.z));
+        atomicMax(&bounds[3], orderedFromFloat(hi.x)), atomicMax(&bounds[4], orderedFromFloat(hi.y)), atomicMax(&bounds[5], orderedFromFloat(hi.z));
+    }
+}
+
+void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t nTris, Tri *tris, TriAttr *attrs, TriAttrExt *ext, uint32_t *bounds)
+{
+    if (nTris == 0) return;
+    hipLaunchKernelGGL(k_assemble, dim3((nTris + 255) / 256), dim3(256), 0, st, geoms, nGeoms, nTris, tris, attrs, ext, bounds);
+}
+
+// --------------------------------------------------------------------------------------- morton
+HRD uint32_t expandBits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+HRD uint32_t quantize10(float c, float lo, float ext)
+{
+    float q = (ext > 0.0f) ? (c - lo) / ext : 0.0f;
+    q = q * 1024.0f;
+    q = fmin_(fmax_(q, 0.0f), 1023.0f);
+    return (uint32_t)q;
+}
+struct Box6 {
+    float lo[3], hi[3];
+};
+HRD void triBounds(const Tri &t, v3 &bl, v3 &bh)
+{
+    const v3 v0(t.p.x, t.p.y, t.p.z), e1(t.p.w, t.q.x, t.q.y), e2(t.q.z, t.q.w, t.r.x);
+    const v3 p1 = v0 + e1, p2 = v0 + e2;
+    bl = min3(min3(v0, p1), p2);
+    bh = max3(max3(v0, p1), p2);
+}
+
+__global__ __launch_bounds__(256) void k_morton(const Tri *__restrict__ tris, uint32_t n, v3 lo, v3 ext, uint32_t *__restrict__ keys,
+                                                uint32_t *__restrict__ vals)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    v3 bl, bh;
+    triBounds(tris[i], bl, bh);
+    const v3 c = (bl + bh) * 0.5f;
+    keys[i] = (expandBits10(quantize10(c.x, lo.x, ext.x)) << 2) | (expandBits10(quantize10(c.y, lo.y, ext.y)) << 1) |
+              expandBits10(quantize10(c.z, lo.z, ext.z));
+    vals[i] = i;
+}
+
+// ----------------------------------------------------------------------------------- radix sort
+static const int kSortTile = 2048; // keys per single-wave workgroup
+
+__global__ __launch_bounds__(64) void k_sort_hist(const uint32_t *__restrict__ keys, uint32_t n, int shift, uint32_t *__restrict__ blockHist,
+                                                  uint32_t nBlocks)
+{
+    __shared__ uint32_t hist[256];
+    for (int i = threadIdx.x; i < 256; i += 64) hist[i] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortTile / 64; ++r) {
+        const uint32_t i = base + r * 64 + threadIdx.x;
+        if (i < n) atomicAdd(&hist[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256; i += 64) blockHist[(uint32_t)i * nBlocks + blockIdx.x] = hist[i];
+}
+
+// exclusive scan of `n` values by ONE workgroup of 1024 threads (n is at most a few hundred thousand)
+__global__ __launch_bounds__(1024) void k_scan_single(uint32_t *__restrict__ data, uint32_t n, uint32_t *__restrict__ total)
+{
+    __shared__ uint32_t waveSums[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = (i < n) ? data[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t t = __shfl_up(inc, o);
+            if ((int)lane >= o) inc += t;
+        }
+        if (lane == 63) waveSums[wave] = inc;
+        __syncthreads();
+        uint32_t wavePrefix = 0;
+        for (uint32_t w = 0; w < wave; ++w) wavePrefix += waveSums[w];
+        const uint32_t c = carry;
+        if (i < n) data[i] = c + wavePrefix + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + wavePrefix + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(64) void k_sort_scatter(const uint32_t *__restrict__ keysIn, const uint32_t *__restrict__ valsIn, uint32_t n, int shift,
+                                                     const uint32_t *__restrict__ blockOffsets, uint32_t nBlocks, uint32_t *__restrict__ keysOut,
+                                                     uint32_t *__restrict__ valsOut)
+{
+    __shared__ uint32_t off[256];
+    for (int i = threadIdx.x; i < 256; i += 64) off[i] = blockOffsets[(uint32_t)i * nBlocks + blockIdx.x];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    const uint32_t base = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortTile / 64; ++r) {
+        const uint32_t i = base + r * 64 + lane;
+        const bool valid = i < n;
+        const uint32_t key = valid ? keysIn[i] : 0u, val = valid ? valsIn[i] : 0u;
+        const uint32_t d = (key >> shift) & 255u;
+        // lanes holding the same digit (stable: rank = number of equal-digit lanes before me)
+        unsigned long long same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            same &= bit ? m : ~m;
+        }
+        uint32_t pos = 0;
+        if (valid) pos = off[d] + (uint32_t)__popcll(same & ltMask);
+        __syncthreads();
+        if (valid && (same & ltMask) == 0ull) off[d] += (uint32_t)__popcll(same); // first lane of each digit group
+        __syncthreads();
+        if (valid) {
+            keysOut[pos] = key;
+            valsOut[pos] = val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gather_tris(const Tri *__restrict__ trisPrim, const uint32_t *__restrict__ order, uint32_t n,
+                                                     Tri *__restrict__ sorted, float pad, Box6 *__restrict__ leafBox)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Tri t = trisPrim[order[i]];
+    sorted[i] = t;
+    v3 bl, bh;
+    triBounds(t, bl, bh);
+    Box6 b;
+    b.lo[0] = bl.x - pad, b.lo[1] = bl.y - pad, b.lo[2] = bl.z - pad;
+    b.hi[0] = bh.x + pad, b.hi[1] = bh.y + pad, b.hi[2] = bh.z + pad;
+    leafBox[i] = b;
+}
+
+// --------------------------------------------------------------------------------------- karras
+HRD int deltaKey(const uint32_t *keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = keys[i], b = keys[j];
+    if (a == b) return 32 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+    return __clz((int)(a ^ b));
+}
+
+struct KNode {
+    int left, right; // >= 0: internal node, < 0: leaf ~index
+    int first, last; // covered range of sorted triangles
+};
+
+__global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ keys, int n, KNode *__restrict__ nodes)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (deltaKey(keys, n, i, i + 1) - deltaKey(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = deltaKey(keys, n, i, i - d);
+    int lmax = 2;
+    while (deltaKey(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (deltaKey(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = deltaKey(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) >> 1;
+        if (deltaKey(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    KNode k;
+    k.left = (lo == gamma) ? ~gamma : gamma;
+    k.right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    k.first = lo, k.last = hi;
+    nodes[i] = k;
+}
+
+// One bottom-up round: a node whose children were finished in an EARLIER launch gets its box.
+// stamp[i] = round in which node i was finished (0 = not yet); visibility comes from the kernel boundary.
+__global__ __launch_bounds__(256) void k_refit_round(const KNode *__restrict__ nodes, int nInternal, const Box6 *__restrict__ leafBox,
+                                                     Box6 *__restrict__ nodeBox, uint32_t *__restrict__ stamp, uint32_t round)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nInternal || stamp[i] != 0u) return;
+    const KNode k = nodes[i];
+    const bool lr = k.left < 0 || (stamp[k.left] != 0u && stamp[k.left] < round);
+    const bool rr = k.right < 0 || (stamp[k.right] != 0u && stamp[k.right] < round);
+    if (!(lr && rr)) return;
+    const Box6 a = k.left < 0 ? leafBox[~k.left] : nodeBox[k.left];
+    const Box6 b = k.right < 0 ? leafBox[~k.right] : nodeBox[k.right];
+    Box6 u;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        u.lo[c] = fmin_(a.lo[c], b.lo[c]);
+        u.hi[c] = fmax_(a.hi[c], b.hi[c]);
+    }
+    nodeBox[i] = u;
+    stamp[i] = round;
+}
+
+__global__ __launch_bounds__(256) void k_flag_internal(const KNode *__restrict__ nodes, int nInternal, uint32_t *__restrict__ flags)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nInternal) return;
+    flags[i] = (nodes[i].last - nodes[i].first + 1 > kLeafMax) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_emit_nodes(const KNode *__restrict__ nodes, int nInternal, const Box6 *__restrict__ leafBox,
+                                                    const Box6 *__restrict__ nodeBox, const uint32_t *__restrict__ outIndex, Node *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nInternal) return;
+    const KNode k = nodes[i];
+    if (k.last - k.first + 1 <= kLeafMax) return;
+    const int refs[2] = {k.left, k.right};
+    Box6 bx[2];
+    int child[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ref = refs[c];
+        int first, last;
+        if (ref < 0) {
+            first = last = ~ref;
+            bx[c] = leafBox[~ref];
+        } else {
+            first = nodes[ref].first, last = nodes[ref].last;
+            bx[c] = nodeBox[ref];
+        }
+        const int count = last - first + 1;
+        child[c] = (count <= kLeafMax) ? ~(first | ((count - 1) << 28)) : (int)outIndex[ref];
+    }
+    Node nd;
+    nd.a = make_float4(bx[0].lo[0], bx[0].lo[1], bx[0].lo[2], bx[0].hi[0]);
+    nd.b = make_float4(bx[0].hi[1], bx[0].hi[2], bx[1].lo[0], bx[1].lo[1]);
+    nd.c = make_float4(bx[1].lo[2], bx[1].hi[0], bx[1].hi[1], bx[1].hi[2]);
+    nd.d = make_int4(child[0], child[1], 0, 0);
+    out[outIndex[i]] = nd;
+}
+
+int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, BuildResult *out)
+{
+    out->nodes = nullptr, out->tris = nullptr, out->nNodes = 0, out->rootLeafCount = 0;
+    if (n == 0) return 0;
+    if (n >= (1u << 28)) return 2;
+    const uint32_t nBlocks = (n + kSortTile - 1) / kSortTile;
+    uint32_t *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr, *blockHist = nullptr, *flags = nullptr, *stamp = nullptr,
+             *total = nullptr;
+    KNode *knodes = nullptr;
+    Box6 *leafBox = nullptr, *nodeBox = nullptr;
+    Tri *sorted = nullptr;
+    HR_CHECK(hipMalloc(&keysA, 4ull * n));
+    HR_CHECK(hipMalloc(&keysB, 4ull * n));
+    HR_CHECK(hipMalloc(&valsA, 4ull * n));
+    HR_CHECK(hipMalloc(&valsB, 4ull * n));
+    HR_CHECK(hipMalloc(&blockHist, 4ull * 256 * nBlocks));
+    HR_CHECK(hipMalloc(&sorted, sizeof(Tri) * (size_t)n));
+    HR_CHECK(hipMalloc(&leafBox, sizeof(Box6) * (size_t)n));
+    HR_CHECK(hipMalloc(&total, 4));
+    const v3 vlo(lo[0], lo[1], lo[2]);
+    const v3 ext(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+    const uint32_t g256 = (n + 255) / 256;
+    hipLaunchKernelGGL(k_morton, dim3(g256), dim3(256), 0, st, trisPrim, n, vlo, ext, keysA, valsA);
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(k_sort_hist, dim3(nBlocks), dim3(64), 0, st, keysA, n, shift, blockHist, nBlocks);
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, blockHist, 256u * nBlocks, (uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nBlocks), dim3(64), 0, st, keysA, valsA, n, shift, blockHist, nBlocks, keysB, valsB);
+        std::swap(keysA, keysB);
+        std::swap(valsA, valsB);
+    }
+    hipLaunchKernelGGL(k_gather_tris, dim3(g256), dim3(256), 0, st, trisPrim, valsA, n, sorted, pad, leafBox);
+    int rc = 0;
+    if (n <= (uint32_t)kLeafMax) {
+        out->rootLeafCount = (int)n;
+    } else {
+        const int nInternal = (int)n - 1;
+        const uint32_t gi = (nInternal + 255) / 256;
+        HR_CHECK(hipMalloc(&knodes, sizeof(KNode) * (size_t)nInternal));
+        HR_CHECK(hipMalloc(&nodeBox, sizeof(Box6) * (size_t)nInternal));
+        HR_CHECK(hipMalloc(&stamp, 4ull * nInternal));
+        HR_CHECK(hipMalloc(&flags, 4ull * nInternal));
+        HR_CHECK(hipMemsetAsync(stamp, 0, 4ull * nInternal, st));
+        hipLaunchKernelGGL(k_karras, dim3(gi), dim3(256), 0, st, keysA, (int)n, knodes);
+        // tree height <= 30 key bits + 28 index bits; check the root every 16 rounds
+        uint32_t rootStamp = 0;
+        for (uint32_t round = 1; round <= 64 && rootStamp == 0; ++round) {
+            hipLaunchKernelGGL(k_refit_round, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, stamp, round);
+            if ((round & 15u) == 0u) {
+                HR_CHECK(hipMemcpyAsync(&rootStamp, stamp, 4, hipMemcpyDeviceToHost, st));
+                HR_CHECK(hipStreamSynchronize(st));
+            }
+        }
+        if (rootStamp == 0) {
+            HR_CHECK(hipMemcpyAsync(&rootStamp, stamp, 4, hipMemcpyDeviceToHost, st));
+            HR_CHECK(hipStreamSynchronize(st));
+        }
+        if (rootStamp == 0) rc = 3;
+        hipLaunchKernelGGL(k_flag_internal, dim3(gi), dim3(256), 0, st, knodes, nInternal, flags);
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, flags, (uint32_t)nInternal, total);
+        uint32_t nOut = 0;
+        HR_CHECK(hipMemcpyAsync(&nOut, total, 4, hipMemcpyDeviceToHost, st));
+        HR_CHECK(hipStreamSynchronize(st));
+        HR_CHECK(hipMalloc(&out->nodes, sizeof(Node) * (size_t)(nOut ? nOut : 1)));
+        hipLaunchKernelGGL(k_emit_nodes, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, flags, out->nodes);
+        out->nNodes = (int)nOut;
+    }
+    out->tris = sorted;
+    HR_CHECK(hipStreamSynchronize(st));
+    hipFree(keysA), hipFree(keysB), hipFree(valsA), hipFree(valsB), hipFree(blockHist), hipFree(leafBox), hipFree(total);
+    if (knodes) hipFree(knodes);
+    if (nodeBox) hipFree(nodeBox);
+    if (stamp) hipFree(stamp);
+    if (flags) hipFree(flags);
+    if (hipGetLastError() != hipSuccess) return 1;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------- QMC
+// Random.h:26-34 (see oracle/oracle_qmc.cpp for the x86 conversion note)
+HRD uint32_t toUint32(float f) { return (uint32_t)(unsigned long long)(long long)(f * 4294967296.0f); }
+HRD float toNormalizedFloat(uint32_t u) { return (float)u * (1.0f / 4294967296.0f); }
+HRD uint32_t burleyHash(uint32_t x) // Random.h:36-45
+{
+    x ^= x >> 16;
+    x *= 0x85ebca6bu;
+    x ^= x >> 13;
+    x *= 0xc2b2ae35u;
+    x ^= x >> 16;
+    return x;
+}
+HRD uint32_t burleyHashCombine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); } // :47-50
+HRD uint32_t nestedUniformScramble(uint32_t x, uint32_t seed) // Random.h:52-78 (bit reversal = v_bfrev_b32)
+{
+    x = __brev(x);
+    x += seed;
+    x ^= x * 0x6c50b47cu;
+    x ^= x * 0xb82f1e52u;
+    x ^= x * 0xc7afe638u;
+    x ^= x * 0x8d22f6e6u;
+    return __brev(x);
+}
+HRD uint32_t sobolDim1(uint32_t index) // Random.h:236-244: v[b] = v[b-1] ^ (v[b-1] >> 1)
+{
+    uint32_t result = 0, v = 0x80000000u;
+    for (uint32_t bit = 0; bit < 32; ++bit) {
+        if ((index >> bit) & 1u) result ^= v;
+        v ^= v >> 1;
+    }
+    return result;
+}
+HRD float haltonValue(uint32_t index, int base) // Random.h:192-204
+{
+    float result = 0.0f, f = 1.0f;
+    const float denom = (float)base;
+    uint32_t n = index;
+    while (n > 0) {
+        f = f / denom;
+        result += f * (float)(n % (uint32_t)base);
+        n = n / (uint32_t)base;
+    }
+    return result;
+}
+__constant__ int kHaltonBases[16][2] = {{2, 3},  {2, 5},  {2, 7},  {3, 7}, {4, 5},   {5, 7},  {5, 9},  {5, 11},
+                                        {6, 11}, {5, 11}, {8, 11}, {3, 5}, {11, 15}, {2, 15}, {3, 19}, {7, 10}}; // Random.h:172-189
+
+// owenScrambleSequence (Random.h:85-108) with sobol / halton / hammersley generators; radial: Random.h:268-289
+__global__ __launch_bounds__(256) void k_qmc(int mode, uint32_t sequenceIndex, uint32_t count, int radial, float2 *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t seed = burleyHash(sequenceIndex + 1);
+    const uint32_t index = nestedUniformScramble(i, seed);
+    float sx, sy;
+    if (mode == HR_SAMPLE_SOBOL) {
+        sx = toNormalizedFloat(__brev(index)); // dimension 0: direction numbers 2^(31-bit)
+        sy = toNormalizedFloat(sobolDim1(index));
+    } else if (mode == HR_SAMPLE_HALTON) {
+        sx = haltonValue(index, kHaltonBases[sequenceIndex & 15][0]);
+        sy = haltonValue(index, kHaltonBases[sequenceIndex & 15][1]);
+    } else {
+        sx = (float)i * (1.0f / (float)count);
+        sy = (float)__brev(index) * 2.3283064365386963e-10f;
+    }
+    float x = toNormalizedFloat(nestedUniformScramble(toUint32(sx), burleyHashCombine(seed, 0)));
+    float y = toNormalizedFloat(nestedUniformScramble(toUint32(sy), burleyHashCombine(seed, 1)));
+    if (radial) {
+        const float sqrt_t = sqrt_(y);
+        float sn, cs;
+        sincos_(6.28318530717958647692f * x, &sn, &cs);
+        x = (sqrt_t * cs + 1.0f) * 0.5f;
+        y = (sqrt_t * sn + 1.0f) * 0.5f;
+    }
+    out[i] = make_float2(x, y);
+}
+
+void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, int radial, float2 *out)
+{
+    if (count == 0) return;
+    hipLaunchKernelGGL(k_qmc, dim3((count + 255) / 256), dim3(256), 0, st, mode, sequenceIndex, count, radial, out);
+}
+
+// ------------------------------------------------------------------------------ multiscatter LUT
+// MultiScatterUtil.cpp:20-139: one thread per texel integrates 4096 Sobol samples of the GGX lobe.
+HRD float lutG1(float NdotI, float alpha)
+{
+    const float alpha2 = alpha * alpha;
+    const float denom = sqrt_(alpha2 + (1.0f - alpha2) * (NdotI * NdotI)) + NdotI;
+    return (2.0f * NdotI) / fmax_(denom, 1e-5f);
+}
+__global__ __launch_bounds__(128) void k_multiscatter_lut(const float2 *__restrict__ seq, int samples, float *__restrict__ out, int dim)
+{
+    const int col = threadIdx.x, row = blockIdx.x;
+    const float roughness = clamp_(((float)row + 0.5f) / (float)dim, 0.0f, 1.0f);
+    const float alpha = roughness * roughness;
+    const float NdotV = clamp_(((float)col + 0.5f) / (float)dim, 0.0f, 1.0f);
+    const v3 V(sqrt_(1.0f - (NdotV * NdotV)), 0.0f, NdotV);
+    float result = 0.0f;
+    for (int i = 0; i < samples; ++i) {
+        const float2 r = seq[i];
+        const float a2 = alpha * alpha;
+        const float cosTheta = sqrt_(fmax_(0.0f, (1.0f - r.x) / ((a2 - 1.0f) * r.x + 1.0f)));
+        const float sinTheta = sqrt_(fmax_(0.0f, 1.0f - cosTheta * cosTheta));
+        float sn, cs;
+        sincos_(6.28318530717958647692f * r.y, &sn, &cs);
+        v3 H(sinTheta * cs, sinTheta * sn, cosTheta);
+        H = normalize(H);
+        const v3 L = 2.0f * dot(V, H) * H - V;
+        const float NdotL = clamp_(L.z, 0.0f, 1.0f);
+        if (NdotL > 0.0f) {
+            const float VdotH = clamp_(dot(V, H), 0.0f, 1.0f);
+            const float NdotH = clamp_(H.z, 0.0f, 1.0f);
+            result += (lutG1(NdotL, alpha) * lutG1(NdotV, alpha) * VdotH) / (NdotV * NdotH);
+        }
+    }
+    const float value = result / (float)samples;
+    out[row * dim + col] = (1.0f - value) / value;
+}
+
+void launchMultiscatterLUT(hipStream_t st, const float2 *sobol4096, float *out128x128)
+{
+    hipLaunchKernelGGL(k_multiscatter_lut, dim3(128), dim3(128), 0, st, sobol4096, 4096, out128x128, 128);
+}
+
+} // namespace hr

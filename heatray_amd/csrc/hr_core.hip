@@ -1,0 +1,760 @@
+// hr_core.hip — host side of libhrcore: the C-ABI of include/hrcore.h over the HIP kernels.
+//
+// Owns device memory (scene, BVH, tables, ray queues, accumulation buffer) and sequences the kernels of
+// a pass.  There is no CPU rendering path in this library: without a usable HIP device every entry point
+// that needs one fails with HR_ERR_DEVICE.
+#include "hr_kernels.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hr;
+
+namespace {
+
+struct Texture {
+    float *dpx = nullptr;
+    TexDesc desc{};
+    bool alive = false;
+};
+
+struct Geom {
+    bool alive = false;
+    int nVerts = 0;
+    std::vector<float> pos, nrm, uv, tan, bit, col;
+    std::vector<uint32_t> idx;
+    int mode = HR_TRIANGLES;
+    float world[16];
+    int frontFaceCW = 0, isOccluder = 1, material = 0;
+    uint32_t nTris() const { return mode == HR_TRIANGLE_STRIP ? (idx.size() >= 3 ? (uint32_t)idx.size() - 2 : 0u) : (uint32_t)(idx.size() / 3); }
+};
+
+} // namespace
+
+struct hr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool collectStats = false;
+    int rank = 0, world = 1, tile = 32;
+    int numCUs = 256;
+    std::string err;
+
+    // frame
+    int W = 0, H = 0;
+    float *fbInternal = nullptr, *fbExternal = nullptr;
+    float *pinned = nullptr;
+    size_t pinnedBytes = 0;
+    FrameDev frame{};
+    uint32_t queueCapacity = 0;
+    RayQueue q[2]{};
+    ShadowQueue sq{};
+    void *hits = nullptr;
+
+    // scene (host mirror)
+    std::vector<Geom> geoms;
+    std::vector<Texture> textures;
+    std::vector<hr_material> materials;
+    hr_lights lights{};
+    bool committed = false, sceneDirty = true, hasPassthrough = false;
+    hr_scene_info info{};
+
+    // scene (device)
+    Node *nodes = nullptr;
+    Tri *tris = nullptr;
+    TriAttr *attrs = nullptr;
+    TriAttrExt *attrsExt = nullptr;
+    hr_material *dMaterials = nullptr;
+    size_t dMaterialsCap = 0;
+    TexDesc *dTextures = nullptr;
+    size_t dTexturesCap = 0;
+    float2 *dSeq = nullptr, *dAperture = nullptr, *dSeqOffsets = nullptr;
+    int nSeq = 0, seqLen = 0, nSeqOffsets = 0;
+    SceneDev hScene{};
+    SceneDev *dScene = nullptr;
+    Counters *dCounters = nullptr;
+    Stats *dStats = nullptr;
+    uint32_t *dScratch = nullptr; // 8 words: ordered bounds etc.
+
+    float *fb() const { return fbExternal ? fbExternal : fbInternal; }
+    LaunchCfg cfg() const { return LaunchCfg{stream, numCUs, 8, 8, collectStats}; }
+};
+
+#define FAIL(ctx, code, msg)  \
+    do {                      \
+        (ctx)->err = (msg);   \
+        return (code);        \
+    } while (0)
+
+#define HIP_TRY(ctx, expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return HR_ERR_DEVICE;                                                                 \
+        }                                                                                         \
+    } while (0)
+
+#define ENTER(ctx)                                   \
+    if (!(ctx)) return HR_ERR_INVALID;               \
+    HIP_TRY(ctx, hipSetDevice((ctx)->device))
+
+static void freeQueues(hr_ctx *c)
+{
+    for (int i = 0; i < 2; ++i) {
+        hipFree(c->q[i].A), hipFree(c->q[i].B), hipFree(c->q[i].C), hipFree(c->q[i].D);
+        c->q[i] = RayQueue{};
+    }
+    hipFree(c->sq.A), hipFree(c->sq.B), hipFree(c->sq.C);
+    c->sq = ShadowQueue{};
+    hipFree(c->hits);
+    c->hits = nullptr;
+    c->queueCapacity = 0;
+}
+
+static void freeSceneDevice(hr_ctx *c)
+{
+    hipFree(c->nodes), hipFree(c->tris), hipFree(c->attrs), hipFree(c->attrsExt);
+    c->nodes = nullptr, c->tris = nullptr, c->attrs = nullptr, c->attrsExt = nullptr;
+}
+
+extern "C" {
+
+int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
+{
+    if (!out) return HR_ERR_INVALID;
+    *out = nullptr;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return HR_ERR_DEVICE;
+    hr_ctx *c = new hr_ctx();
+    if (desc) {
+        c->device = desc->device_id;
+        c->rank = desc->rank;
+        c->world = desc->world > 0 ? desc->world : 1;
+        c->tile = desc->tile_size > 0 ? desc->tile_size : 32;
+        c->stream = (hipStream_t)desc->stream;
+        c->collectStats = (desc->flags & HR_CTX_COLLECT_STATS) != 0;
+    }
+    if (c->device < 0 || c->device >= nDev || c->rank < 0 || c->rank >= c->world || (c->tile & 7) != 0) {
+        delete c;
+        return HR_ERR_INVALID;
+    }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(c->device) != hipSuccess || hipGetDeviceProperties(&prop, c->device) != hipSuccess) {
+        delete c;
+        return HR_ERR_DEVICE;
+    }
+    c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters)) != hipSuccess ||
+        hipMalloc(&c->dStats, sizeof(Stats)) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess) {
+        delete c;
+        return HR_ERR_DEVICE;
+    }
+    hipMemset(c->dStats, 0, sizeof(Stats));
+    hipMemset(c->dCounters, 0, sizeof(Counters));
+    *out = c;
+    return HR_OK;
+}
+
+int hr_ctx_destroy(hr_ctx *c)
+{
+    if (!c) return HR_OK;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    freeQueues(c);
+    freeSceneDevice(c);
+    for (Texture &t : c->textures) hipFree(t.dpx);
+    hipFree(c->fbInternal);
+    if (c->pinned) hipHostFree(c->pinned);
+    hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
+    hipFree(c->dScene), hipFree(c->dCounters), hipFree(c->dStats), hipFree(c->dScratch);
+    delete c;
+    return HR_OK;
+}
+
+const char *hr_last_error(const hr_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+int hr_ctx_set_stream(hr_ctx *c, void *stream)
+{
+    ENTER(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = (hipStream_t)stream;
+    return HR_OK;
+}
+
+int hr_synchronize(hr_ctx *c)
+{
+    ENTER(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ frame
+int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
+{
+    ENTER(c);
+    if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 28)) FAIL(c, HR_ERR_INVALID, "bad frame size");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->W = w, c->H = h;
+    hipFree(c->fbInternal);
+    c->fbInternal = nullptr;
+    c->fbExternal = nullptr;
+    const size_t fbBytes = (size_t)w * h * 4 * sizeof(float);
+    HIP_TRY(c, hipMalloc(&c->fbInternal, fbBytes));
+    HIP_TRY(c, hipMemsetAsync(c->fbInternal, 0, fbBytes, c->stream));
+    if (c->pinnedBytes < fbBytes) {
+        if (c->pinned) hipHostFree(c->pinned);
+        c->pinned = nullptr, c->pinnedBytes = 0;
+        HIP_TRY(c, hipHostMalloc((void **)&c->pinned, fbBytes, hipHostMallocDefault));
+        c->pinnedBytes = fbBytes;
+    }
+    FrameDev &f = c->frame;
+    f.W = w, f.H = h, f.rank = c->rank, f.world = c->world, f.tile = c->tile;
+    f.tilesX = (w + c->tile - 1) / c->tile, f.tilesY = (h + c->tile - 1) / c->tile;
+    const int nTiles = f.tilesX * f.tilesY;
+    f.nOwnedTiles = nTiles > c->rank ? (nTiles - c->rank + c->world - 1) / c->world : 0;
+    // one path per owned pixel: queue capacity = owned tiles x tile^2
+    freeQueues(c);
+    const uint32_t cap = (uint32_t)f.nOwnedTiles * (uint32_t)(c->tile * c->tile);
+    const size_t n16 = (size_t)(cap ? cap : 1) * 16;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(c, hipMalloc(&c->q[i].A, n16));
+        HIP_TRY(c, hipMalloc(&c->q[i].B, n16));
+        HIP_TRY(c, hipMalloc(&c->q[i].C, n16));
+        HIP_TRY(c, hipMalloc(&c->q[i].D, n16));
+    }
+    HIP_TRY(c, hipMalloc(&c->sq.A, n16));
+    HIP_TRY(c, hipMalloc(&c->sq.B, n16));
+    HIP_TRY(c, hipMalloc(&c->sq.C, n16));
+    HIP_TRY(c, hipMalloc(&c->hits, (size_t)(cap ? cap : 1) * hitRecordSize()));
+    c->queueCapacity = cap;
+    return HR_OK;
+}
+
+int hr_frame_bind_external(hr_ctx *c, void *deviceRgba)
+{
+    ENTER(c);
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->fbExternal = (float *)deviceRgba;
+    return HR_OK;
+}
+
+int hr_frame_device_ptr(hr_ctx *c, void **deviceRgba)
+{
+    ENTER(c);
+    if (c->W <= 0 || !deviceRgba) FAIL(c, HR_ERR_INVALID, "no frame");
+    *deviceRgba = c->fb();
+    return HR_OK;
+}
+
+// --------------------------------------------------------------------------------------- geometry
+static void copyAttr(std::vector<float> &dst, const float *src, int stride, int comps, int n)
+{
+    dst.clear();
+    if (!src) return;
+    if (stride == 0) stride = comps * (int)sizeof(float);
+    dst.resize((size_t)n * comps);
+    for (int i = 0; i < n; ++i) std::memcpy(&dst[(size_t)i * comps], (const char *)src + (size_t)i * stride, comps * sizeof(float));
+}
+
+int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
+{
+    ENTER(c);
+    if (!d || !d->positions || !d->normals || !d->indices || d->n_vertices <= 0 || d->n_indices < 0)
+        FAIL(c, HR_ERR_INVALID, "mesh needs positions, normals, indices");
+    if (d->mode != HR_TRIANGLES && d->mode != HR_TRIANGLE_STRIP) FAIL(c, HR_ERR_INVALID, "unsupported draw mode");
+    for (int i = 0; i < d->n_indices; ++i)
+        if (d->indices[i] >= (uint32_t)d->n_vertices) FAIL(c, HR_ERR_INVALID, "index out of range");
+    Geom g;
+    g.alive = true;
+    g.nVerts = d->n_vertices;
+    copyAttr(g.pos, d->positions, d->position_stride, 3, d->n_vertices);
+    copyAttr(g.nrm, d->normals, d->normal_stride, 3, d->n_vertices);
+    copyAttr(g.uv, d->uvs, d->uv_stride, 2, d->n_vertices);
+    copyAttr(g.tan, d->tangents, d->tangent_stride, 3, d->n_vertices);
+    copyAttr(g.bit, d->bitangents, d->bitangent_stride, 3, d->n_vertices);
+    copyAttr(g.col, d->colors, d->color_stride, 3, d->n_vertices);
+    g.idx.assign(d->indices, d->indices + d->n_indices);
+    g.mode = d->mode;
+    std::memcpy(g.world, d->world_from_entity, sizeof(g.world));
+    g.frontFaceCW = d->front_face_cw, g.isOccluder = d->is_occluder, g.material = d->material_id;
+    c->geoms.push_back(std::move(g));
+    c->committed = false;
+    if (out) *out = (hr_geom_id)c->geoms.size() - 1;
+    return HR_OK;
+}
+
+int hr_geom_remove(hr_ctx *c, hr_geom_id id)
+{
+    ENTER(c);
+    if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive) FAIL(c, HR_ERR_INVALID, "bad geom id");
+    c->geoms[id] = Geom();
+    c->committed = false;
+    return HR_OK;
+}
+
+int hr_geom_set_transform(hr_ctx *c, hr_geom_id id, const float m[16])
+{
+    ENTER(c);
+    if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive || !m) FAIL(c, HR_ERR_INVALID, "bad geom id");
+    std::memcpy(c->geoms[id].world, m, 16 * sizeof(float));
+    c->committed = false;
+    return HR_OK;
+}
+
+int hr_scene_clear(hr_ctx *c)
+{
+    ENTER(c);
+    c->geoms.clear();
+    c->committed = false;
+    return HR_OK;
+}
+
+static inline float floatFromOrdered(uint32_t u)
+{
+    uint32_t b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
+    float f;
+    std::memcpy(&f, &b, 4);
+    return f;
+}
+
+int hr_scene_commit(hr_ctx *c)
+{
+    ENTER(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0));
+    HIP_TRY(c, hipEventCreate(&e1));
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    freeSceneDevice(c);
+    // ---- stage every live geometry into one device buffer
+    std::vector<GeomDev> gd;
+    std::vector<float> stageF;
+    std::vector<uint32_t> stageI;
+    struct Off {
+        size_t pos, nrm, uv, tan, bit, col, idx;
+    };
+    std::vector<Off> offs;
+    uint32_t nTris = 0;
+    bool anyExt = false;
+    const size_t none = (size_t)-1;
+    auto push = [&](const std::vector<float> &v) {
+        if (v.empty()) return none;
+        size_t o = stageF.size();
+        stageF.insert(stageF.end(), v.begin(), v.end());
+        return o;
+    };
+    for (const Geom &g : c->geoms) {
+        if (!g.alive || g.nTris() == 0) continue;
+        GeomDev d{};
+        Off o;
+        o.pos = push(g.pos), o.nrm = push(g.nrm), o.uv = push(g.uv), o.tan = push(g.tan), o.bit = push(g.bit), o.col = push(g.col);
+        o.idx = stageI.size();
+        stageI.insert(stageI.end(), g.idx.begin(), g.idx.end());
+        d.triOffset = nTris, d.nTris = g.nTris(), d.strip = g.mode == HR_TRIANGLE_STRIP;
+        d.flags = (g.frontFaceCW ? TF_FRONT_CW : 0u) | (g.isOccluder ? 0u : TF_NON_OCCLUDER) | (!g.uv.empty() ? TF_HAS_UV : 0u) |
+                  ((!g.tan.empty() && !g.bit.empty()) ? TF_HAS_TANGENTS : 0u) | (!g.col.empty() ? TF_HAS_COLORS : 0u);
+        d.material = (uint32_t)g.material;
+        std::memcpy(d.world, g.world, sizeof(d.world));
+        if (d.flags & (TF_HAS_TANGENTS | TF_HAS_COLORS)) anyExt = true;
+        nTris += d.nTris;
+        gd.push_back(d);
+        offs.push_back(o);
+    }
+    std::memset(&c->info, 0, sizeof(c->info));
+    c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0;
+    c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
+    c->hScene.rayEps = 0.0f;
+    if (nTris > 0) {
+        float *dF = nullptr;
+        uint32_t *dI = nullptr;
+        GeomDev *dG = nullptr;
+        Tri *trisPrim = nullptr;
+        HIP_TRY(c, hipMalloc(&dF, stageF.size() * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&dI, stageI.size() * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&dG, gd.size() * sizeof(GeomDev)));
+        HIP_TRY(c, hipMalloc(&trisPrim, sizeof(Tri) * (size_t)nTris));
+        HIP_TRY(c, hipMalloc(&c->attrs, sizeof(TriAttr) * (size_t)nTris));
+        if (anyExt) HIP_TRY(c, hipMalloc(&c->attrsExt, sizeof(TriAttrExt) * (size_t)nTris));
+        for (size_t i = 0; i < gd.size(); ++i) {
+            const Off &o = offs[i];
+            gd[i].pos = dF + o.pos, gd[i].nrm = dF + o.nrm;
+            gd[i].uv = o.uv == none ? nullptr : dF + o.uv;
+            gd[i].tan = o.tan == none ? nullptr : dF + o.tan;
+            gd[i].bit = o.bit == none ? nullptr : dF + o.bit;
+            gd[i].col = o.col == none ? nullptr : dF + o.col;
+            gd[i].idx = dI + o.idx;
+        }
+        HIP_TRY(c, hipMemcpyAsync(dF, stageF.data(), stageF.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dI, stageI.data(), stageI.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(dG, gd.data(), gd.size() * sizeof(GeomDev), hipMemcpyHostToDevice, c->stream));
+        const uint32_t initB[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+        HIP_TRY(c, hipMemcpyAsync(c->dScratch, initB, sizeof(initB), hipMemcpyHostToDevice, c->stream));
+        launchAssemble(c->stream, dG, (int)gd.size(), nTris, trisPrim, c->attrs, c->attrsExt, c->dScratch);
+        uint32_t ob[6];
+        HIP_TRY(c, hipMemcpyAsync(ob, c->dScratch, sizeof(ob), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        float lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) lo[k] = floatFromOrdered(ob[k]), hi[k] = floatFromOrdered(ob[3 + k]);
+        // |hi - lo| with the contract's operation order: sqrt((x*x + y*y) + z*z)
+        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
+        const float diag = sqrtf(ex * ex + ey * ey + ez * ez);
+        const float pad = 1e-5f * diag;
+        BuildResult br{};
+        const int rc = buildLBVH(c->stream, trisPrim, nTris, lo, hi, pad, &br);
+        hipFree(dF), hipFree(dI), hipFree(dG), hipFree(trisPrim);
+        if (rc != 0) {
+            hipFree(br.nodes), hipFree(br.tris);
+            FAIL(c, HR_ERR_DEVICE, rc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
+        }
+        c->nodes = br.nodes, c->tris = br.tris;
+        c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = c->attrsExt;
+        c->hScene.nTris = (int)nTris, c->hScene.nNodes = br.nNodes, c->hScene.rootLeafCount = br.rootLeafCount;
+        c->hScene.rayEps = 1e-4f * diag;
+        for (int k = 0; k < 3; ++k) c->info.aabb_min[k] = lo[k], c->info.aabb_max[k] = hi[k];
+        c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)br.nNodes, c->info.ray_epsilon = c->hScene.rayEps;
+    }
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    hipEventElapsedTime(&c->info.build_ms, e0, e1);
+    hipEventDestroy(e0), hipEventDestroy(e1);
+    c->committed = true;
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+int hr_scene_get_info(hr_ctx *c, hr_scene_info *out)
+{
+    ENTER(c);
+    if (!c->committed || !out) FAIL(c, HR_ERR_INVALID, "scene not committed");
+    *out = c->info;
+    return HR_OK;
+}
+
+// --------------------------------------------------------------------------------------- textures
+int hr_texture_create(hr_ctx *c, const hr_texture_desc *d, const void *pixels, hr_tex_id *out)
+{
+    ENTER(c);
+    if (!d || !pixels || d->width <= 0 || d->height <= 0 || (d->channels != 1 && d->channels != 3 && d->channels != 4))
+        FAIL(c, HR_ERR_INVALID, "bad texture descriptor");
+    const size_t n = (size_t)d->width * d->height * d->channels;
+    std::vector<float> tmp;
+    const float *src = (const float *)pixels;
+    if (d->dtype == HR_TEX_U8) { // normalised: float(byte) / 255.0f
+        tmp.resize(n);
+        const uint8_t *p = (const uint8_t *)pixels;
+        for (size_t i = 0; i < n; ++i) tmp[i] = (float)p[i] / 255.0f;
+        src = tmp.data();
+    } else if (d->dtype != HR_TEX_F32) {
+        FAIL(c, HR_ERR_INVALID, "bad texture dtype");
+    }
+    Texture t;
+    HIP_TRY(c, hipMalloc(&t.dpx, n * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(t.dpx, src, n * sizeof(float), hipMemcpyHostToDevice));
+    t.desc = TexDesc{t.dpx, d->width, d->height, d->channels, d->wrap_s, d->wrap_t, d->filter};
+    t.alive = true;
+    c->textures.push_back(t);
+    c->sceneDirty = true;
+    if (out) *out = (hr_tex_id)c->textures.size() - 1;
+    return HR_OK;
+}
+
+int hr_texture_destroy(hr_ctx *c, hr_tex_id id)
+{
+    ENTER(c);
+    if (id < 0 || id >= (int)c->textures.size() || !c->textures[id].alive) FAIL(c, HR_ERR_INVALID, "bad texture id");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(c->textures[id].dpx);
+    c->textures[id] = Texture();
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+int hr_material_set(hr_ctx *c, int32_t id, const hr_material *m)
+{
+    ENTER(c);
+    if (id < 0 || id > (1 << 20) || !m) FAIL(c, HR_ERR_INVALID, "bad material id");
+    if ((int)c->materials.size() <= id) {
+        hr_material none{};
+        none.type = -1;
+        c->materials.resize(id + 1, none);
+    }
+    c->materials[id] = *m;
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+int hr_lights_set(hr_ctx *c, const hr_lights *l)
+{
+    ENTER(c);
+    if (!l || l->n_directional < 0 || l->n_directional > HR_MAX_DIRECTIONAL_LIGHTS || l->n_point < 0 || l->n_point > HR_MAX_POINT_LIGHTS ||
+        l->n_spot < 0 || l->n_spot > HR_MAX_SPOT_LIGHTS)
+        FAIL(c, HR_ERR_INVALID, "bad light block");
+    c->lights = *l;
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+// ----------------------------------------------------------------------------------- sample tables
+static int setTable(hr_ctx *c, float2 **dst, const float *src, size_t n)
+{
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(*dst);
+    *dst = nullptr;
+    HIP_TRY(c, hipMalloc(dst, n * sizeof(float2)));
+    if (src) HIP_TRY(c, hipMemcpy(*dst, src, n * sizeof(float2), hipMemcpyHostToDevice));
+    return HR_OK;
+}
+
+int hr_sequences_set(hr_ctx *c, const float *seq, const float *ap, int32_t nSeq, int32_t len)
+{
+    ENTER(c);
+    if (!seq || !ap || nSeq <= 0 || nSeq > 255 || len <= 0) FAIL(c, HR_ERR_INVALID, "bad sequence table");
+    int rc = setTable(c, &c->dSeq, seq, (size_t)nSeq * len);
+    if (rc) return rc;
+    rc = setTable(c, &c->dAperture, ap, (size_t)nSeq * len);
+    if (rc) return rc;
+    c->nSeq = nSeq, c->seqLen = len;
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+int hr_seq_offsets_set(hr_ctx *c, const float *off, int32_t n)
+{
+    ENTER(c);
+    if (!off || n <= 0) FAIL(c, HR_ERR_INVALID, "bad offsets table");
+    int rc = setTable(c, &c->dSeqOffsets, off, (size_t)n);
+    if (rc) return rc;
+    c->nSeqOffsets = n;
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+int hr_qmc_generate(hr_ctx *c, int32_t mode, uint32_t seqIndex, uint32_t count, int32_t radial, float *out)
+{
+    ENTER(c);
+    if (mode != HR_SAMPLE_SOBOL && mode != HR_SAMPLE_HALTON && mode != HR_SAMPLE_HAMMERSLEY)
+        FAIL(c, HR_ERR_UNSUPPORTED, "sample mode has no device generator (host tables only)");
+    if (radial && mode != HR_SAMPLE_SOBOL) FAIL(c, HR_ERR_INVALID, "radial is defined for Sobol only");
+    if (count == 0 || !out) FAIL(c, HR_ERR_INVALID, "bad count / output");
+    float2 *d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, (size_t)count * sizeof(float2)));
+    launchQmc(c->stream, mode, seqIndex, count, radial, d);
+    hipError_t e = hipMemcpyAsync(out, d, (size_t)count * sizeof(float2), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    HIP_TRY(c, e);
+    return HR_OK;
+}
+
+int hr_sequences_generate(hr_ctx *c, int32_t sampleMode, int32_t bokeh, int32_t len)
+{
+    ENTER(c);
+    if (sampleMode != HR_SAMPLE_SOBOL && sampleMode != HR_SAMPLE_HALTON && sampleMode != HR_SAMPLE_HAMMERSLEY)
+        FAIL(c, HR_ERR_UNSUPPORTED, "sample mode has no device generator: upload host tables with hr_sequences_set");
+    if (bokeh != HR_BOKEH_CIRCULAR) FAIL(c, HR_ERR_UNSUPPORTED, "polygonal bokeh tables are host-generated: use hr_sequences_set");
+    if (len <= 0) FAIL(c, HR_ERR_INVALID, "bad sequence length");
+    const int nSeq = HR_NUM_RANDOM_SEQUENCES;
+    int rc = setTable(c, &c->dSeq, nullptr, (size_t)nSeq * len);
+    if (rc) return rc;
+    rc = setTable(c, &c->dAperture, nullptr, (size_t)nSeq * len);
+    if (rc) return rc;
+    for (int s = 0; s < nSeq; ++s) { // PassGenerator.cpp:614-662
+        launchQmc(c->stream, sampleMode, (uint32_t)s, (uint32_t)len, 0, c->dSeq + (size_t)s * len);
+        launchQmc(c->stream, HR_SAMPLE_SOBOL, (uint32_t)s, (uint32_t)len, 1, c->dAperture + (size_t)s * len);
+    }
+    HIP_TRY(c, hipGetLastError());
+    c->nSeq = nSeq, c->seqLen = len;
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+int hr_seq_offsets_generate(hr_ctx *c)
+{
+    ENTER(c);
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    const size_t n = (size_t)c->W * c->H;
+    int rc = setTable(c, &c->dSeqOffsets, nullptr, n);
+    if (rc) return rc;
+    launchQmc(c->stream, HR_SAMPLE_SOBOL, 0, (uint32_t)n, 0, c->dSeqOffsets); // PassGenerator.cpp:150-159
+    HIP_TRY(c, hipGetLastError());
+    c->nSeqOffsets = (int)n;
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
+int hr_multiscatter_lut_generate(hr_ctx *c, float *out, hr_tex_id *outTex)
+{
+    ENTER(c);
+    float2 *seq = nullptr;
+    float *lut = nullptr;
+    HIP_TRY(c, hipMalloc(&seq, 4096 * sizeof(float2)));
+    HIP_TRY(c, hipMalloc(&lut, 128 * 128 * sizeof(float)));
+    launchQmc(c->stream, HR_SAMPLE_SOBOL, 0, 4096, 0, seq); // MultiScatterUtil.cpp:102-104
+    launchMultiscatterLUT(c->stream, seq, lut);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && out) e = hipMemcpy(out, lut, 128 * 128 * sizeof(float), hipMemcpyDeviceToHost);
+    hipFree(seq);
+    if (e != hipSuccess) {
+        hipFree(lut);
+        HIP_TRY(c, e);
+    }
+    if (outTex) { // loadMultiscatterTexture: LINEAR + CLAMP_TO_EDGE sampler (TextureLoader.cpp:36-41)
+        Texture t;
+        t.dpx = lut;
+        t.desc = TexDesc{lut, 128, 128, 1, HR_WRAP_CLAMP_TO_EDGE, HR_WRAP_CLAMP_TO_EDGE, HR_FILTER_LINEAR};
+        t.alive = true;
+        c->textures.push_back(t);
+        c->sceneDirty = true;
+        *outTex = (hr_tex_id)c->textures.size() - 1;
+    } else {
+        hipFree(lut);
+    }
+    return HR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ pass
+static int uploadScene(hr_ctx *c)
+{
+    if (!c->sceneDirty) return HR_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->dMaterialsCap < c->materials.size() || !c->dMaterials) {
+        hipFree(c->dMaterials);
+        c->dMaterialsCap = c->materials.size() + 16;
+        HIP_TRY(c, hipMalloc(&c->dMaterials, c->dMaterialsCap * sizeof(hr_material)));
+    }
+    if (!c->materials.empty())
+        HIP_TRY(c, hipMemcpy(c->dMaterials, c->materials.data(), c->materials.size() * sizeof(hr_material), hipMemcpyHostToDevice));
+    if (c->dTexturesCap < c->textures.size() || !c->dTextures) {
+        hipFree(c->dTextures);
+        c->dTexturesCap = c->textures.size() + 16;
+        HIP_TRY(c, hipMalloc(&c->dTextures, c->dTexturesCap * sizeof(TexDesc)));
+    }
+    std::vector<TexDesc> td(c->textures.size());
+    for (size_t i = 0; i < td.size(); ++i) {
+        td[i] = c->textures[i].desc;
+        if (!c->textures[i].alive) td[i].px = nullptr;
+    }
+    if (!td.empty()) HIP_TRY(c, hipMemcpy(c->dTextures, td.data(), td.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+    SceneDev &s = c->hScene;
+    s.materials = c->dMaterials, s.nMaterials = (int)c->materials.size();
+    s.textures = c->dTextures, s.nTextures = (int)c->textures.size();
+    s.lights = c->lights;
+    s.seq = c->dSeq, s.aperture = c->dAperture, s.seqOffsets = c->dSeqOffsets;
+    s.nSeq = c->nSeq, s.seqLen = c->seqLen, s.nSeqOffsets = c->nSeqOffsets;
+    HIP_TRY(c, hipMemcpy(c->dScene, &s, sizeof(SceneDev), hipMemcpyHostToDevice));
+    // rays can outlive maxRayDepth only by passing through single-sided / alpha-masked surfaces
+    c->hasPassthrough = false;
+    for (const hr_material &m : c->materials)
+        if (m.type == HR_MAT_PBR && (!(m.flags & HR_MF_DOUBLE_SIDED) || (m.flags & HR_MF_ALPHA_MASK))) c->hasPassthrough = true;
+    c->sceneDirty = false;
+    return HR_OK;
+}
+
+int hr_clear(hr_ctx *c)
+{
+    ENTER(c);
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    HIP_TRY(c, hipMemsetAsync(c->fb(), 0, (size_t)c->W * c->H * 4 * sizeof(float), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats), c->stream));
+    return HR_OK;
+}
+
+int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
+{
+    ENTER(c);
+    if (!pp) FAIL(c, HR_ERR_INVALID, "null params");
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    if (!c->committed) FAIL(c, HR_ERR_INVALID, "scene not committed");
+    if (c->nSeq <= 0 || c->nSeqOffsets <= 0) FAIL(c, HR_ERR_INVALID, "sample tables not set");
+    if (pp->max_ray_depth < 0 || pp->max_ray_depth + 2 >= kMaxBounceSlots - 8) FAIL(c, HR_ERR_INVALID, "max_ray_depth out of range");
+    if (pp->interactive_mode && (pp->block_size[0] <= 0 || pp->block_size[1] <= 0)) FAIL(c, HR_ERR_INVALID, "bad block size");
+    int rc = uploadScene(c);
+    if (rc) return rc;
+    if (c->frame.nOwnedTiles == 0) return HR_OK;
+    const LaunchCfg cfg = c->cfg();
+    FrameDev fr = c->frame;
+    fr.fb = c->fb();
+    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(Counters), c->stream));
+    launchRaygen(cfg, c->dScene, *pp, fr, c->q[0], c->dCounters, c->dStats);
+    int slot = 0;
+    int nIter = pp->max_ray_depth + 1;
+    for (;;) {
+        for (; slot < nIter; ++slot) {
+            launchTraceClosest(cfg, c->dScene, c->q[slot & 1], c->hits, c->dCounters, c->dStats, slot);
+            if (slot > 0) launchTraceShadow(cfg, c->dScene, c->sq, fr.fb, c->dCounters, c->dStats, slot - 1);
+            launchShade(cfg, c->dScene, *pp, fr.fb, c->q[slot & 1], c->hits, c->q[(slot + 1) & 1], c->sq, c->dCounters, c->dStats, slot);
+        }
+        if (!c->hasPassthrough || slot >= kMaxBounceSlots - 2) break;
+        // pass-through rays (back faces of single-sided materials, alpha masks) are not bounded by maxRayDepth
+        uint32_t remaining = 0;
+        HIP_TRY(c, hipMemcpyAsync(&remaining, &c->dCounters->qCount[slot], 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (remaining == 0) break;
+        nIter = slot + 4 < kMaxBounceSlots - 2 ? slot + 4 : kMaxBounceSlots - 2;
+    }
+    launchTraceShadow(cfg, c->dScene, c->sq, fr.fb, c->dCounters, c->dStats, slot - 1);
+    HIP_TRY(c, hipGetLastError());
+    return HR_OK;
+}
+
+int hr_get_stats(hr_ctx *c, hr_pass_stats *out)
+{
+    ENTER(c);
+    if (!out) FAIL(c, HR_ERR_INVALID, "null output");
+    Stats s;
+    HIP_TRY(c, hipMemcpyAsync(&s, c->dStats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->paths = s.paths, out->rays_closest = s.raysClosest, out->rays_any = s.raysAny, out->shaded_hits = s.shadedHits;
+    out->accumulates = s.accumulates, out->node_visits = s.nodeVisits, out->tri_tests = s.triTests;
+    return HR_OK;
+}
+
+int hr_readback(hr_ctx *c, const float **rgba, int32_t *w, int32_t *h)
+{
+    ENTER(c);
+    if (c->W <= 0 || !rgba) FAIL(c, HR_ERR_INVALID, "no frame");
+    const size_t bytes = (size_t)c->W * c->H * 4 * sizeof(float);
+    HIP_TRY(c, hipMemcpyAsync(c->pinned, c->fb(), bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *rgba = c->pinned;
+    if (w) *w = c->W;
+    if (h) *h = c->H;
+    return HR_OK;
+}
+
+int hr_debug_trace(hr_ctx *c, int32_t n, const float *o, const float *d, const float *tmax, const int32_t *skip, int32_t anyHit, hr_hit *out)
+{
+    ENTER(c);
+    if (!c->committed) FAIL(c, HR_ERR_INVALID, "scene not committed");
+    if (n <= 0 || !o || !d || !out) FAIL(c, HR_ERR_INVALID, "bad arguments");
+    int rc = uploadScene(c);
+    if (rc) return rc;
+    float *dO = nullptr, *dD = nullptr, *dT = nullptr;
+    int *dS = nullptr;
+    hr_hit *dH = nullptr;
+    HIP_TRY(c, hipMalloc(&dO, (size_t)n * 12));
+    HIP_TRY(c, hipMalloc(&dD, (size_t)n * 12));
+    HIP_TRY(c, hipMalloc(&dH, (size_t)n * sizeof(hr_hit)));
+    HIP_TRY(c, hipMemcpy(dO, o, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(dD, d, (size_t)n * 12, hipMemcpyHostToDevice));
+    if (tmax) {
+        HIP_TRY(c, hipMalloc(&dT, (size_t)n * 4));
+        HIP_TRY(c, hipMemcpy(dT, tmax, (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    if (skip) {
+        HIP_TRY(c, hipMalloc(&dS, (size_t)n * 4));
+        HIP_TRY(c, hipMemcpy(dS, skip, (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    launchDebugTrace(c->cfg(), c->dScene, n, dO, dD, dT, dS, anyHit, dH);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, dH, (size_t)n * sizeof(hr_hit), hipMemcpyDeviceToHost);
+    hipFree(dO), hipFree(dD), hipFree(dT), hipFree(dS), hipFree(dH);
+    HIP_TRY(c, e);
+    return HR_OK;
+}
+
+} // extern "C"

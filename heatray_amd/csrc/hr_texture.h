@@ -1,0 +1,57 @@
+// hr_texture.h — texture2D at LOD 0 (bilinear / nearest, repeat / clamp-to-edge).
+//
+// Replaces OpenRL's texture unit for openrl::Texture objects
+// (/root/reference/Source/RLWrapper/Texture.h:26-93).  OpenRL's filtering without ray differentials
+// is parity-unpinned; this build samples level 0 with GL texel addressing.
+#pragma once
+
+#include "hr_types.h"
+
+namespace hr {
+
+HRD int wrapIndex(int i, int n, int mode)
+{
+    if (mode == HR_WRAP_CLAMP_TO_EDGE) return i < 0 ? 0 : (i >= n ? n - 1 : i);
+    int m = i % n;
+    return m < 0 ? m + n : m;
+}
+
+HRD v4 texel(const TexDesc &t, int x, int y)
+{
+    const float *p = t.px + ((size_t)y * t.w + x) * t.c;
+    v4 r;
+    if (t.c == 1) { // RL_LUMINANCE
+        r.x = r.y = r.z = p[0];
+        r.w = 1.0f;
+    } else if (t.c == 3) {
+        r.x = p[0], r.y = p[1], r.z = p[2], r.w = 1.0f;
+    } else {
+        r.x = p[0], r.y = p[1], r.z = p[2], r.w = p[3];
+    }
+    return r;
+}
+
+HRD v4 sampleTexture(const TexDesc &t, float u, float v)
+{
+    if (t.filter == HR_FILTER_NEAREST) {
+        int x = wrapIndex((int)floor_(u * (float)t.w), t.w, t.wrapS);
+        int y = wrapIndex((int)floor_(v * (float)t.h), t.h, t.wrapT);
+        return texel(t, x, y);
+    }
+    float x = u * (float)t.w - 0.5f;
+    float y = v * (float)t.h - 0.5f;
+    float x0f = floor_(x), y0f = floor_(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = wrapIndex((int)x0f, t.w, t.wrapS), x1 = wrapIndex((int)x0f + 1, t.w, t.wrapS);
+    int y0 = wrapIndex((int)y0f, t.h, t.wrapT), y1 = wrapIndex((int)y0f + 1, t.h, t.wrapT);
+    v4 c00 = texel(t, x0, y0), c10 = texel(t, x1, y0), c01 = texel(t, x0, y1), c11 = texel(t, x1, y1);
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    v4 r;
+    r.x = (c00.x * gx + c10.x * fx) * gy + (c01.x * gx + c11.x * fx) * fy;
+    r.y = (c00.y * gx + c10.y * fx) * gy + (c01.y * gx + c11.y * fx) * fy;
+    r.z = (c00.z * gx + c10.z * fx) * gy + (c01.z * gx + c11.z * fx) * fy;
+    r.w = (c00.w * gx + c10.w * fx) * gy + (c01.w * gx + c11.w * fx) * fy;
+    return r;
+}
+
+} // namespace hr

@@ -1,0 +1,90 @@
+// hr_types.h — device-resident data layouts of libhrcore (DESIGN.md §Data layout in HBM).
+#pragma once
+
+#include "../../include/hrcore.h"
+#include "hr_math.h"
+
+namespace hr {
+
+// ---- acceleration structure -------------------------------------------------------------------
+// Binary BVH node holding BOTH child boxes: one 64-byte, 64-byte-aligned record = four dwordx4 loads.
+//   a = (lo0.x lo0.y lo0.z hi0.x)  b = (hi0.y hi0.z lo1.x lo1.y)  c = (lo1.z hi1.x hi1.y hi1.z)
+//   d = (child0, child1, -, -)   child >= 0: node index; child < 0: leaf ~(first | (count-1) << 28)
+struct alignas(64) Node {
+    float4 a, b, c;
+    int4 d;
+};
+
+// World-space triangle in BVH leaf order, 48 bytes = three dwordx4 loads:
+//   p = (v0.x v0.y v0.z e1.x)  q = (e1.y e1.z e2.x e2.y)  r = (e2.z, prim id, flags, -)
+struct alignas(16) Tri {
+    float4 p, q, r;
+};
+
+// Shading attributes per triangle in SUBMISSION order (prim id), 64 bytes:
+//   n0 n1 n2 (world normals, 9 floats) uv0 uv1 uv2 (6 floats) matflags (material id | TF_* << 24)
+struct alignas(64) TriAttr {
+    float n[9];
+    float uv[6];
+    uint32_t matflags;
+};
+// Optional per-triangle tangent / bitangent / colour varyings (only allocated when a mesh has them)
+struct alignas(16) TriAttrExt {
+    float tan[9], bit[9], col[9];
+    float pad;
+};
+
+enum : uint32_t { TF_FRONT_CW = 1u, TF_NON_OCCLUDER = 2u, TF_HAS_UV = 4u, TF_HAS_TANGENTS = 8u, TF_HAS_COLORS = 16u };
+static const uint32_t kMatMask = 0x00FFFFFFu;
+
+// ---- textures ---------------------------------------------------------------------------------
+struct TexDesc {
+    const float *px; // w*h*c floats, row 0 = bottom
+    int32_t w, h, c;
+    int32_t wrapS, wrapT, filter;
+};
+
+// ---- ray queues (structure of arrays, one float4 / int4 stream per field group) -----------------
+//   A = (origin.xyz, tmax)   B = (dir.xyz, extraT)   C = (weight.xyz, pixel bits)
+//   D = (meta, sequenceIndexOffset, srcPrim, -)
+//   meta = sequenceID | depth << 8 | missKind << 24 | missIdx << 27
+struct RayQueue {
+    float4 *A, *B, *C;
+    int4 *D;
+};
+// Occlusion (NEE) rays: A = (origin.xyz, tmax)  B = (dir.xyz, srcPrim bits)
+//   C = (value.rgb, pixel bits): the clamped radiance the light shader adds when the ray is unoccluded
+struct ShadowQueue {
+    float4 *A, *B, *C;
+};
+// closest-hit record: prim | frontCCW << 31 (prim == 0x7FFFFFFF: miss), t, u, v
+static const uint32_t kMissPrim = 0x7FFFFFFFu;
+
+enum MissKind { MISS_NONE = 0, MISS_ENV = 1, MISS_DIR = 2, MISS_POINT = 3, MISS_SPOT = 4 };
+
+// ---- per-scene constant block (device copy) ---------------------------------------------------
+struct SceneDev {
+    const Node *nodes;
+    const Tri *tris;
+    const TriAttr *attrs;
+    const TriAttrExt *attrsExt; // may be null
+    const hr_material *materials;
+    const TexDesc *textures;
+    int32_t nTris, nNodes, rootLeafCount, nMaterials, nTextures;
+    float rayEps;
+    hr_lights lights;
+    // sample tables
+    const float2 *seq, *aperture, *seqOffsets;
+    int32_t nSeq, seqLen, nSeqOffsets;
+};
+
+// ---- counters ---------------------------------------------------------------------------------
+static const int kMaxBounceSlots = 72;
+struct Counters {
+    uint32_t qCount[kMaxBounceSlots]; // rays in the closest-hit queue of iteration i
+    uint32_t sCount[kMaxBounceSlots]; // rays in the occlusion queue produced by iteration i
+    uint32_t qHead[kMaxBounceSlots];  // work-fetch cursors of the persistent trace kernels
+    uint32_t sHead[kMaxBounceSlots];
+};
+
+} // namespace hr

@@ -3,7 +3,7 @@
  *
  * This is the drop-in boundary.  The reference talks to its
  * ray engine through the OpenRL C API (3rdParty/OpenRL/rl.h:383-528) wrapped
- * by Source/RLWrapper/*.h; this header declares the entry points a
+ * by the headers in Source/RLWrapper/; this header declares the entry points a
  * re-implemented PassGenerator / Scene / Mesh / Material / Light layer binds
  * instead.  Every entry point cites the reference interface it replaces.
  *

@@ -889,12 +889,14 @@ struct Shader {
             Ray nee, next;
             const int mid = ctx.attrs[h.prim].material;
             if (mid >= 0 && mid < (int)ctx.materials.size()) {
-                st.shaded_hits++;
                 const hr_material &M = ctx.materials[mid];
-                if (M.type == HR_MAT_GLASS)
+                if (M.type == HR_MAT_GLASS) {
+                    st.shaded_hits++;
                     glass(ray, h, M, nee, next);
-                else
+                } else if (M.type == HR_MAT_PBR) {
+                    st.shaded_hits++;
                     physicallyBased(ray, h, M, nee, next);
+                }
             }
             if (nee.valid) {
                 st.rays_any++;
