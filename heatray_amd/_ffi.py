@@ -15,6 +15,8 @@ HR_MAX_LIGHTS = 5
 HR_NUM_RANDOM_SEQUENCES = 16
 
 HR_CTX_COLLECT_STATS = 1
+HR_CTX_TIME_KERNELS = 2
+HR_KERNEL_NAMES = ("raygen", "trace_closest", "trace_any", "shade")
 
 HR_TRIANGLES, HR_TRIANGLE_STRIP = 0, 1
 HR_TEX_U8, HR_TEX_F32 = 0, 1
@@ -104,10 +106,14 @@ class PassParams(C.Structure):
 class PassStats(C.Structure):
     _fields_ = [("ms", C.c_float), ("paths", C.c_uint64), ("rays_closest", C.c_uint64), ("rays_any", C.c_uint64),
                 ("shaded_hits", C.c_uint64), ("accumulates", C.c_uint64), ("node_visits", C.c_uint64),
-                ("tri_tests", C.c_uint64)]
+                ("tri_tests", C.c_uint64), ("node_visits_any", C.c_uint64), ("tri_tests_any", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4)]
 
 
 class Hit(C.Structure):
@@ -122,7 +128,7 @@ ABI_SYMBOLS = [
     "frame_device_ptr", "geom_add", "geom_remove", "geom_set_transform", "scene_clear", "scene_commit",
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
-    "clear", "render_pass", "get_stats", "readback", "synchronize", "debug_trace",
+    "clear", "render_pass", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
 ]
 
 
@@ -293,6 +299,12 @@ class Engine:
         s = PassStats()
         self._call("get_stats", C.byref(s))
         return s
+
+    def kernel_times(self):
+        """{kernel: (total_ms, launches)} since the last clear (HR_CTX_TIME_KERNELS contexts only)."""
+        t = KernelTimes()
+        self._call("get_kernel_times", C.byref(t))
+        return {n: (t.ms[i], t.launches[i]) for i, n in enumerate(HR_KERNEL_NAMES)}
 
     def synchronize(self):
         self._call("synchronize")

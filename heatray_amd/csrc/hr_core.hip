@@ -77,6 +77,54 @@ struct hr_ctx {
     Stats *dStats = nullptr;
     uint32_t *dScratch = nullptr; // 8 words: ordered bounds etc.
 
+    // optional per-kernel timing (HR_CTX_TIME_KERNELS)
+    bool timeKernels = false;
+    struct Timed {
+        int kind;
+        hipEvent_t e0, e1;
+    };
+    std::vector<Timed> pending;
+    std::vector<hipEvent_t> eventPool;
+    float kernelMs[HR_KERNEL_COUNT] = {0, 0, 0, 0};
+    uint32_t kernelLaunches[HR_KERNEL_COUNT] = {0, 0, 0, 0};
+    hipEvent_t getEvent()
+    {
+        hipEvent_t e = nullptr;
+        if (!eventPool.empty()) {
+            e = eventPool.back();
+            eventPool.pop_back();
+        } else {
+            hipEventCreate(&e);
+        }
+        return e;
+    }
+    void timeBegin(int kind)
+    {
+        if (!timeKernels) return;
+        Timed t{kind, getEvent(), getEvent()};
+        hipEventRecord(t.e0, stream);
+        pending.push_back(t);
+    }
+    void timeEnd()
+    {
+        if (!timeKernels) return;
+        hipEventRecord(pending.back().e1, stream);
+    }
+    void drainTimes()
+    {
+        if (pending.empty()) return;
+        hipStreamSynchronize(stream);
+        for (Timed &t : pending) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, t.e0, t.e1) == hipSuccess) {
+                kernelMs[t.kind] += ms;
+                kernelLaunches[t.kind] += 1;
+            }
+            eventPool.push_back(t.e0), eventPool.push_back(t.e1);
+        }
+        pending.clear();
+    }
+
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     LaunchCfg cfg() const { return LaunchCfg{stream, numCUs, 8, 8, collectStats}; }
 };
@@ -135,6 +183,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         c->tile = desc->tile_size > 0 ? desc->tile_size : 32;
         c->stream = (hipStream_t)desc->stream;
         c->collectStats = (desc->flags & HR_CTX_COLLECT_STATS) != 0;
+        c->timeKernels = (desc->flags & HR_CTX_TIME_KERNELS) != 0;
     }
     if (c->device < 0 || c->device >= nDev || c->rank < 0 || c->rank >= c->world || (c->tile & 7) != 0) {
         delete c;
@@ -162,6 +211,8 @@ int hr_ctx_destroy(hr_ctx *c)
     if (!c) return HR_OK;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    c->drainTimes();
+    for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
     freeQueues(c);
     freeSceneDevice(c);
     for (Texture &t : c->textures) hipFree(t.dpx);
@@ -659,6 +710,8 @@ int hr_clear(hr_ctx *c)
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
     HIP_TRY(c, hipMemsetAsync(c->fb(), 0, (size_t)c->W * c->H * 4 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats), c->stream));
+    c->drainTimes();
+    for (int k = 0; k < HR_KERNEL_COUNT; ++k) c->kernelMs[k] = 0.0f, c->kernelLaunches[k] = 0;
     return HR_OK;
 }
 
@@ -678,14 +731,25 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     FrameDev fr = c->frame;
     fr.fb = c->fb();
     HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(Counters), c->stream));
+    if (c->pending.size() > 8192) c->drainTimes();
+    c->timeBegin(HR_KERNEL_RAYGEN);
     launchRaygen(cfg, c->dScene, *pp, fr, c->q[0], c->dCounters, c->dStats);
+    c->timeEnd();
     int slot = 0;
     int nIter = pp->max_ray_depth + 1;
     for (;;) {
         for (; slot < nIter; ++slot) {
+            c->timeBegin(HR_KERNEL_TRACE_CLOSEST);
             launchTraceClosest(cfg, c->dScene, c->q[slot & 1], c->hits, c->dCounters, c->dStats, slot);
-            if (slot > 0) launchTraceShadow(cfg, c->dScene, c->sq, fr.fb, c->dCounters, c->dStats, slot - 1);
+            c->timeEnd();
+            if (slot > 0) {
+                c->timeBegin(HR_KERNEL_TRACE_ANY);
+                launchTraceShadow(cfg, c->dScene, c->sq, fr.fb, c->dCounters, c->dStats, slot - 1);
+                c->timeEnd();
+            }
+            c->timeBegin(HR_KERNEL_SHADE);
             launchShade(cfg, c->dScene, *pp, fr.fb, c->q[slot & 1], c->hits, c->q[(slot + 1) & 1], c->sq, c->dCounters, c->dStats, slot);
+            c->timeEnd();
         }
         if (!c->hasPassthrough || slot >= kMaxBounceSlots - 2) break;
         // pass-through rays (back faces of single-sided materials, alpha masks) are not bounded by maxRayDepth
@@ -695,7 +759,9 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
         if (remaining == 0) break;
         nIter = slot + 4 < kMaxBounceSlots - 2 ? slot + 4 : kMaxBounceSlots - 2;
     }
+    c->timeBegin(HR_KERNEL_TRACE_ANY);
     launchTraceShadow(cfg, c->dScene, c->sq, fr.fb, c->dCounters, c->dStats, slot - 1);
+    c->timeEnd();
     HIP_TRY(c, hipGetLastError());
     return HR_OK;
 }
@@ -710,6 +776,17 @@ int hr_get_stats(hr_ctx *c, hr_pass_stats *out)
     std::memset(out, 0, sizeof(*out));
     out->paths = s.paths, out->rays_closest = s.raysClosest, out->rays_any = s.raysAny, out->shaded_hits = s.shadedHits;
     out->accumulates = s.accumulates, out->node_visits = s.nodeVisits, out->tri_tests = s.triTests;
+    out->node_visits_any = s.nodeVisitsAny, out->tri_tests_any = s.triTestsAny;
+    return HR_OK;
+}
+
+int hr_get_kernel_times(hr_ctx *c, hr_kernel_times *out)
+{
+    ENTER(c);
+    if (!out) FAIL(c, HR_ERR_INVALID, "null output");
+    if (!c->timeKernels) FAIL(c, HR_ERR_INVALID, "context was not created with HR_CTX_TIME_KERNELS");
+    c->drainTimes();
+    for (int k = 0; k < HR_KERNEL_COUNT; ++k) out->ms[k] = c->kernelMs[k], out->launches[k] = c->kernelLaunches[k];
     return HR_OK;
 }
 

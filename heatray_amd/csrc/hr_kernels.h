@@ -12,7 +12,7 @@ struct FrameDev {
 };
 
 struct Stats {
-    unsigned long long paths, raysClosest, raysAny, shadedHits, accumulates, nodeVisits, triTests;
+    unsigned long long paths, raysClosest, raysAny, shadedHits, accumulates, nodeVisits, triTests, nodeVisitsAny, triTestsAny;
 };
 
 struct LaunchCfg {

@@ -47,7 +47,7 @@ HRD v3 max3(v3 a, v3 b) { return v3(fmax_(a.x, b.x), fmax_(a.y, b.y), fmax_(a.z,
 
 HRD float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 HRD v3 cross(v3 a, v3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-HRD float sqrt_(float x) { return __fsqrt_rn(x); }
+HRD float sqrt_(float x) { return __builtin_sqrtf(x); } // correctly rounded (v_sqrt_f32 + residual fix-up); __fsqrt_rn is NOT
 HRD float inversesqrt(float x) { return 1.0f / sqrt_(x); }
 HRD float length(v3 v) { return sqrt_(dot(v, v)); }
 HRD v3 normalize(v3 v) { return v * inversesqrt(dot(v, v)); }

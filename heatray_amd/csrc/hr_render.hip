@@ -160,6 +160,8 @@ __global__ __launch_bounds__(kBlock) void k_trace_shadow(const SceneDev *__restr
         if (lane == 0) {
             atomicAdd(&stats->nodeVisits, (unsigned long long)nv);
             atomicAdd(&stats->triTests, (unsigned long long)nt);
+            atomicAdd(&stats->nodeVisitsAny, (unsigned long long)nv);
+            atomicAdd(&stats->triTestsAny, (unsigned long long)nt);
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->raysAny, (unsigned long long)count);

@@ -60,6 +60,7 @@ typedef struct hr_ctx_desc {
 } hr_ctx_desc;
 
 #define HR_CTX_COLLECT_STATS 1u /* count node visits / triangle tests per pass (slower) */
+#define HR_CTX_TIME_KERNELS 2u  /* bracket every kernel launch with HIP events (hr_get_kernel_times) */
 
 /* replaces OpenRLCreateContext / OpenRLSetCurrentContext (PassGenerator.cpp:164-165) */
 int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out);
@@ -319,9 +320,24 @@ typedef struct hr_pass_stats {
     uint64_t rays_any;      /* occlusion traversals launched                         */
     uint64_t shaded_hits;   /* material shader invocations                           */
     uint64_t accumulates;   /* accumulate() calls with RGB payload                   */
-    uint64_t node_visits;   /* BVH nodes fetched   (HR_CTX_COLLECT_STATS only)       */
-    uint64_t tri_tests;     /* triangle tests      (HR_CTX_COLLECT_STATS only)       */
+    uint64_t node_visits;   /* BVH nodes fetched, all rays   (HR_CTX_COLLECT_STATS only) */
+    uint64_t tri_tests;     /* triangle tests, all rays      (HR_CTX_COLLECT_STATS only) */
+    uint64_t node_visits_any; /* ... of which by occlusion rays                          */
+    uint64_t tri_tests_any;
 } hr_pass_stats;
+
+/* Per-kernel device time, summed over every launch since the last hr_clear
+ * (HR_CTX_TIME_KERNELS only).  OpenRL's counterpart: RL_RENDER_FRAME_TIME /
+ * RL_PROFILE (rl.h:346-355), which Heatray never queries. */
+#define HR_KERNEL_RAYGEN 0
+#define HR_KERNEL_TRACE_CLOSEST 1
+#define HR_KERNEL_TRACE_ANY 2
+#define HR_KERNEL_SHADE 3
+#define HR_KERNEL_COUNT 4
+typedef struct hr_kernel_times {
+    float ms[HR_KERNEL_COUNT];
+    uint32_t launches[HR_KERNEL_COUNT];
+} hr_kernel_times;
 
 /* replaces rlClear(RL_COLOR_BUFFER_BIT) (PassGenerator.cpp:439) */
 int hr_clear(hr_ctx *ctx);
@@ -331,6 +347,8 @@ int hr_clear(hr_ctx *ctx);
 int hr_render_pass(hr_ctx *ctx, const hr_pass_params *params);
 /* synchronises the stream, then copies the counters */
 int hr_get_stats(hr_ctx *ctx, hr_pass_stats *out);
+/* synchronises the stream, then sums the recorded event pairs */
+int hr_get_kernel_times(hr_ctx *ctx, hr_kernel_times *out);
 /* replaces PixelPackBuffer::setPixelData + mapPixelData (PixelPackBuffer.h:39-60):
  * synchronous copy to a pinned host buffer owned by the ctx; the pointer stays
  * valid until the next hr_readback / hr_frame_resize / hr_ctx_destroy. */

@@ -36,7 +36,7 @@ struct Shader {
     const hr_pass_params &pp;
     float *px; // RGBA of the pixel being shaded
     hr_pass_stats &st;
-    TraceCounters tc;
+    TraceCounters tc, tcAny;
 
     Shader(Context &c, const hr_pass_params &p, float *pixel, hr_pass_stats &s) : ctx(c), pp(p), px(pixel), st(s) {}
 
@@ -900,7 +900,7 @@ struct Shader {
             }
             if (nee.valid) {
                 st.rays_any++;
-                if (!traceOccluded(ctx, nee.o, nee.d, ctx.rayEps, nee.maxT, nee.srcPrim, &tc, ctx.brute)) lightShader(nee, nee.maxT);
+                if (!traceOccluded(ctx, nee.o, nee.d, ctx.rayEps, nee.maxT, nee.srcPrim, &tcAny, ctx.brute)) lightShader(nee, nee.maxT);
             }
             ray = next;
         }
@@ -913,7 +913,7 @@ void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
     const int tilesX = (W + tile - 1) / tile;
     if (nThreads <= 0) nThreads = omp_get_max_threads();
     std::vector<hr_pass_stats> stats(nThreads);
-    std::vector<TraceCounters> tcs(nThreads);
+    std::vector<TraceCounters> tcs(nThreads), tcsAny(nThreads);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nThreads)
     for (int y = 0; y < H; ++y) {
         const int tid = omp_get_thread_num();
@@ -924,6 +924,8 @@ void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
             sh.tracePath(x, y);
             tcs[tid].nodeVisits += sh.tc.nodeVisits;
             tcs[tid].triTests += sh.tc.triTests;
+            tcsAny[tid].nodeVisits += sh.tcAny.nodeVisits;
+            tcsAny[tid].triTests += sh.tcAny.triTests;
         }
     }
     for (int i = 0; i < nThreads; ++i) {
@@ -932,8 +934,10 @@ void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
         ctx.stats.rays_any += stats[i].rays_any;
         ctx.stats.shaded_hits += stats[i].shaded_hits;
         ctx.stats.accumulates += stats[i].accumulates;
-        ctx.stats.node_visits += tcs[i].nodeVisits;
-        ctx.stats.tri_tests += tcs[i].triTests;
+        ctx.stats.node_visits += tcs[i].nodeVisits + tcsAny[i].nodeVisits;
+        ctx.stats.tri_tests += tcs[i].triTests + tcsAny[i].triTests;
+        ctx.stats.node_visits_any += tcsAny[i].nodeVisits;
+        ctx.stats.tri_tests_any += tcsAny[i].triTests;
     }
 }
 

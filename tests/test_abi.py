@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_oracle_mirrors_the_abi(oracle_lib):
     for s in ffi.ABI_SYMBOLS:
-        if s in ("ctx_set_stream", "frame_bind_external", "frame_device_ptr"):
+        if s in ("ctx_set_stream", "frame_bind_external", "frame_device_ptr", "get_kernel_times"):
             continue  # device-memory plumbing has no CPU counterpart
         assert hasattr(oracle_lib, "ora_" + s), s
 
@@ -41,7 +41,7 @@ def test_struct_sizes_match_the_c_layout():
     assert ctypes.sizeof(ffi.Material) == 4 * 10 + 4 * 15
     assert ctypes.sizeof(ffi.Lights) == 4 + 120 + 4 + 120 + 4 + 180 + 40 + 16
     assert ctypes.sizeof(ffi.PassParams) == 7 * 4 + 64 + 4 + 16 + 4 + 5 * 4
-    assert ctypes.sizeof(ffi.PassStats) == 64
+    assert ctypes.sizeof(ffi.PassStats) == 80
     assert ctypes.sizeof(ffi.Hit) == 16
 
 
