@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s of the per-pass ray kernel at 1920x1080, 8 bounces (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W           (N > 1: launched by torch.distributed.run)
+
+A "step" is one pass (one sample per pixel) of the hot path — primary-ray generation, BVH traversal,
+PBR/glass shading with NEE + environment, accumulation — over the whole frame; the scene, BVH, sample
+tables and the accumulation buffer are resident in HBM before the timed region.  With N > 1 the frame is
+sharded by 32x32-pixel tile across the ranks (strong scaling: the frame is fixed) and every step ends
+with the RCCL reduce of the RGBA32F accumulation buffer to rank 0.
+
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (closest-hit traversal), timed
+with HIP events inside libhrcore over the timed region; `cpu_baseline` is the CPU oracle (oracle/, the
+checker — used here only as the reported baseline leg) timed on a bounded tile sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from heatray_amd import _ffi as ffi  # noqa: E402
+from heatray_amd import core, scenes  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # BASELINE.json configs; c3 is the configuration the north-star target (>= 1 Gray/s) is quoted on
+    "c1": dict(desc="Cornell box (32 tris), 256x256, 4 bounces"),
+    "c2": dict(desc="synthetic soup 50k tris, 16 PBR materials, 1 directional light, 1920x1080, 8 bounces"),
+    "c3": dict(desc="synthetic soup 1M tris + 2048x1024 HDRI + NEE, 1920x1080, 8 bounces"),
+    "c5": dict(desc="soup 1M tris, 25% glass, 25% clearcoat, f/2.8 DoF, 3840x2160, 16 bounces"),
+}
+
+
+def build_scene(name, width, height, passes):
+    if name == "c1":
+        return scenes.cornell_box(width or 256, height or 256, bounces=4, passes=passes)
+    if name == "c2":
+        return scenes.triangle_soup(50_000, width or 1920, height or 1080, bounces=8, passes=passes, env=False)
+    if name == "c3":
+        return scenes.triangle_soup(1_000_000, width or 1920, height or 1080, bounces=8, passes=passes, env=True)
+    if name == "c5":
+        sc = scenes.triangle_soup(1_000_000, width or 3840, height or 2160, bounces=16, passes=passes, env=True,
+                                  glass_fraction=0.25, clearcoat_fraction=0.25)
+        sc.options.fstop = 2.8
+        return sc
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(sc, budget_s, lut):
+    """The CPU oracle (kind "port") on the host cores, on a bounded sample: a 1/16 interleaved tile shard
+    of the same frame, as many passes as fit the time budget."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    n_tiles = ((sc.width + 31) // 32) * ((sc.height + 31) // 32)
+    world = max(1, min(16, n_tiles))
+    eng = oracle_lib.engine(rank=0, world=world, tile_size=32)
+    t0 = time.perf_counter()
+    sc.apply(eng, lut=lut)
+    build_s = time.perf_counter() - t0
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        eng.render_pass(sc.options.pass_params(passes))
+        passes += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or passes >= sc.options.max_render_passes:
+            break
+    st = eng.stats()
+    rays = st.rays_closest + st.rays_any
+    cores = os.cpu_count() or 1
+    v_closest = (st.node_visits - st.node_visits_any) / max(st.rays_closest, 1)
+    t_closest = (st.tri_tests - st.tri_tests_any) / max(st.rays_closest, 1)
+    return {
+        "value": rays / el / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "sample": f"1/{world} of the frame's 32x32 tiles (interleaved), {passes} passes, {rays} rays in {el:.1f} s "
+                  f"(+{build_s:.1f} s scene/BVH build), OpenMP over tiles on {cores} threads",
+        "per_core": rays / el / 1e6 / cores,
+        "V_closest": v_closest, "T_closest": t_closest,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    passes_total = args.warmup + args.steps
+    sc = build_scene(args.workload, args.width, args.height, max(32, passes_total))
+    stream = torch.cuda.current_stream().cuda_stream
+    eng = core.create_engine(device_id=local_rank, rank=rank, world=world, tile_size=32, stream=stream, time_kernels=True)
+    sc.apply(eng)  # tables and LUT are generated on the device
+    info = eng.scene_info()
+    fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
+    eng.bind_external_frame(fb.data_ptr())
+    disp = torch.empty_like(fb) if world > 1 else None
+
+    def step(i):
+        eng.render_pass(sc.options.pass_params(i))
+        if world > 1:  # reduce of the HDR accumulation buffer; a copy keeps this rank's accumulator shard-only
+            disp.copy_(fb)
+            dist.reduce(disp, dst=0, op=dist.ReduceOp.SUM)
+
+    for i in range(args.warmup):
+        step(i)
+    eng.clear()  # resets the accumulation buffer, the device counters and the kernel timers
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    st = eng.stats()
+    kt = eng.kernel_times()
+    rays = torch.tensor([float(st.rays_closest + st.rays_any), float(st.paths), float(st.rays_closest)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    total_rays, total_paths, total_closest = (float(x) for x in rays.tolist())
+
+    if rank == 0:
+        # sanity of the timed result itself: every owned pixel got exactly `steps` samples
+        a = fb[..., 3]
+        owned = a > 0
+        assert bool((a[owned] == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
+        assert bool(torch.isfinite(fb).all())
+
+        # ---- V, T of the roofline model: one extra counted pass on this rank's shard (outside the timed region)
+        V = T = None
+        if not args.no_stats_pass:
+            se = core.create_engine(device_id=local_rank, rank=rank, world=world, tile_size=32, stream=stream, collect_stats=True)
+            sc.apply(se)
+            se.render_pass(sc.options.pass_params(args.warmup))
+            ss = se.stats()
+            V = (ss.node_visits - ss.node_visits_any) / max(ss.rays_closest, 1)
+            T = (ss.tri_tests - ss.tri_tests_any) / max(ss.rays_closest, 1)
+            V_any = ss.node_visits_any / max(ss.rays_any, 1)
+            T_any = ss.tri_tests_any / max(ss.rays_any, 1)
+            H = ss.shaded_hits / max(ss.rays_closest + ss.rays_any, 1)
+            A = ss.accumulates / max(ss.rays_closest + ss.rays_any, 1)
+            se.close()
+
+        # ---- roofline of the dominant kernel: closest-hit traversal.
+        # Algorithmic bytes per ray in that kernel: 48 B ray read (origin/tmax, dir, src prim)
+        # + 16 B hit record written + 64 B per BVH node visited + 48 B per triangle tested.
+        ms_closest, n_closest = kt["trace_closest"]
+        roofline = None
+        if V is not None and n_closest:
+            bytes_per_ray = 48.0 + 16.0 + 64.0 * V + 48.0 * T
+            rays_per_launch = float(st.rays_closest) / n_closest
+            avg_ms = ms_closest / n_closest
+            achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("trace_closest_hbm_bytes_per_launch")
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "kernel": "k_trace_closest", "avg_launch_ms": avg_ms, "launches": n_closest,
+                        "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
+                        "V": V, "T": T, "V_any": V_any, "T_any": T_any}
+
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            lut, _ = eng.generate_multiscatter_lut()
+            cpu = cpu_baseline(sc, args.cpu_seconds, lut)
+
+        mrays = total_rays / elapsed / 1e6
+        out = {
+            "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3") else f"Mrays/s ({args.workload})",
+            "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "width": sc.width, "height": sc.height,
+                       "max_ray_depth": sc.options.max_ray_depth, "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
+                       "sharding": f"32x32 pixel tiles round-robin over {world} GPU(s)" + ("; RCCL reduce of the RGBA32F buffer every step" if world > 1 else ""),
+                       "seed": hex(scenes.SEED)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,
+                      "rays_per_path": total_rays / max(total_paths, 1.0), "bvh_build_ms": info.build_ms,
+                      "kernel_ms_rank0": {k: v[0] for k, v in kt.items()}, "kernel_launches_rank0": {k: v[1] for k, v in kt.items()},
+                      "shaded_hit_fraction_H": None if V is None else H, "accumulate_fraction_A": None if V is None else A},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

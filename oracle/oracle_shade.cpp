@@ -914,19 +914,27 @@ void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
     if (nThreads <= 0) nThreads = omp_get_max_threads();
     std::vector<hr_pass_stats> stats(nThreads);
     std::vector<TraceCounters> tcs(nThreads), tcsAny(nThreads);
+    const int tilesY = (H + tile - 1) / tile;
+    std::vector<int> owned;
+    for (int t = ctx.rank; t < tilesX * tilesY; t += ctx.world) owned.push_back(t);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nThreads)
-    for (int y = 0; y < H; ++y) {
+    for (int k = 0; k < (int)owned.size(); ++k) {
         const int tid = omp_get_thread_num();
-        for (int x = 0; x < W; ++x) {
-            const int t = (y / tile) * tilesX + (x / tile);
-            if (t % ctx.world != ctx.rank) continue;
-            Shader sh(ctx, pp, &ctx.fb[((size_t)y * W + x) * 4], stats[tid]);
-            sh.tracePath(x, y);
-            tcs[tid].nodeVisits += sh.tc.nodeVisits;
-            tcs[tid].triTests += sh.tc.triTests;
-            tcsAny[tid].nodeVisits += sh.tcAny.nodeVisits;
-            tcsAny[tid].triTests += sh.tcAny.triTests;
+        const int tx = owned[k] % tilesX, ty = owned[k] / tilesX;
+        hr_pass_stats local{};
+        TraceCounters tcl, tcla;
+        for (int y = ty * tile; y < (ty + 1) * tile && y < H; ++y) {
+            for (int x = tx * tile; x < (tx + 1) * tile && x < W; ++x) {
+                Shader sh(ctx, pp, &ctx.fb[((size_t)y * W + x) * 4], local);
+                sh.tracePath(x, y);
+                tcl.nodeVisits += sh.tc.nodeVisits, tcl.triTests += sh.tc.triTests;
+                tcla.nodeVisits += sh.tcAny.nodeVisits, tcla.triTests += sh.tcAny.triTests;
+            }
         }
+        stats[tid].paths += local.paths, stats[tid].rays_closest += local.rays_closest, stats[tid].rays_any += local.rays_any;
+        stats[tid].shaded_hits += local.shaded_hits, stats[tid].accumulates += local.accumulates;
+        tcs[tid].nodeVisits += tcl.nodeVisits, tcs[tid].triTests += tcl.triTests;
+        tcsAny[tid].nodeVisits += tcla.nodeVisits, tcsAny[tid].triTests += tcla.triTests;
     }
     for (int i = 0; i < nThreads; ++i) {
         ctx.stats.paths += stats[i].paths;
