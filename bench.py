@@ -122,7 +122,10 @@ def main():
 
     def step(i):
         eng.render_pass(sc.options.pass_params(i))
-        if world > 1:  # reduce of the HDR accumulation buffer; a copy keeps this rank's accumulator shard-only
+        if world > 1:
+            # RCCL reduce of the HDR accumulation buffer for display.  The buffer holds every pass whose last stage
+            # has run (passes still in the pipeline live in their own pass buffers), so reducing it at any point of
+            # the stream gives a consistent progressive image; a copy keeps this rank's accumulator shard-only.
             disp.copy_(fb)
             dist.reduce(disp, dst=0, op=dist.ReduceOp.SUM)
 
@@ -136,6 +139,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
+    eng.flush()  # the pass pipeline keeps depth+2 passes in flight: enqueue their remaining stages
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -174,23 +178,27 @@ def main():
             A = ss.accumulates / max(ss.rays_closest + ss.rays_any, 1)
             se.close()
 
-        # ---- roofline of the dominant kernel: closest-hit traversal.
+        # ---- roofline of the dominant kernel: k_trace (closest-hit + occlusion traversal in one launch).
         # Algorithmic bytes per ray in that kernel: 48 B ray read (origin/tmax, dir, src prim)
-        # + 16 B hit record written + 64 B per BVH node visited + 48 B per triangle tested.
-        ms_closest, n_closest = kt["trace_closest"]
+        # + 16 B result (hit record, or the pass-buffer RMW of an unoccluded occlusion ray)
+        # + 64 B per BVH node visited + 48 B per triangle tested.
+        ms_trace, n_trace = kt["trace"]
         roofline = None
-        if V is not None and n_closest:
-            bytes_per_ray = 48.0 + 16.0 + 64.0 * V + 48.0 * T
-            rays_per_launch = float(st.rays_closest) / n_closest
-            avg_ms = ms_closest / n_closest
-            achieved = bytes_per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e9
+        if V is not None and n_trace:
+            bytes_closest = 48.0 + 16.0 + 64.0 * V + 48.0 * T
+            bytes_any = 48.0 + 16.0 + 64.0 * V_any + 48.0 * T_any
+            total_bytes = bytes_closest * float(st.rays_closest) + bytes_any * float(st.rays_any)
+            avg_ms = ms_trace / n_trace
+            achieved = total_bytes / n_trace / (avg_ms * 1e-3) / 1e9
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("trace_closest_hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("k_trace_hbm_bytes_per_launch")
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "kernel": "k_trace_closest", "avg_launch_ms": avg_ms, "launches": n_closest,
-                        "algorithmic_bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
+                        "traffic": traffic, "kernel": "k_trace", "avg_launch_ms": avg_ms, "launches": n_trace,
+                        "algorithmic_bytes_per_launch": total_bytes / n_trace,
+                        "algorithmic_bytes_per_closest_ray": bytes_closest, "algorithmic_bytes_per_occlusion_ray": bytes_any,
+                        "rays_per_launch": float(st.rays_closest + st.rays_any) / n_trace,
                         "V": V, "T": T, "V_any": V_any, "T_any": T_any}
 
         cpu = None

@@ -16,7 +16,7 @@ HR_NUM_RANDOM_SEQUENCES = 16
 
 HR_CTX_COLLECT_STATS = 1
 HR_CTX_TIME_KERNELS = 2
-HR_KERNEL_NAMES = ("raygen", "trace_closest", "trace_any", "shade")
+HR_KERNEL_NAMES = ("raygen", "trace", "shade", "resolve")
 
 HR_TRIANGLES, HR_TRIANGLE_STRIP = 0, 1
 HR_TEX_U8, HR_TEX_F32 = 0, 1
@@ -128,7 +128,7 @@ ABI_SYMBOLS = [
     "frame_device_ptr", "geom_add", "geom_remove", "geom_set_transform", "scene_clear", "scene_commit",
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
-    "clear", "render_pass", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
+    "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
 ]
 
 
@@ -294,6 +294,9 @@ class Engine:
 
     def render_pass(self, params):
         self._call("render_pass", C.byref(params))
+
+    def flush(self):
+        self._call("flush")
 
     def stats(self):
         s = PassStats()

@@ -48,9 +48,26 @@ struct hr_ctx {
     size_t pinnedBytes = 0;
     FrameDev frame{};
     uint32_t queueCapacity = 0;
-    RayQueue q[2]{};
-    ShadowQueue sq{};
-    void *hits = nullptr;
+    // Pipeline of in-flight passes (hr_render.hip header): every slot owns the queues, hit records, counters and
+    // the pass buffer of one pass.
+    struct PassSlot {
+        bool allocated = false, active = false;
+        int step = 0, nIter = 0;
+        unsigned long long order = 0; // injection order (passes resolve in this order)
+        hr_pass_params pp{};
+        RayQueue q[2]{};
+        ShadowQueue sq{};
+        void *hits = nullptr;
+        float *passbuf = nullptr;
+        Counters *ctr = nullptr;
+    };
+    PassSlot slots[kMaxSegs];
+    int nSlotsAllocated = 0;
+    int maxSlots = kMaxSegs; // bounded by device memory at resize
+    unsigned long long injected = 0;
+    StepTable *dTables = nullptr; // small ring of device step tables
+    unsigned long long stepCounter = 0;
+    uint32_t *dZero = nullptr;    // a zero word (occlusion count of a pass's first step)
 
     // scene (host mirror)
     std::vector<Geom> geoms;
@@ -73,7 +90,6 @@ struct hr_ctx {
     int nSeq = 0, seqLen = 0, nSeqOffsets = 0;
     SceneDev hScene{};
     SceneDev *dScene = nullptr;
-    Counters *dCounters = nullptr;
     Stats *dStats = nullptr;
     uint32_t *dScratch = nullptr; // 8 words: ordered bounds etc.
 
@@ -148,16 +164,31 @@ struct hr_ctx {
     if (!(ctx)) return HR_ERR_INVALID;               \
     HIP_TRY(ctx, hipSetDevice((ctx)->device))
 
+static const int kTableRing = 4;
+static int drainPipeline(hr_ctx *c);
+// finish every enqueued pass and wait for the device: required before anything the in-flight kernels read changes
+static int quiesce(hr_ctx *c)
+{
+    int rc = drainPipeline(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HR_OK;
+}
+#define QUIESCE(ctx)              \
+    do {                          \
+        int rc_ = quiesce(ctx);   \
+        if (rc_) return rc_;      \
+    } while (0)
+
 static void freeQueues(hr_ctx *c)
 {
-    for (int i = 0; i < 2; ++i) {
-        hipFree(c->q[i].A), hipFree(c->q[i].B), hipFree(c->q[i].C), hipFree(c->q[i].D);
-        c->q[i] = RayQueue{};
+    for (hr_ctx::PassSlot &ps : c->slots) {
+        for (int i = 0; i < 2; ++i) hipFree(ps.q[i].A), hipFree(ps.q[i].B), hipFree(ps.q[i].C), hipFree(ps.q[i].D);
+        hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C);
+        hipFree(ps.hits), hipFree(ps.passbuf), hipFree(ps.ctr);
+        ps = hr_ctx::PassSlot();
     }
-    hipFree(c->sq.A), hipFree(c->sq.B), hipFree(c->sq.C);
-    c->sq = ShadowQueue{};
-    hipFree(c->hits);
-    c->hits = nullptr;
+    c->nSlotsAllocated = 0;
     c->queueCapacity = 0;
 }
 
@@ -195,13 +226,14 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         return HR_ERR_DEVICE;
     }
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters)) != hipSuccess ||
-        hipMalloc(&c->dStats, sizeof(Stats)) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess) {
+    if (hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess || hipMalloc(&c->dTables, sizeof(StepTable) * kTableRing) != hipSuccess ||
+        hipMalloc(&c->dStats, sizeof(Stats)) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess ||
+        hipMalloc(&c->dZero, 64) != hipSuccess) {
         delete c;
         return HR_ERR_DEVICE;
     }
     hipMemset(c->dStats, 0, sizeof(Stats));
-    hipMemset(c->dCounters, 0, sizeof(Counters));
+    hipMemset(c->dZero, 0, 64);
     *out = c;
     return HR_OK;
 }
@@ -210,6 +242,7 @@ int hr_ctx_destroy(hr_ctx *c)
 {
     if (!c) return HR_OK;
     hipSetDevice(c->device);
+    drainPipeline(c);
     hipStreamSynchronize(c->stream);
     c->drainTimes();
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
@@ -219,7 +252,7 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->fbInternal);
     if (c->pinned) hipHostFree(c->pinned);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
-    hipFree(c->dScene), hipFree(c->dCounters), hipFree(c->dStats), hipFree(c->dScratch);
+    hipFree(c->dScene), hipFree(c->dTables), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero);
     delete c;
     return HR_OK;
 }
@@ -229,7 +262,7 @@ const char *hr_last_error(const hr_ctx *c) { return c ? c->err.c_str() : "null c
 int hr_ctx_set_stream(hr_ctx *c, void *stream)
 {
     ENTER(c);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     c->stream = (hipStream_t)stream;
     return HR_OK;
 }
@@ -237,7 +270,7 @@ int hr_ctx_set_stream(hr_ctx *c, void *stream)
 int hr_synchronize(hr_ctx *c)
 {
     ENTER(c);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     return HR_OK;
 }
 
@@ -246,7 +279,7 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
 {
     ENTER(c);
     if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 28)) FAIL(c, HR_ERR_INVALID, "bad frame size");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     c->W = w, c->H = h;
     hipFree(c->fbInternal);
     c->fbInternal = nullptr;
@@ -265,21 +298,17 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
     f.tilesX = (w + c->tile - 1) / c->tile, f.tilesY = (h + c->tile - 1) / c->tile;
     const int nTiles = f.tilesX * f.tilesY;
     f.nOwnedTiles = nTiles > c->rank ? (nTiles - c->rank + c->world - 1) / c->world : 0;
-    // one path per owned pixel: queue capacity = owned tiles x tile^2
+    // one path per owned pixel and pass: queue capacity = owned tiles x tile^2; pass slots are allocated on demand
     freeQueues(c);
-    const uint32_t cap = (uint32_t)f.nOwnedTiles * (uint32_t)(c->tile * c->tile);
-    const size_t n16 = (size_t)(cap ? cap : 1) * 16;
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(c, hipMalloc(&c->q[i].A, n16));
-        HIP_TRY(c, hipMalloc(&c->q[i].B, n16));
-        HIP_TRY(c, hipMalloc(&c->q[i].C, n16));
-        HIP_TRY(c, hipMalloc(&c->q[i].D, n16));
+    c->queueCapacity = (uint32_t)f.nOwnedTiles * (uint32_t)(c->tile * c->tile);
+    // how many passes may be in flight: each slot holds two ray queues, an occlusion queue, hit records and a pass buffer
+    size_t freeB = 0, totalB = 0;
+    c->maxSlots = kMaxSegs;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 + hitRecordSize()) + fbBytes + sizeof(Counters);
+        const size_t fit = (freeB / 2) / perSlot;
+        c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSegs ? kMaxSegs : (int)fit);
     }
-    HIP_TRY(c, hipMalloc(&c->sq.A, n16));
-    HIP_TRY(c, hipMalloc(&c->sq.B, n16));
-    HIP_TRY(c, hipMalloc(&c->sq.C, n16));
-    HIP_TRY(c, hipMalloc(&c->hits, (size_t)(cap ? cap : 1) * hitRecordSize()));
-    c->queueCapacity = cap;
     return HR_OK;
 }
 
@@ -287,7 +316,7 @@ int hr_frame_bind_external(hr_ctx *c, void *deviceRgba)
 {
     ENTER(c);
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     c->fbExternal = (float *)deviceRgba;
     return HR_OK;
 }
@@ -374,7 +403,7 @@ static inline float floatFromOrdered(uint32_t u)
 int hr_scene_commit(hr_ctx *c)
 {
     ENTER(c);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0));
     HIP_TRY(c, hipEventCreate(&e1));
@@ -516,7 +545,7 @@ int hr_texture_destroy(hr_ctx *c, hr_tex_id id)
 {
     ENTER(c);
     if (id < 0 || id >= (int)c->textures.size() || !c->textures[id].alive) FAIL(c, HR_ERR_INVALID, "bad texture id");
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     hipFree(c->textures[id].dpx);
     c->textures[id] = Texture();
     c->sceneDirty = true;
@@ -551,7 +580,7 @@ int hr_lights_set(hr_ctx *c, const hr_lights *l)
 // ----------------------------------------------------------------------------------- sample tables
 static int setTable(hr_ctx *c, float2 **dst, const float *src, size_t n)
 {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     hipFree(*dst);
     *dst = nullptr;
     HIP_TRY(c, hipMalloc(dst, n * sizeof(float2)));
@@ -670,7 +699,7 @@ int hr_multiscatter_lut_generate(hr_ctx *c, float *out, hr_tex_id *outTex)
 static int uploadScene(hr_ctx *c)
 {
     if (!c->sceneDirty) return HR_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     if (c->dMaterialsCap < c->materials.size() || !c->dMaterials) {
         hipFree(c->dMaterials);
         c->dMaterialsCap = c->materials.size() + 16;
@@ -708,10 +737,134 @@ int hr_clear(hr_ctx *c)
 {
     ENTER(c);
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    int rc = drainPipeline(c);
+    if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->fb(), 0, (size_t)c->W * c->H * 4 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats), c->stream));
     c->drainTimes();
     for (int k = 0; k < HR_KERNEL_COUNT; ++k) c->kernelMs[k] = 0.0f, c->kernelLaunches[k] = 0;
+    return HR_OK;
+}
+
+static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
+{
+    const size_t cap = c->queueCapacity ? c->queueCapacity : 1;
+    const size_t n16 = cap * 16;
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(c, hipMalloc(&ps.q[i].A, n16));
+        HIP_TRY(c, hipMalloc(&ps.q[i].B, n16));
+        HIP_TRY(c, hipMalloc(&ps.q[i].C, n16));
+        HIP_TRY(c, hipMalloc(&ps.q[i].D, n16));
+    }
+    HIP_TRY(c, hipMalloc(&ps.sq.A, n16));
+    HIP_TRY(c, hipMalloc(&ps.sq.B, n16));
+    HIP_TRY(c, hipMalloc(&ps.sq.C, n16));
+    HIP_TRY(c, hipMalloc(&ps.hits, cap * hitRecordSize()));
+    HIP_TRY(c, hipMalloc(&ps.passbuf, (size_t)c->W * c->H * 4 * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&ps.ctr, sizeof(Counters)));
+    ps.allocated = true;
+    c->nSlotsAllocated++;
+    return HR_OK;
+}
+
+static int activePasses(const hr_ctx *c)
+{
+    int n = 0;
+    for (const hr_ctx::PassSlot &ps : c->slots) n += ps.active ? 1 : 0;
+    return n;
+}
+
+// One macro step: (raygen of the injected pass) -> trace of every in-flight pass -> shade -> resolve finished passes.
+static int macroStep(hr_ctx *c, const hr_pass_params *inject)
+{
+    const LaunchCfg cfg = c->cfg();
+    FrameDev fr = c->frame;
+    fr.fb = c->fb();
+    int injectedSlot = -1;
+    if (inject) {
+        for (int i = 0; i < kMaxSegs && injectedSlot < 0; ++i)
+            if (!c->slots[i].active) injectedSlot = i;
+        if (injectedSlot < 0) FAIL(c, HR_ERR_INVALID, "internal: no free pass slot");
+        hr_ctx::PassSlot &ps = c->slots[injectedSlot];
+        if (!ps.allocated) {
+            int rc = allocSlot(c, ps);
+            if (rc) return rc;
+        }
+        ps.active = true, ps.step = 0, ps.nIter = inject->max_ray_depth + 1, ps.pp = *inject, ps.order = c->injected++;
+        HIP_TRY(c, hipMemsetAsync(ps.ctr, 0, sizeof(Counters), c->stream));
+    }
+    // Pass-through rays (back faces of single-sided materials, alpha masks) are not bounded by maxRayDepth:
+    // before a pass's last step, see whether closest-hit rays are still queued and extend the pass if so.
+    if (c->hasPassthrough) {
+        for (hr_ctx::PassSlot &ps : c->slots) {
+            if (!ps.active || ps.step != ps.nIter || ps.nIter >= kMaxBounceSlots - 2) continue;
+            uint32_t remaining = 0;
+            HIP_TRY(c, hipMemcpyAsync(&remaining, &ps.ctr->qCount[ps.nIter], 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (remaining > 0) ps.nIter = ps.nIter + 4 < kMaxBounceSlots - 2 ? ps.nIter + 4 : kMaxBounceSlots - 2;
+        }
+    }
+    // table of the in-flight passes, oldest first
+    StepTable tbl{};
+    int order[kMaxSegs], n = 0;
+    for (int i = 0; i < kMaxSegs; ++i)
+        if (c->slots[i].active) order[n++] = i;
+    for (int a = 1; a < n; ++a)
+        for (int b = a; b > 0 && c->slots[order[b]].order < c->slots[order[b - 1]].order; --b) std::swap(order[b], order[b - 1]);
+    if (n == 0) return HR_OK;
+    tbl.nSeg = n;
+    int injectedSeg = -1;
+    for (int k = 0; k < n; ++k) {
+        hr_ctx::PassSlot &ps = c->slots[order[k]];
+        SegDev &sg = tbl.seg[k];
+        const int st = ps.step;
+        sg.qin = ps.q[st & 1], sg.qout = ps.q[(st + 1) & 1], sg.sq = ps.sq;
+        sg.hits = (HitRec *)ps.hits, sg.passbuf = ps.passbuf;
+        sg.qCountIn = &ps.ctr->qCount[st];
+        sg.sCountIn = st > 0 ? &ps.ctr->sCount[st - 1] : c->dZero;
+        sg.qCountOut = &ps.ctr->qCount[st + 1];
+        sg.sCountOut = &ps.ctr->sCount[st];
+        sg.pp = ps.pp;
+        sg.closestEnabled = st < ps.nIter ? 1 : 0;
+        if (order[k] == injectedSlot) injectedSeg = k;
+    }
+    StepTable *dTbl = c->dTables + (c->stepCounter++ % kTableRing);
+    HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, sizeof(StepTable), hipMemcpyHostToDevice, c->stream));
+    if (c->pending.size() > 8192) c->drainTimes();
+    if (injectedSeg >= 0) {
+        c->timeBegin(HR_KERNEL_RAYGEN);
+        launchRaygen(cfg, c->dScene, dTbl, injectedSeg, fr, c->dStats);
+        c->timeEnd();
+    }
+    c->timeBegin(HR_KERNEL_TRACE);
+    launchTrace(cfg, c->dScene, dTbl, c->dStats);
+    c->timeEnd();
+    c->timeBegin(HR_KERNEL_SHADE);
+    launchShade(cfg, c->dScene, dTbl, c->dStats);
+    c->timeEnd();
+    for (int k = 0; k < n; ++k) {
+        hr_ctx::PassSlot &ps = c->slots[order[k]];
+        if (ps.step >= ps.nIter) {
+            c->timeBegin(HR_KERNEL_RESOLVE);
+            launchResolve(cfg, fr, ps.passbuf);
+            c->timeEnd();
+            ps.active = false;
+        } else {
+            ps.step++;
+        }
+    }
+    HIP_TRY(c, hipGetLastError());
+    return HR_OK;
+}
+
+static int drainPipeline(hr_ctx *c)
+{
+    int guard = 0;
+    while (activePasses(c) > 0) {
+        int rc = macroStep(c, nullptr);
+        if (rc) return rc;
+        if (++guard > 4 * kMaxBounceSlots) FAIL(c, HR_ERR_DEVICE, "internal: pass pipeline did not drain");
+    }
     return HR_OK;
 }
 
@@ -724,55 +877,40 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     if (c->nSeq <= 0 || c->nSeqOffsets <= 0) FAIL(c, HR_ERR_INVALID, "sample tables not set");
     if (pp->max_ray_depth < 0 || pp->max_ray_depth + 2 >= kMaxBounceSlots - 8) FAIL(c, HR_ERR_INVALID, "max_ray_depth out of range");
     if (pp->interactive_mode && (pp->block_size[0] <= 0 || pp->block_size[1] <= 0)) FAIL(c, HR_ERR_INVALID, "bad block size");
-    int rc = uploadScene(c);
+    int rc = uploadScene(c); // drains the pipeline first when the scene constants changed
     if (rc) return rc;
     if (c->frame.nOwnedTiles == 0) return HR_OK;
-    const LaunchCfg cfg = c->cfg();
-    FrameDev fr = c->frame;
-    fr.fb = c->fb();
-    HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, sizeof(Counters), c->stream));
-    if (c->pending.size() > 8192) c->drainTimes();
-    c->timeBegin(HR_KERNEL_RAYGEN);
-    launchRaygen(cfg, c->dScene, *pp, fr, c->q[0], c->dCounters, c->dStats);
-    c->timeEnd();
-    int slot = 0;
-    int nIter = pp->max_ray_depth + 1;
-    for (;;) {
-        for (; slot < nIter; ++slot) {
-            c->timeBegin(HR_KERNEL_TRACE_CLOSEST);
-            launchTraceClosest(cfg, c->dScene, c->q[slot & 1], c->hits, c->dCounters, c->dStats, slot);
-            c->timeEnd();
-            if (slot > 0) {
-                c->timeBegin(HR_KERNEL_TRACE_ANY);
-                launchTraceShadow(cfg, c->dScene, c->sq, fr.fb, c->dCounters, c->dStats, slot - 1);
-                c->timeEnd();
-            }
-            c->timeBegin(HR_KERNEL_SHADE);
-            launchShade(cfg, c->dScene, *pp, fr.fb, c->q[slot & 1], c->hits, c->q[(slot + 1) & 1], c->sq, c->dCounters, c->dStats, slot);
-            c->timeEnd();
-        }
-        if (!c->hasPassthrough || slot >= kMaxBounceSlots - 2) break;
-        // pass-through rays (back faces of single-sided materials, alpha masks) are not bounded by maxRayDepth
-        uint32_t remaining = 0;
-        HIP_TRY(c, hipMemcpyAsync(&remaining, &c->dCounters->qCount[slot], 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (remaining == 0) break;
-        nIter = slot + 4 < kMaxBounceSlots - 2 ? slot + 4 : kMaxBounceSlots - 2;
+    // pipeline depth: a pass occupies depth+2 macro steps; passes that may need extra stages run alone
+    int depth = c->hasPassthrough ? 1 : pp->max_ray_depth + 2;
+    if (depth > kMaxSegs) depth = kMaxSegs;
+    if (depth > c->maxSlots) depth = c->maxSlots;
+    while (activePasses(c) >= depth) {
+        rc = macroStep(c, nullptr);
+        if (rc) return rc;
     }
-    c->timeBegin(HR_KERNEL_TRACE_ANY);
-    launchTraceShadow(cfg, c->dScene, c->sq, fr.fb, c->dCounters, c->dStats, slot - 1);
-    c->timeEnd();
-    HIP_TRY(c, hipGetLastError());
+    rc = macroStep(c, pp);
+    if (rc) return rc;
+    if (c->hasPassthrough) return drainPipeline(c);
     return HR_OK;
+}
+
+int hr_flush(hr_ctx *c)
+{
+    ENTER(c);
+    return drainPipeline(c);
 }
 
 int hr_get_stats(hr_ctx *c, hr_pass_stats *out)
 {
     ENTER(c);
     if (!out) FAIL(c, HR_ERR_INVALID, "null output");
+    {
+        int rc = drainPipeline(c);
+        if (rc) return rc;
+    }
     Stats s;
     HIP_TRY(c, hipMemcpyAsync(&s, c->dStats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     std::memset(out, 0, sizeof(*out));
     out->paths = s.paths, out->rays_closest = s.raysClosest, out->rays_any = s.raysAny, out->shaded_hits = s.shadedHits;
     out->accumulates = s.accumulates, out->node_visits = s.nodeVisits, out->tri_tests = s.triTests;
@@ -785,6 +923,10 @@ int hr_get_kernel_times(hr_ctx *c, hr_kernel_times *out)
     ENTER(c);
     if (!out) FAIL(c, HR_ERR_INVALID, "null output");
     if (!c->timeKernels) FAIL(c, HR_ERR_INVALID, "context was not created with HR_CTX_TIME_KERNELS");
+    {
+        int rc = drainPipeline(c);
+        if (rc) return rc;
+    }
     c->drainTimes();
     for (int k = 0; k < HR_KERNEL_COUNT; ++k) out->ms[k] = c->kernelMs[k], out->launches[k] = c->kernelLaunches[k];
     return HR_OK;
@@ -795,8 +937,12 @@ int hr_readback(hr_ctx *c, const float **rgba, int32_t *w, int32_t *h)
     ENTER(c);
     if (c->W <= 0 || !rgba) FAIL(c, HR_ERR_INVALID, "no frame");
     const size_t bytes = (size_t)c->W * c->H * 4 * sizeof(float);
+    {
+        int rc = drainPipeline(c);
+        if (rc) return rc;
+    }
     HIP_TRY(c, hipMemcpyAsync(c->pinned, c->fb(), bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    QUIESCE(c);
     *rgba = c->pinned;
     if (w) *w = c->W;
     if (h) *h = c->H;

@@ -11,6 +11,8 @@ struct FrameDev {
     int32_t rank, world, tile, tilesX, tilesY, nOwnedTiles;
 };
 
+struct HitRec; // hr_trace.h
+
 struct Stats {
     unsigned long long paths, raysClosest, raysAny, shadedHits, accumulates, nodeVisits, triTests, nodeVisitsAny, triTestsAny;
 };
@@ -23,12 +25,35 @@ struct LaunchCfg {
     bool collectStats;
 };
 
+// One in-flight pass as seen by the kernels of one macro step.
+struct SegDev {
+    RayQueue qin;        // closest-hit rays traced and shaded this step
+    RayQueue qout;       // closest-hit rays emitted for the next step
+    ShadowQueue sq;      // occlusion rays: traced this step (emitted by the previous step's shade), then refilled by this step's shade
+    HitRec *hits;        // closest-hit records of qin
+    float *passbuf;      // RGBA32F sample of this pass (full-frame indexing)
+    uint32_t *qCountIn;  // number of rays in qin
+    uint32_t *sCountIn;  // number of occlusion rays to trace this step
+    uint32_t *qCountOut; // counter shade appends qout with
+    uint32_t *sCountOut; // counter shade appends sq with
+    hr_pass_params pp;   // per-pass uniforms
+    int32_t closestEnabled; // 0 in a pass's last step (only its occlusion rays remain)
+    int32_t pad;
+};
+
+static const int kMaxSegs = 12;
+struct StepTable {
+    uint32_t traceHead; // work cursor of the persistent trace kernel (reset with every table upload)
+    int32_t nSeg;
+    int32_t pad[2];
+    SegDev seg[kMaxSegs];
+};
+
 // ---- hr_render.hip
-void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const hr_pass_params &pp, const FrameDev &fr, RayQueue q, Counters *ctr, Stats *stats);
-void launchTraceClosest(const LaunchCfg &cfg, const SceneDev *S, RayQueue q, void *hits, Counters *ctr, Stats *stats, int slot);
-void launchTraceShadow(const LaunchCfg &cfg, const SceneDev *S, ShadowQueue sq, float *fb, Counters *ctr, Stats *stats, int slot);
-void launchShade(const LaunchCfg &cfg, const SceneDev *S, const hr_pass_params &pp, float *fb, RayQueue qin, const void *hits, RayQueue qout,
-                 ShadowQueue sq, Counters *ctr, Stats *stats, int slot);
+void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, int segIdx, const FrameDev &fr, Stats *stats);
+void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbuf);
+void launchTrace(const LaunchCfg &cfg, const SceneDev *S, StepTable *tbl, Stats *stats);
+void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,
                       int anyHit, hr_hit *out);
 size_t hitRecordSize();

@@ -1,17 +1,23 @@
-// hr_render.hip — the per-pass wavefront loop: primary-ray generation, persistent-threads BVH
-// traversal (closest hit + occlusion), SoA shading with wave-level queue compaction, accumulation.
+// hr_render.hip — the per-pass wavefront pipeline: primary-ray generation, persistent-threads BVH
+// traversal (closest hit + occlusion in ONE kernel), SoA shading with wave-level queue compaction,
+// accumulation.
 //
 // Replaces rlRenderFrame() (/root/reference/Source/HeatrayRenderer/PassGenerator.cpp:386) and the RLSL
 // programs it runs (Resources/shaders/perspective.rlsl, physicallyBased.rlsl, glass.rlsl, *Light.rlsl,
-// accumulator.rlsl).  Kernel sequence of one pass (all on one stream):
+// accumulator.rlsl).
 //
-//   raygen -> { trace(i): closest hits of queue i  +  occlusion rays emitted by shade(i-1)
-//               shade(i): materials / miss shaders, emits queue i+1 and occlusion queue i } x (depth+1)
-//          -> trace of the last occlusion queue
+// A pass needs depth+2 dependent stages (trace -> shade -> trace -> ...), and late stages hold few, long
+// rays, so running one pass at a time leaves the chip idle in every stage's tail.  The host therefore
+// keeps up to `depth+2` passes in flight, each at a different stage, and every "macro step" launches
 //
-// Every pixel has at most one live path and one live occlusion ray, and kernels are stream-ordered, so
-// the accumulation buffer is updated with plain read-modify-write in a fixed per-pixel order
-// (A+=1, then per bounce: emissive, NEE light, environment) — reproducible bit for bit.
+//   raygen (the pass injected this step)  ->  k_trace (all in-flight passes: closest-hit rays of the
+//   current stage + occlusion rays emitted by the previous stage)  ->  k_shade (all in-flight passes)
+//   ->  k_resolve (passes that finished)
+//
+// so each launch carries about one whole pass worth of rays of every depth.  Each in-flight pass sums its
+// sample into its own pass buffer (plain read-modify-write: a pixel has at most one live path and one
+// live occlusion ray per pass, and the stages are stream-ordered), and k_resolve adds finished samples to
+// the accumulation buffer in pass order — reproducible bit for bit.
 #include "hr_kernels.h"
 #include "hr_shade.h"
 #include "hr_trace.h"
@@ -56,138 +62,339 @@ HRD void storeRay(const RayQueue &q, uint32_t slot, const Ray &r, uint32_t pixel
     q.D[slot] = make_int4((int)packMeta(r), r.sequenceIndexOffset, (int)srcPrim, 0);
 }
 
-// ------------------------------------------------------------------------------------------ raygen
-__global__ __launch_bounds__(kBlock) void k_raygen(const SceneDev *__restrict__ Sp, hr_pass_params pp, FrameDev fr, RayQueue q,
-                                                   Counters *ctr, Stats *stats)
+// pixel of thread `gid` in this context's tile shard: tiles in round-robin order, 8x8-pixel blocks inside
+// a tile so that one wave covers a compact screen patch
+HRD bool ownedPixel(const FrameDev &fr, uint32_t gid, int &x, int &y)
 {
-    const SceneDev &S = *Sp;
-    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t perTile = (uint32_t)(fr.tile * fr.tile);
     const uint32_t tileSlot = gid / perTile, within = gid % perTile;
-    bool active = tileSlot < (uint32_t)fr.nOwnedTiles;
+    if (tileSlot >= (uint32_t)fr.nOwnedTiles) return false;
+    const int tileId = fr.rank + (int)tileSlot * fr.world;
+    const int tx = tileId % fr.tilesX, ty = tileId / fr.tilesX;
+    const int blk = (int)(within >> 6), l = (int)(within & 63u), bpr = fr.tile >> 3;
+    x = tx * fr.tile + (blk % bpr) * 8 + (l & 7);
+    y = ty * fr.tile + (blk / bpr) * 8 + (l >> 3);
+    return x < fr.W && y < fr.H;
+}
+
+// ------------------------------------------------------------------------------------------ raygen
+__global__ __launch_bounds__(kBlock) void k_raygen(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, int segIdx, FrameDev fr,
+                                                   Stats *stats)
+{
+    const SceneDev &S = *Sp;
+    const SegDev &seg = tbl->seg[segIdx];
     int x = 0, y = 0;
-    if (active) {
-        const int tileId = fr.rank + (int)tileSlot * fr.world;
-        const int tx = tileId % fr.tilesX, ty = tileId / fr.tilesX;
-        // 8x8-pixel blocks inside the tile so that one wave covers a compact screen patch
-        const int blk = (int)(within >> 6), l = (int)(within & 63u), bpr = fr.tile >> 3;
-        x = tx * fr.tile + (blk % bpr) * 8 + (l & 7);
-        y = ty * fr.tile + (blk / bpr) * 8 + (l >> 3);
-        active = x < fr.W && y < fr.H;
-    }
+    const bool inFrame = ownedPixel(fr, blockIdx.x * kBlock + threadIdx.x, x, y);
+    const uint32_t pixel = (uint32_t)(y * fr.W + x);
     Ray r;
     r.valid = false;
-    if (active) active = generatePrimary(S, pp, fr.W, fr.H, x, y, r);
-    const uint32_t pixel = (uint32_t)(y * fr.W + x);
-    if (active) fr.fb[(size_t)pixel * 4 + 3] += 1.0f; // perspective.rlsl:60 accumulate(vec4(0,0,0,1))
-    const uint32_t slot = waveReserve(active, &ctr->qCount[0]);
-    if (active) storeRay(q, slot, r, pixel, 0xFFFFFFFFu);
+    bool active = inFrame;
+    if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
+    // the pass's sample starts at zero; perspective.rlsl:60 accumulate(vec4(0,0,0,1)) for sampled pixels
+    if (inFrame) reinterpret_cast<float4 *>(seg.passbuf)[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
+    const uint32_t slot = waveReserve(active, seg.qCountIn);
+    if (active) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
     const uint32_t n = waveSum(active ? 1u : 0u);
     if (laneId() == 0 && n) atomicAdd(&stats->paths, (unsigned long long)n);
 }
 
-// ------------------------------------------------------------------------------- closest-hit trace
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_trace_closest(const SceneDev *__restrict__ Sp, RayQueue q, HitRec *__restrict__ hits,
-                                                          Counters *ctr, Stats *stats, int slot)
+// ------------------------------------------------------------------------------------------ resolve
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, const float *__restrict__ passbuf)
 {
-    __shared__ int stack[kWavesPerBlock][kStackLDS][64];
-    const SceneDev &S = *Sp;
-    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
-    int *stackLane = &stack[wave][0][lane];
-    const uint32_t count = ctr->qCount[slot];
-    uint32_t nv = 0, nt = 0;
-    // persistent threads: each wave pulls 64-ray batches until the queue is drained
-    while (true) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->qHead[slot], 64u);
-        base = __shfl(base, 0);
-        if (base >= count) break;
-        const uint32_t i = base + lane;
-        if (i < count) {
-            const float4 a = q.A[i], b = q.B[i];
-            const uint32_t src = (uint32_t)q.D[i].z;
-            HitRec h;
-            traverse<false, STATS>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), S.rayEps, a.w, src, stackLane, h, nv, nt);
-            hits[i] = h;
-        }
-    }
-    if (STATS) {
-        nv = waveSum(nv), nt = waveSum(nt);
-        if (lane == 0) {
-            atomicAdd(&stats->nodeVisits, (unsigned long long)nv);
-            atomicAdd(&stats->triTests, (unsigned long long)nt);
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->raysClosest, (unsigned long long)count);
+    int x = 0, y = 0;
+    if (!ownedPixel(fr, blockIdx.x * kBlock + threadIdx.x, x, y)) return;
+    const uint32_t pixel = (uint32_t)(y * fr.W + x);
+    const float4 s = reinterpret_cast<const float4 *>(passbuf)[pixel];
+    float4 a = reinterpret_cast<float4 *>(fr.fb)[pixel];
+    a.x = a.x + s.x, a.y = a.y + s.y, a.z = a.z + s.z, a.w = a.w + s.w;
+    reinterpret_cast<float4 *>(fr.fb)[pixel] = a;
 }
 
-// --------------------------------------------------------------------------------- occlusion trace
+// -------------------------------------------------------------------------------------------- trace
+// Work items of one launch: for every in-flight pass k, its closest-hit queue followed by its occlusion
+// queue.  segStart[2k] / segStart[2k+1] are the first global indices of the two.
+HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxSegs+1 */, bool closestOnly)
+{
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        const int n = tbl->nSeg;
+        for (int k = 0; k < n; ++k) {
+            const SegDev &sg = tbl->seg[k];
+            segStart[2 * k] = acc;
+            acc += sg.closestEnabled ? *sg.qCountIn : 0u;
+            segStart[2 * k + 1] = acc;
+            acc += closestOnly ? 0u : *sg.sCountIn;
+        }
+        segStart[2 * n] = acc;
+    }
+    __syncthreads();
+}
+
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_trace_shadow(const SceneDev *__restrict__ Sp, ShadowQueue sq, float *__restrict__ fb, Counters *ctr,
-                                                         Stats *stats, int slot)
+__global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ Sp, StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ int stack[kWavesPerBlock][kStackLDS][64];
+    __shared__ uint32_t segStart[2 * kMaxSegs + 1];
     const SceneDev &S = *Sp;
+    buildSegStarts(tbl, segStart, false);
+    const int nSeg2 = 2 * tbl->nSeg;
+    const uint32_t total = segStart[nSeg2];
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
     int *stackLane = &stack[wave][0][lane];
-    const uint32_t count = ctr->sCount[slot];
-    uint32_t nv = 0, nt = 0, nacc = 0;
-    while (true) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&ctr->sHead[slot], 64u);
-        base = __shfl(base, 0);
-        if (base >= count) break;
-        const uint32_t i = base + lane;
-        if (i < count) {
-            const float4 a = sq.A[i], b = sq.B[i];
-            HitRec h;
-            traverse<true, STATS>(S, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), S.rayEps, a.w, __float_as_uint(b.w), stackLane, h, nv, nt);
-            if (h.prim == kMissPrim) { // unoccluded: the light's shader accumulates (single owner per pixel)
-                const float4 c = sq.C[i];
-                float *px = fb + (size_t)__float_as_uint(c.w) * 4;
-                px[0] = px[0] + c.x;
-                px[1] = px[1] + c.y;
-                px[2] = px[2] + c.z;
-                ++nacc;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+
+    // ---- per-lane traversal state (one ray per lane, refilled from the work pool when a lane finishes)
+    int cur = kSentinel, sp = 0;
+    uint32_t item = 0xFFFFFFFFu; // global work index of the ray this lane holds
+    int segIdx = 0;              // 2k: closest-hit ray of pass k, 2k+1: occlusion ray of pass k
+    uint32_t local = 0;          // index inside that queue
+    v3 o(0.0f), d(0.0f);
+    float idx = 0, idy = 0, idz = 0, oix = 0, oiy = 0, oiz = 0, tmax = 0, tlim = 0;
+    uint32_t skipPrim = 0xFFFFFFFFu;
+    HitRec best;
+    best.prim = kMissPrim, best.t = 0, best.u = 0, best.v = 0;
+    int ovf[kStackOvf];
+    const float tmin = S.rayEps;
+    const int rootRef = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
+
+    uint32_t poolLo = 0, poolHi = 0; // wave-uniform: indices this wave has reserved and not handed out yet
+    bool exhausted = false;          // wave-uniform: the global cursor ran past the end
+    uint32_t nvC = 0, ntC = 0, nvA = 0, ntA = 0, nacc = 0;
+
+#define HR_PUSH(v)                          \
+    do {                                    \
+        if (sp < kStackLDS)                 \
+            stackLane[sp * 64] = (v);       \
+        else                                \
+            ovf[sp - kStackLDS] = (v);      \
+        ++sp;                               \
+    } while (0)
+#define HR_POP()                                                                   \
+    do {                                                                           \
+        if (sp == 0)                                                               \
+            cur = kSentinel;                                                       \
+        else {                                                                     \
+            --sp;                                                                  \
+            cur = (sp < kStackLDS) ? stackLane[sp * 64] : ovf[sp - kStackLDS];     \
+        }                                                                          \
+    } while (0)
+
+    for (;;) {
+        // ---------------- refill idle lanes (persistent threads with dynamic fetch)
+        bool idle = (cur == kSentinel);
+        unsigned long long idleMask = __ballot(idle);
+        int nIdle = __popcll(idleMask);
+        if (!exhausted && (nIdle >= kRefillLanes || nIdle == 64)) {
+            for (int round = 0; round < 2 && nIdle > 0; ++round) {
+                if (poolLo == poolHi) { // reserve another chunk of the global index space
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&tbl->traceHead, (uint32_t)kFetchChunk);
+                    base = __shfl(base, 0);
+                    if (base >= total) {
+                        exhausted = true;
+                        break;
+                    }
+                    poolLo = base;
+                    poolHi = (base + kFetchChunk < total) ? base + kFetchChunk : total;
+                }
+                const uint32_t avail = poolHi - poolLo;
+                const uint32_t rank = (uint32_t)__popcll(idleMask & ltMask);
+                if (idle && rank < avail) {
+                    item = poolLo + rank;
+                    // which queue does the item belong to (at most 2*kMaxSegs entries)
+                    int sI = 0;
+                    while (sI + 1 < nSeg2 && item >= segStart[sI + 1]) ++sI;
+                    segIdx = sI;
+                    local = item - segStart[sI];
+                    const SegDev &sg = tbl->seg[sI >> 1];
+                    float4 a, b;
+                    if (sI & 1) { // occlusion ray
+                        a = sg.sq.A[local], b = sg.sq.B[local];
+                        skipPrim = __float_as_uint(b.w);
+                    } else {
+                        a = sg.qin.A[local], b = sg.qin.B[local];
+                        skipPrim = (uint32_t)sg.qin.D[local].z;
+                    }
+                    o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
+                    tmax = a.w, tlim = a.w;
+                    idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
+                    oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
+                    best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
+                    sp = 0;
+                    cur = rootRef;
+                    idle = false;
+                }
+                const uint32_t taken = avail < (uint32_t)nIdle ? avail : (uint32_t)nIdle;
+                poolLo += taken;
+                idleMask = __ballot(idle);
+                nIdle = __popcll(idleMask);
             }
         }
+        if (nIdle == 64) { // nothing to traverse (finished rays were retired at the end of the previous round)
+            if (exhausted) break;
+            continue;
+        }
+
+        const bool isAny = (segIdx & 1) != 0;
+        // ---------------- inner nodes: descend until this lane holds a leaf or runs out of work
+        while (cur >= 0 && cur != kSentinel) {
+            const Node &n = S.nodes[cur];
+            const float4 na = n.a, nb = n.b, nc = n.c;
+            const int4 nd = n.d;
+            if (STATS) {
+                if (isAny)
+                    ++nvA;
+                else
+                    ++nvC;
+            }
+            float t0 = __builtin_fmaf(na.x, idx, -oix), t1 = __builtin_fmaf(na.w, idx, -oix);
+            float t2 = __builtin_fmaf(na.y, idy, -oiy), t3 = __builtin_fmaf(nb.x, idy, -oiy);
+            float t4 = __builtin_fmaf(na.z, idz, -oiz), t5 = __builtin_fmaf(nb.y, idz, -oiz);
+            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
+                                              __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
+            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
+                                              __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
+            t0 = __builtin_fmaf(nb.z, idx, -oix), t1 = __builtin_fmaf(nc.y, idx, -oix);
+            t2 = __builtin_fmaf(nb.w, idy, -oiy), t3 = __builtin_fmaf(nc.z, idy, -oiy);
+            t4 = __builtin_fmaf(nc.x, idz, -oiz), t5 = __builtin_fmaf(nc.w, idz, -oiz);
+            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
+                                              __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
+            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
+                                              __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            if (h0 && h1) {
+                const bool firstIs0 = tn0 <= tn1;
+                const int nearC = firstIs0 ? nd.x : nd.y, farC = firstIs0 ? nd.y : nd.x;
+                HR_PUSH(farC);
+                cur = nearC;
+            } else if (h0) {
+                cur = nd.x;
+            } else if (h1) {
+                cur = nd.y;
+            } else {
+                HR_POP();
+            }
+        }
+        // ---------------- leaf: 1..4 triangles
+        if (cur < 0) {
+            const int enc = ~cur;
+            const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
+            bool occluded = false;
+            for (int k = 0; k < count; ++k) {
+                const Tri &tr = S.tris[first + k];
+                const float4 tp = tr.p, tq = tr.q, trr = tr.r;
+                if (STATS) {
+                    if (isAny)
+                        ++ntA;
+                    else
+                        ++ntC;
+                }
+                const uint32_t prim = __float_as_uint(trr.y);
+                if (prim == skipPrim) continue;
+                const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
+                // Möller–Trumbore; the operation order is part of the arithmetic contract
+                const v3 pvec = cross(d, e2);
+                const float det = dot(e1, pvec);
+                if (det == 0.0f) continue;
+                const float inv = 1.0f / det;
+                const v3 tvec = o - v0;
+                const float u = dot(tvec, pvec) * inv;
+                if (!(u >= 0.0f) || u > 1.0f) continue;
+                const v3 qvec = cross(tvec, e1);
+                const float v = dot(d, qvec) * inv;
+                if (!(v >= 0.0f) || u + v > 1.0f) continue;
+                const float t = dot(e2, qvec) * inv;
+                if (!(t > tmin) || !(t < tmax)) continue;
+                if (isAny) {
+                    if ((__float_as_uint(trr.z) & TF_NON_OCCLUDER) && alphaPasses(S, prim, u, v)) continue;
+                    occluded = true;
+                    break;
+                }
+                const uint32_t bp = best.prim & 0x7FFFFFFFu;
+                if (best.prim == kMissPrim || t < best.t || (t == best.t && prim < bp)) {
+                    best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
+                    best.t = t, best.u = u, best.v = v;
+                    tlim = t;
+                }
+            }
+            if (occluded) {
+                best.prim = 0u; // anything but kMissPrim
+                cur = kSentinel;
+            } else {
+                HR_POP();
+            }
+        }
+        // ---------------- retire finished rays
+        if (cur == kSentinel && item != 0xFFFFFFFFu) {
+            const SegDev &sg = tbl->seg[segIdx >> 1];
+            if (isAny) {
+                if (best.prim == kMissPrim) { // unoccluded: the light's shader accumulates into the pass's sample
+                    const float4 c = sg.sq.C[local];
+                    float *px = sg.passbuf + (size_t)__float_as_uint(c.w) * 4;
+                    px[0] = px[0] + c.x;
+                    px[1] = px[1] + c.y;
+                    px[2] = px[2] + c.z;
+                    ++nacc;
+                }
+            } else {
+                sg.hits[local] = best;
+            }
+            item = 0xFFFFFFFFu;
+        }
     }
+#undef HR_PUSH
+#undef HR_POP
+
     nacc = waveSum(nacc);
     if (lane == 0 && nacc) atomicAdd(&stats->accumulates, (unsigned long long)nacc);
     if (STATS) {
-        nv = waveSum(nv), nt = waveSum(nt);
+        nvC = waveSum(nvC), ntC = waveSum(ntC), nvA = waveSum(nvA), ntA = waveSum(ntA);
         if (lane == 0) {
-            atomicAdd(&stats->nodeVisits, (unsigned long long)nv);
-            atomicAdd(&stats->triTests, (unsigned long long)nt);
-            atomicAdd(&stats->nodeVisitsAny, (unsigned long long)nv);
-            atomicAdd(&stats->triTestsAny, (unsigned long long)nt);
+            atomicAdd(&stats->nodeVisits, (unsigned long long)nvC + nvA);
+            atomicAdd(&stats->triTests, (unsigned long long)ntC + ntA);
+            atomicAdd(&stats->nodeVisitsAny, (unsigned long long)nvA);
+            atomicAdd(&stats->triTestsAny, (unsigned long long)ntA);
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats->raysAny, (unsigned long long)count);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long nc = 0, na = 0;
+        for (int k = 0; k < tbl->nSeg; ++k) {
+            nc += segStart[2 * k + 1] - segStart[2 * k];
+            na += segStart[2 * k + 2] - segStart[2 * k + 1];
+        }
+        atomicAdd(&stats->raysClosest, nc);
+        atomicAdd(&stats->raysAny, na);
+    }
 }
 
 // ------------------------------------------------------------------------------------------- shade
-__global__ __launch_bounds__(kBlock) void k_shade(const SceneDev *__restrict__ Sp, hr_pass_params pp, float *__restrict__ fb, RayQueue qin,
-                                                  const HitRec *__restrict__ hits, RayQueue qout, ShadowQueue sq, Counters *ctr, Stats *stats,
-                                                  int slot)
+__global__ __launch_bounds__(kBlock) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
 {
+    __shared__ uint32_t segStart[2 * kMaxSegs + 1];
     const SceneDev &S = *Sp;
-    const uint32_t count = ctr->qCount[slot];
+    buildSegStarts(tbl, segStart, true);
+    const int nSeg = tbl->nSeg;
+    const uint32_t total = segStart[2 * nSeg];
     const uint32_t lane = laneId();
     uint32_t nShaded = 0, nAccum = 0;
-    // wave-uniform trip count: every lane of a wave takes part in the compaction ballots
-    for (uint32_t base = (blockIdx.x * kBlock + (threadIdx.x & ~63u)); base < count; base += gridDim.x * kBlock) {
+    // Waves take 64 consecutive work items; a batch may straddle two passes, so the compaction ballots are
+    // done per pass.  The trip count is wave-uniform.
+    for (uint32_t base = (blockIdx.x * kBlock + (threadIdx.x & ~63u)); base < total; base += gridDim.x * kBlock) {
         const uint32_t i = base + lane;
-        const bool live = i < count;
+        const bool live = i < total;
+        int sI = 0;
+        if (live)
+            while (sI + 1 < nSeg && i >= segStart[2 * (sI + 1)]) ++sI;
         Ray nee, next;
         nee.valid = next.valid = false;
         uint32_t pixel = 0, prim = 0xFFFFFFFFu;
         v3 neeValue(0.0f);
         if (live) {
-            const float4 a = qin.A[i], b = qin.B[i], c = qin.C[i];
-            const int4 dm = qin.D[i];
-            const HitRec h = hits[i];
+            const SegDev &sg = tbl->seg[sI];
+            const uint32_t li = i - segStart[2 * sI];
+            const float4 a = sg.qin.A[li], b = sg.qin.B[li], c = sg.qin.C[li];
+            const int4 dm = sg.qin.D[li];
+            const HitRec h = sg.hits[li];
             Ray in;
             in.o = v3(a.x, a.y, a.z), in.d = v3(b.x, b.y, b.z), in.maxT = a.w, in.extraT = b.w;
             in.weight = v3(c.x, c.y, c.z);
@@ -197,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void k_shade(const SceneDev *__restrict__ S
             in.missKind = (int)((meta >> 24) & 7u), in.missIdx = (int)((meta >> 27) & 7u);
             in.sequenceIndexOffset = dm.y;
             in.occlusionTest = false, in.valid = true;
-            Shader sh(S, pp, fb + (size_t)pixel * 4);
+            Shader sh(S, sg.pp, sg.passbuf + (size_t)pixel * 4);
             if (h.prim == kMissPrim) {
                 // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
                 if (in.missKind == MISS_ENV) sh.performAccumulate(sh.environmentRadiance(in.d, in.weight));
@@ -219,14 +426,24 @@ __global__ __launch_bounds__(kBlock) void k_shade(const SceneDev *__restrict__ S
             }
             nAccum += sh.nAccum;
         }
-        const uint32_t sSlot = waveReserve(nee.valid, &ctr->sCount[slot]);
-        if (nee.valid) {
-            sq.A[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
-            sq.B[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-            sq.C[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+        // per-pass compaction of the emitted rays
+        // work items ascend with the lane index, so the passes present in this batch are a contiguous range
+        const int sLo = __shfl(sI, 0);
+        const int sHi = __shfl(sI, __popcll(__ballot(live)) - 1);
+        for (int s = sLo; s <= sHi; ++s) {
+            const SegDev &sg = tbl->seg[s];
+            const bool mine = live && sI == s;
+            const bool wantS = mine && nee.valid;
+            const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
+            if (wantS) {
+                sg.sq.A[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                sg.sq.B[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
+                sg.sq.C[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+            }
+            const bool wantQ = mine && next.valid;
+            const uint32_t qSlot = waveReserve(wantQ, sg.qCountOut);
+            if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
         }
-        const uint32_t qSlot = waveReserve(next.valid, &ctr->qCount[slot + 1]);
-        if (next.valid) storeRay(qout, qSlot, next, pixel, prim);
     }
     nShaded = waveSum(nShaded), nAccum = waveSum(nAccum);
     if (lane == 0) {
@@ -266,39 +483,35 @@ __global__ __launch_bounds__(kBlock) void k_debug_trace(const SceneDev *__restri
 }
 
 // ------------------------------------------------------------------------------------- launchers
-static int gridFor(const LaunchCfg &cfg, int blocksPerCU) { return cfg.numCUs * blocksPerCU; }
+static int ownedThreads(const FrameDev &fr) { return fr.nOwnedTiles * fr.tile * fr.tile; }
 
-void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const hr_pass_params &pp, const FrameDev &fr, RayQueue q, Counters *ctr, Stats *stats)
+void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, int segIdx, const FrameDev &fr, Stats *stats)
 {
-    const long long threads = (long long)fr.nOwnedTiles * fr.tile * fr.tile;
+    const int threads = ownedThreads(fr);
     if (threads <= 0) return;
-    const int blocks = (int)((threads + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_raygen, dim3(blocks), dim3(kBlock), 0, cfg.stream, S, pp, fr, q, ctr, stats);
+    hipLaunchKernelGGL(k_raygen, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, S, tbl, segIdx, fr, stats);
 }
 
-void launchTraceClosest(const LaunchCfg &cfg, const SceneDev *S, RayQueue q, void *hits, Counters *ctr, Stats *stats, int slot)
+void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbuf)
 {
-    const int grid = gridFor(cfg, cfg.traceBlocksPerCU);
+    const int threads = ownedThreads(fr);
+    if (threads <= 0) return;
+    hipLaunchKernelGGL(k_resolve, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, fr, passbuf);
+}
+
+void launchTrace(const LaunchCfg &cfg, const SceneDev *S, StepTable *tbl, Stats *stats)
+{
+    const int grid = cfg.numCUs * cfg.traceBlocksPerCU;
     if (cfg.collectStats)
-        hipLaunchKernelGGL(k_trace_closest<true>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, q, (HitRec *)hits, ctr, stats, slot);
+        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, tbl, stats);
     else
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, q, (HitRec *)hits, ctr, stats, slot);
+        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, tbl, stats);
 }
 
-void launchTraceShadow(const LaunchCfg &cfg, const SceneDev *S, ShadowQueue sq, float *fb, Counters *ctr, Stats *stats, int slot)
+void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats)
 {
-    const int grid = gridFor(cfg, cfg.traceBlocksPerCU);
-    if (cfg.collectStats)
-        hipLaunchKernelGGL(k_trace_shadow<true>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, sq, fb, ctr, stats, slot);
-    else
-        hipLaunchKernelGGL(k_trace_shadow<false>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, sq, fb, ctr, stats, slot);
-}
-
-void launchShade(const LaunchCfg &cfg, const SceneDev *S, const hr_pass_params &pp, float *fb, RayQueue qin, const void *hits, RayQueue qout,
-                 ShadowQueue sq, Counters *ctr, Stats *stats, int slot)
-{
-    const int grid = gridFor(cfg, cfg.shadeBlocksPerCU);
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, cfg.stream, S, pp, fb, qin, (const HitRec *)hits, qout, sq, ctr, stats, slot);
+    const int grid = cfg.numCUs * cfg.shadeBlocksPerCU;
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, cfg.stream, S, tbl, stats);
 }
 
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,

@@ -18,6 +18,8 @@ namespace hr {
 static const int kStackLDS = 24;   // entries per lane kept in LDS
 static const int kStackOvf = 40;   // private overflow (LBVH depth <= 30 + 28 index bits < 64)
 static const int kSentinel = 0x7FFFFFFF;
+static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
+static const int kFetchChunk = 256; // work items a wave reserves per global atomic
 
 struct HitRec {
     uint32_t prim; // kMissPrim when nothing was hit; bit 31: counter-clockwise front face seen by the ray

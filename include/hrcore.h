@@ -330,9 +330,9 @@ typedef struct hr_pass_stats {
  * (HR_CTX_TIME_KERNELS only).  OpenRL's counterpart: RL_RENDER_FRAME_TIME /
  * RL_PROFILE (rl.h:346-355), which Heatray never queries. */
 #define HR_KERNEL_RAYGEN 0
-#define HR_KERNEL_TRACE_CLOSEST 1
-#define HR_KERNEL_TRACE_ANY 2
-#define HR_KERNEL_SHADE 3
+#define HR_KERNEL_TRACE 1   /* closest-hit + occlusion traversal (one kernel) */
+#define HR_KERNEL_SHADE 2
+#define HR_KERNEL_RESOLVE 3 /* finished pass samples -> accumulation buffer */
 #define HR_KERNEL_COUNT 4
 typedef struct hr_kernel_times {
     float ms[HR_KERNEL_COUNT];
@@ -342,9 +342,15 @@ typedef struct hr_kernel_times {
 /* replaces rlClear(RL_COLOR_BUFFER_BIT) (PassGenerator.cpp:439) */
 int hr_clear(hr_ctx *ctx);
 /* replaces rlRenderFrame() (PassGenerator.cpp:386): one sample per owned pixel.
- * Asynchronous on the ctx stream; stats (optional) are cumulative since the last
- * hr_clear and are fetched with hr_get_stats. */
+ * Asynchronous on the ctx stream, and PIPELINED: up to max_ray_depth+2 passes are
+ * kept in flight at different bounce stages; a pass's sample reaches the
+ * accumulation buffer when its last stage has run, always in pass order.
+ * hr_readback / hr_get_stats / hr_clear / hr_synchronize / hr_flush and every call
+ * that changes scene state complete all enqueued passes first. */
 int hr_render_pass(hr_ctx *ctx, const hr_pass_params *params);
+/* enqueue the remaining stages of every pass in flight (asynchronous): after it, work
+ * the caller puts on the ctx stream sees every requested sample in the buffer */
+int hr_flush(hr_ctx *ctx);
 /* synchronises the stream, then copies the counters */
 int hr_get_stats(hr_ctx *ctx, hr_pass_stats *out);
 /* synchronises the stream, then sums the recorded event pairs */

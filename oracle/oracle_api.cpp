@@ -294,6 +294,7 @@ int ora_readback(hr_ctx *ctx, const float **rgba, int32_t *w, int32_t *h)
     return HR_OK;
 }
 int ora_synchronize(hr_ctx *) { return HR_OK; }
+int ora_flush(hr_ctx *) { return HR_OK; }
 
 int ora_debug_trace(hr_ctx *ctx, int32_t n, const float *o, const float *d, const float *tmax, const int32_t *skip, int32_t anyHit, hr_hit *out)
 {

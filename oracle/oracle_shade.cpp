@@ -3,9 +3,10 @@
 // Scalar restatement of the RLSL shaders OpenRL runs inside rlRenderFrame()
 // (/root/reference/Source/HeatrayRenderer/PassGenerator.cpp:386).  Every function cites
 // the shader text it follows (paths relative to /root/reference/Resources/shaders).
-// One path per owned pixel per pass; per pixel the framebuffer adds happen in the
-// order  A+=1, then for each bounce: emissive, NEE light, (miss) environment —
-// the order the HIP wavefront loop reproduces.
+// One path per owned pixel per pass.  A pass's sample is the sum, in path order
+// (A+=1, then for each bounce: emissive, NEE light, (miss) environment), of the path's
+// accumulate() calls, starting from zero; the sample is added to the accumulation
+// buffer once when the path ends — the order the HIP wavefront pipeline reproduces.
 #include "oracle_internal.h"
 
 #include <cmath>
@@ -34,11 +35,16 @@ struct Ray {
 struct Shader {
     Context &ctx;
     const hr_pass_params &pp;
-    float *px; // RGBA of the pixel being shaded
+    float *fbPixel;  // RGBA of the pixel being shaded in the accumulation buffer
+    float px[4];     // this pass's sample: the path's accumulate() calls are summed here in path order
+                     // and added to the accumulation buffer ONCE when the path ends
     hr_pass_stats &st;
     TraceCounters tc, tcAny;
 
-    Shader(Context &c, const hr_pass_params &p, float *pixel, hr_pass_stats &s) : ctx(c), pp(p), px(pixel), st(s) {}
+    Shader(Context &c, const hr_pass_params &p, float *pixel, hr_pass_stats &s) : ctx(c), pp(p), fbPixel(pixel), st(s)
+    {
+        px[0] = px[1] = px[2] = px[3] = 0.0f;
+    }
 
     // ---- sequence.rlsl:18-28 ----
     vec2 getSequenceValue(int sequenceIndex, int sampleIndex) const
@@ -904,6 +910,7 @@ struct Shader {
             }
             ray = next;
         }
+        for (int k = 0; k < 4; ++k) fbPixel[k] = fbPixel[k] + px[k];
     }
 };
 
