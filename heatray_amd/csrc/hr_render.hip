@@ -179,9 +179,10 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         }                                                                          \
     } while (0)
 
+    int pend = 0; // postponed leaf (a negative leaf reference) or 0: the lane keeps descending while a leaf waits
     for (;;) {
         // ---------------- refill idle lanes (persistent threads with dynamic fetch)
-        bool idle = (cur == kSentinel);
+        bool idle = (item == 0xFFFFFFFFu);
         unsigned long long idleMask = __ballot(idle);
         int nIdle = __popcll(idleMask);
         if (!exhausted && (nIdle >= kRefillLanes || nIdle == 64)) {
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                     oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
                     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
                     sp = 0;
+                    pend = 0;
                     cur = rootRef;
                     idle = false;
                 }
@@ -230,14 +232,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                 nIdle = __popcll(idleMask);
             }
         }
-        if (nIdle == 64) { // nothing to traverse (finished rays were retired at the end of the previous round)
+        if (nIdle == 64) { // nothing in flight (finished rays were retired at the end of the previous round)
             if (exhausted) break;
             continue;
         }
 
         const bool isAny = (segIdx & 1) != 0;
-        // ---------------- inner nodes: descend until this lane holds a leaf or runs out of work
-        while (cur >= 0 && cur != kSentinel) {
+        // ---------------- one inner-node step for every lane that holds an inner node
+        if (cur >= 0 && cur != kSentinel) {
             const Node &n = S.nodes[cur];
             const float4 na = n.a, nb = n.b, nc = n.c;
             const int4 nd = n.d;
@@ -275,57 +277,63 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                 HR_POP();
             }
         }
-        // ---------------- leaf: 1..4 triangles
-        if (cur < 0) {
-            const int enc = ~cur;
-            const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
-            bool occluded = false;
-            for (int k = 0; k < count; ++k) {
-                const Tri &tr = S.tris[first + k];
-                const float4 tp = tr.p, tq = tr.q, trr = tr.r;
-                if (STATS) {
-                    if (isAny)
-                        ++ntA;
-                    else
-                        ++ntC;
+        // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
+        // postponed it is blocked until the wave runs the triangle phase
+        if (cur < 0 && pend == 0) {
+            pend = cur;
+            HR_POP();
+        }
+        // ---------------- triangle phase: run it once enough lanes wait for it, or when nobody can descend any more
+        const unsigned long long blockedMask = __ballot(pend != 0 && (cur < 0 || cur == kSentinel));
+        const unsigned long long nodeMask = __ballot(cur >= 0 && cur != kSentinel);
+        if (blockedMask != 0ull && (__popcll(blockedMask) >= kTriPhaseLanes || nodeMask == 0ull)) {
+            if (pend != 0) {
+                const int enc = ~pend;
+                const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
+                pend = 0;
+                for (int k = 0; k < count; ++k) {
+                    const Tri &tr = S.tris[first + k];
+                    const float4 tp = tr.p, tq = tr.q, trr = tr.r;
+                    if (STATS) {
+                        if (isAny)
+                            ++ntA;
+                        else
+                            ++ntC;
+                    }
+                    const uint32_t prim = __float_as_uint(trr.y);
+                    if (prim == skipPrim) continue;
+                    const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
+                    // Möller–Trumbore; the operation order is part of the arithmetic contract
+                    const v3 pvec = cross(d, e2);
+                    const float det = dot(e1, pvec);
+                    if (det == 0.0f) continue;
+                    const float inv = 1.0f / det;
+                    const v3 tvec = o - v0;
+                    const float u = dot(tvec, pvec) * inv;
+                    if (!(u >= 0.0f) || u > 1.0f) continue;
+                    const v3 qvec = cross(tvec, e1);
+                    const float v = dot(d, qvec) * inv;
+                    if (!(v >= 0.0f) || u + v > 1.0f) continue;
+                    const float t = dot(e2, qvec) * inv;
+                    if (!(t > tmin) || !(t < tmax)) continue;
+                    if (isAny) {
+                        if ((__float_as_uint(trr.z) & TF_NON_OCCLUDER) && alphaPasses(S, prim, u, v)) continue;
+                        best.prim = 0u; // occluded (anything but kMissPrim)
+                        cur = kSentinel;
+                        sp = 0;
+                        break;
+                    }
+                    const uint32_t bp = best.prim & 0x7FFFFFFFu;
+                    if (best.prim == kMissPrim || t < best.t || (t == best.t && prim < bp)) {
+                        best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
+                        best.t = t, best.u = u, best.v = v;
+                        tlim = t;
+                    }
                 }
-                const uint32_t prim = __float_as_uint(trr.y);
-                if (prim == skipPrim) continue;
-                const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
-                // Möller–Trumbore; the operation order is part of the arithmetic contract
-                const v3 pvec = cross(d, e2);
-                const float det = dot(e1, pvec);
-                if (det == 0.0f) continue;
-                const float inv = 1.0f / det;
-                const v3 tvec = o - v0;
-                const float u = dot(tvec, pvec) * inv;
-                if (!(u >= 0.0f) || u > 1.0f) continue;
-                const v3 qvec = cross(tvec, e1);
-                const float v = dot(d, qvec) * inv;
-                if (!(v >= 0.0f) || u + v > 1.0f) continue;
-                const float t = dot(e2, qvec) * inv;
-                if (!(t > tmin) || !(t < tmax)) continue;
-                if (isAny) {
-                    if ((__float_as_uint(trr.z) & TF_NON_OCCLUDER) && alphaPasses(S, prim, u, v)) continue;
-                    occluded = true;
-                    break;
-                }
-                const uint32_t bp = best.prim & 0x7FFFFFFFu;
-                if (best.prim == kMissPrim || t < best.t || (t == best.t && prim < bp)) {
-                    best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
-                    best.t = t, best.u = u, best.v = v;
-                    tlim = t;
-                }
-            }
-            if (occluded) {
-                best.prim = 0u; // anything but kMissPrim
-                cur = kSentinel;
-            } else {
-                HR_POP();
             }
         }
         // ---------------- retire finished rays
-        if (cur == kSentinel && item != 0xFFFFFFFFu) {
+        if (cur == kSentinel && pend == 0 && item != 0xFFFFFFFFu) {
             const SegDev &sg = tbl->seg[segIdx >> 1];
             if (isAny) {
                 if (best.prim == kMissPrim) { // unoccluded: the light's shader accumulates into the pass's sample

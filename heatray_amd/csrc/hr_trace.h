@@ -20,6 +20,7 @@ static const int kStackOvf = 40;   // private overflow (LBVH depth <= 30 + 28 in
 static const int kSentinel = 0x7FFFFFFF;
 static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
 static const int kFetchChunk = 256; // work items a wave reserves per global atomic
+static const int kTriPhaseLanes = 20; // run the triangle phase once this many lanes are blocked on a postponed leaf
 
 struct HitRec {
     uint32_t prim; // kMissPrim when nothing was hit; bit 31: counter-clockwise front face seen by the ray
