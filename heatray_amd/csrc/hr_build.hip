@@ -331,36 +331,105 @@ __global__ __launch_bounds__(256) void k_flag_internal(const KNode *__restrict__
     flags[i] = (nodes[i].last - nodes[i].first + 1 > kLeafMax) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(256) void k_emit_nodes(const KNode *__restrict__ nodes, int nInternal, const Box6 *__restrict__ leafBox,
-                                                    const Box6 *__restrict__ nodeBox, const uint32_t *__restrict__ outIndex, Node *__restrict__ out)
+// Collapse the binary tree into 4-wide nodes, one tree level per launch.  binOf[i] is the binary (Karras)
+// node that 4-wide node i stands for.  Starting from its two children, the inner child with the largest
+// surface area is replaced by its own two children until four children exist (or none can be opened);
+// subtrees of <= kLeafMax triangles are leaves.  New 4-wide nodes are appended through an atomic counter.
+HRD float boxArea(const Box6 &b)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nInternal) return;
-    const KNode k = nodes[i];
-    if (k.last - k.first + 1 <= kLeafMax) return;
-    const int refs[2] = {k.left, k.right};
-    Box6 bx[2];
-    int child[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int ref = refs[c];
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// biased exponent e (1..254) of the smallest power of two s = 2^(e-127) with ext / s <= 255
+HRD uint32_t quantExponent(float ext)
+{
+    const float f = ext * (1.0f / 255.0f);
+    uint32_t bits = __float_as_uint(f);
+    uint32_t e = (bits >> 23) & 0xFFu;
+    if (bits & 0x007FFFFFu) e += 1;                   // round the scale up to a power of two
+    if (__uint_as_float(e << 23) * 255.0f < ext) e += 1; // guard against the rounding of ext/255
+    return e < 1u ? 1u : (e > 254u ? 254u : e);
+}
+
+__global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ knodes, const Box6 *__restrict__ leafBox,
+                                                   const Box6 *__restrict__ nodeBox, int *__restrict__ binOf, uint32_t levelStart,
+                                                   uint32_t levelEnd, uint32_t *__restrict__ counter, Node4 *__restrict__ out)
+{
+    const uint32_t i = levelStart + blockIdx.x * 256 + threadIdx.x;
+    if (i >= levelEnd) return;
+    const int b = binOf[i];
+    int cand[4];
+    int n = 2;
+    cand[0] = knodes[b].left, cand[1] = knodes[b].right;
+    cand[2] = cand[3] = 0;
+    for (int round = 0; round < 2; ++round) {
+        int pick = -1;
+        float bestArea = -1.0f;
+        for (int c = 0; c < n; ++c) {
+            const int ref = cand[c];
+            if (ref < 0) continue;
+            if (knodes[ref].last - knodes[ref].first + 1 <= kLeafMax) continue;
+            const float a = boxArea(nodeBox[ref]);
+            if (a > bestArea) bestArea = a, pick = c;
+        }
+        if (pick < 0) break;
+        const int ref = cand[pick];
+        cand[pick] = knodes[ref].left;
+        cand[n++] = knodes[ref].right;
+    }
+    Box6 cb[4];
+    int child[4];
+    Box6 nb;
+    for (int k = 0; k < 3; ++k) nb.lo[k] = __builtin_inff(), nb.hi[k] = -__builtin_inff();
+    for (int c = 0; c < 4; ++c) {
+        child[c] = kEmptyChild;
+        if (c >= n) continue;
+        const int ref = cand[c];
         int first, last;
         if (ref < 0) {
             first = last = ~ref;
-            bx[c] = leafBox[~ref];
+            cb[c] = leafBox[~ref];
         } else {
-            first = nodes[ref].first, last = nodes[ref].last;
-            bx[c] = nodeBox[ref];
+            first = knodes[ref].first, last = knodes[ref].last;
+            cb[c] = nodeBox[ref];
         }
         const int count = last - first + 1;
-        child[c] = (count <= kLeafMax) ? ~(first | ((count - 1) << 28)) : (int)outIndex[ref];
+        if (count <= kLeafMax) {
+            child[c] = ~(first | ((count - 1) << 28));
+        } else {
+            const uint32_t j = atomicAdd(counter, 1u);
+            binOf[j] = ref;
+            child[c] = (int)j;
+        }
+        for (int k = 0; k < 3; ++k) nb.lo[k] = fmin_(nb.lo[k], cb[c].lo[k]), nb.hi[k] = fmax_(nb.hi[k], cb[c].hi[k]);
     }
-    Node nd;
-    nd.a = make_float4(bx[0].lo[0], bx[0].lo[1], bx[0].lo[2], bx[0].hi[0]);
-    nd.b = make_float4(bx[0].hi[1], bx[0].hi[2], bx[1].lo[0], bx[1].lo[1]);
-    nd.c = make_float4(bx[1].lo[2], bx[1].hi[0], bx[1].hi[1], bx[1].hi[2]);
-    nd.d = make_int4(child[0], child[1], 0, 0);
-    out[outIndex[i]] = nd;
+    uint32_t e[3];
+    float inv[3];
+    for (int k = 0; k < 3; ++k) {
+        e[k] = quantExponent(nb.hi[k] - nb.lo[k]);
+        inv[k] = 1.0f / __uint_as_float(e[k] << 23);
+    }
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int c = 0; c < 4; ++c) {
+        for (int k = 0; k < 3; ++k) {
+            uint32_t lo8 = 255u, hi8 = 0u; // empty child: inverted box, never hit
+            if (c < n) {
+                const float fl = floor_((cb[c].lo[k] - nb.lo[k]) * inv[k]);
+                const float fh = __builtin_ceilf((cb[c].hi[k] - nb.lo[k]) * inv[k]);
+                lo8 = (uint32_t)fmin_(fmax_(fl, 0.0f), 255.0f);
+                hi8 = (uint32_t)fmin_(fmax_(fh, 0.0f), 255.0f);
+            }
+            qlo[k] |= lo8 << (8 * c);
+            qhi[k] |= hi8 << (8 * c);
+        }
+    }
+    Node4 nd;
+    nd.a = make_float4(nb.lo[0], nb.lo[1], nb.lo[2], __uint_as_float(e[0] | (e[1] << 8) | (e[2] << 16)));
+    nd.b = make_int4(child[0], child[1], child[2], child[3]);
+    nd.c = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+    nd.d = make_uint4(qhi[1], qhi[2], 0u, 0u);
+    out[i] = nd;
 }
 
 int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, BuildResult *out)
@@ -421,14 +490,37 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
             HR_CHECK(hipStreamSynchronize(st));
         }
         if (rootStamp == 0) rc = 3;
+        // upper bound of the 4-wide node count: binary nodes with more than kLeafMax triangles
         hipLaunchKernelGGL(k_flag_internal, dim3(gi), dim3(256), 0, st, knodes, nInternal, flags);
         hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, flags, (uint32_t)nInternal, total);
-        uint32_t nOut = 0;
-        HR_CHECK(hipMemcpyAsync(&nOut, total, 4, hipMemcpyDeviceToHost, st));
+        uint32_t nMax = 0;
+        HR_CHECK(hipMemcpyAsync(&nMax, total, 4, hipMemcpyDeviceToHost, st));
         HR_CHECK(hipStreamSynchronize(st));
-        HR_CHECK(hipMalloc(&out->nodes, sizeof(Node) * (size_t)(nOut ? nOut : 1)));
-        hipLaunchKernelGGL(k_emit_nodes, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, flags, out->nodes);
-        out->nNodes = (int)nOut;
+        if (nMax == 0) nMax = 1;
+        int *binOf = nullptr;
+        HR_CHECK(hipMalloc(&out->nodes, sizeof(Node4) * (size_t)nMax));
+        HR_CHECK(hipMalloc(&binOf, 4ull * nMax));
+        const int rootBin = 0;
+        const uint32_t one = 1;
+        HR_CHECK(hipMemcpyAsync(binOf, &rootBin, 4, hipMemcpyHostToDevice, st));
+        HR_CHECK(hipMemcpyAsync(total, &one, 4, hipMemcpyHostToDevice, st));
+        uint32_t levelStart = 0, levelEnd = 1;
+        for (int level = 0; level < 64 && levelEnd > levelStart; ++level) {
+            const uint32_t cnt = levelEnd - levelStart;
+            hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, total,
+                               out->nodes);
+            uint32_t newEnd = 0;
+            HR_CHECK(hipMemcpyAsync(&newEnd, total, 4, hipMemcpyDeviceToHost, st));
+            HR_CHECK(hipStreamSynchronize(st));
+            if (newEnd > nMax) {
+                rc = 4;
+                break;
+            }
+            levelStart = levelEnd;
+            levelEnd = newEnd;
+        }
+        hipFree(binOf);
+        out->nNodes = (int)levelEnd;
     }
     out->tris = sorted;
     HR_CHECK(hipStreamSynchronize(st));

@@ -78,7 +78,7 @@ struct hr_ctx {
     hr_scene_info info{};
 
     // scene (device)
-    Node *nodes = nullptr;
+    Node4 *nodes = nullptr;
     Tri *tris = nullptr;
     TriAttr *attrs = nullptr;
     TriAttrExt *attrsExt = nullptr;

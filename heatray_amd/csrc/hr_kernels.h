@@ -72,7 +72,7 @@ struct GeomDev {
 };
 
 struct BuildResult {
-    Node *nodes;
+    Node4 *nodes;
     Tri *tris;
     int32_t nNodes, rootLeafCount;
 };

@@ -161,24 +161,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     bool exhausted = false;          // wave-uniform: the global cursor ran past the end
     uint32_t nvC = 0, ntC = 0, nvA = 0, ntA = 0, nacc = 0;
 
-#define HR_PUSH(v)                          \
-    do {                                    \
-        if (sp < kStackLDS)                 \
-            stackLane[sp * 64] = (v);       \
-        else                                \
-            ovf[sp - kStackLDS] = (v);      \
-        ++sp;                               \
-    } while (0)
-#define HR_POP()                                                                   \
-    do {                                                                           \
-        if (sp == 0)                                                               \
-            cur = kSentinel;                                                       \
-        else {                                                                     \
-            --sp;                                                                  \
-            cur = (sp < kStackLDS) ? stackLane[sp * 64] : ovf[sp - kStackLDS];     \
-        }                                                                          \
-    } while (0)
-
     int pend = 0; // postponed leaf (a negative leaf reference) or 0: the lane keeps descending while a leaf waits
     for (;;) {
         // ---------------- refill idle lanes (persistent threads with dynamic fetch)
@@ -240,42 +222,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         const bool isAny = (segIdx & 1) != 0;
         // ---------------- one inner-node step for every lane that holds an inner node
         if (cur >= 0 && cur != kSentinel) {
-            const Node &n = S.nodes[cur];
-            const float4 na = n.a, nb = n.b, nc = n.c;
-            const int4 nd = n.d;
             if (STATS) {
                 if (isAny)
                     ++nvA;
                 else
                     ++nvC;
             }
-            float t0 = __builtin_fmaf(na.x, idx, -oix), t1 = __builtin_fmaf(na.w, idx, -oix);
-            float t2 = __builtin_fmaf(na.y, idy, -oiy), t3 = __builtin_fmaf(nb.x, idy, -oiy);
-            float t4 = __builtin_fmaf(na.z, idz, -oiz), t5 = __builtin_fmaf(nb.y, idz, -oiz);
-            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
-                                              __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
-            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
-                                              __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
-            t0 = __builtin_fmaf(nb.z, idx, -oix), t1 = __builtin_fmaf(nc.y, idx, -oix);
-            t2 = __builtin_fmaf(nb.w, idy, -oiy), t3 = __builtin_fmaf(nc.z, idy, -oiy);
-            t4 = __builtin_fmaf(nc.x, idz, -oiz), t5 = __builtin_fmaf(nc.w, idz, -oiz);
-            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
-                                              __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
-            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
-                                              __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            if (h0 && h1) {
-                const bool firstIs0 = tn0 <= tn1;
-                const int nearC = firstIs0 ? nd.x : nd.y, farC = firstIs0 ? nd.y : nd.x;
-                HR_PUSH(farC);
-                cur = nearC;
-            } else if (h0) {
-                cur = nd.x;
-            } else if (h1) {
-                cur = nd.y;
-            } else {
-                HR_POP();
-            }
+            const RayK rk{idx, idy, idz, oix, oiy, oiz};
+            nodeStep4(S.nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
         }
         // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
         // postponed it is blocked until the wave runs the triangle phase
@@ -350,8 +304,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
             item = 0xFFFFFFFFu;
         }
     }
-#undef HR_PUSH
-#undef HR_POP
 
     nacc = waveSum(nacc);
     if (lane == 0 && nacc) atomicAdd(&stats->accumulates, (unsigned long long)nacc);

@@ -27,6 +27,81 @@ struct HitRec {
     float t, u, v;
 };
 
+// Per-ray constants of the slab test: 1/d and o/d.
+struct RayK {
+    float idx, idy, idz, oix, oiy, oiz;
+};
+
+#define HR_PUSH(v)                          \
+    do {                                    \
+        if (sp < kStackLDS)                 \
+            stackLane[sp * 64] = (v);       \
+        else                                \
+            ovf[sp - kStackLDS] = (v);      \
+        ++sp;                               \
+    } while (0)
+#define HR_POP()                                                                   \
+    do {                                                                           \
+        if (sp == 0)                                                               \
+            cur = kSentinel;                                                       \
+        else {                                                                     \
+            --sp;                                                                  \
+            cur = (sp < kStackLDS) ? stackLane[sp * 64] : ovf[sp - kStackLDS];     \
+        }                                                                          \
+    } while (0)
+
+HRD uint32_t byteOf(uint32_t x, int c) { return (x >> (8 * c)) & 0xFFu; } // -> v_cvt_f32_ubyteN when converted to float
+HRD void cswap(uint32_t &a, uint32_t &b)
+{
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo, b = hi;
+}
+
+// One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that
+// is hit and push the others farthest first (so the nearer one pops first); pop when nothing is hit.
+HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim)
+{
+    const Node4 &n = nodes[cur];
+    const float4 a = n.a;
+    const int4 refs = n.b;
+    const uint4 qc = n.c, qd = n.d;
+    const uint32_t eb = __float_as_uint(a.w);
+    // t = (origin + q * scale - o) / d = q * (scale / d) + (origin / d - o / d)
+    const float bx = __uint_as_float((eb & 0xFFu) << 23) * rk.idx;
+    const float by = __uint_as_float(((eb >> 8) & 0xFFu) << 23) * rk.idy;
+    const float bz = __uint_as_float(((eb >> 16) & 0xFFu) << 23) * rk.idz;
+    const float ax = __builtin_fmaf(a.x, rk.idx, -rk.oix), ay = __builtin_fmaf(a.y, rk.idy, -rk.oiy), az = __builtin_fmaf(a.z, rk.idz, -rk.oiz);
+    const int rr[4] = {refs.x, refs.y, refs.z, refs.w};
+    uint32_t key[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float t0 = __builtin_fmaf((float)byteOf(qc.x, c), bx, ax), t1 = __builtin_fmaf((float)byteOf(qc.w, c), bx, ax);
+        const float t2 = __builtin_fmaf((float)byteOf(qc.y, c), by, ay), t3 = __builtin_fmaf((float)byteOf(qd.x, c), by, ay);
+        const float t4 = __builtin_fmaf((float)byteOf(qc.z, c), bz, az), t5 = __builtin_fmaf((float)byteOf(qd.y, c), bz, az);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
+                                         __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
+                                         __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
+        // entry distance (>= tmin >= 0, so its bits order like the value) with the child slot in the two low bits
+        key[c] = (tn <= tf && rr[c] != kEmptyChild) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+    }
+    cswap(key[0], key[1]), cswap(key[2], key[3]), cswap(key[0], key[2]), cswap(key[1], key[3]), cswap(key[1], key[2]);
+#pragma unroll
+    for (int j = 3; j >= 1; --j) {
+        if (key[j] != 0xFFFFFFFFu) {
+            const uint32_t sl = key[j] & 3u;
+            const int ref = (sl & 2u) ? ((sl & 1u) ? rr[3] : rr[2]) : ((sl & 1u) ? rr[1] : rr[0]);
+            HR_PUSH(ref);
+        }
+    }
+    if (key[0] != 0xFFFFFFFFu) {
+        const uint32_t sl = key[0] & 3u;
+        cur = (sl & 2u) ? ((sl & 1u) ? rr[3] : rr[2]) : ((sl & 1u) ? rr[1] : rr[0]);
+    } else {
+        HR_POP();
+    }
+}
+
 // Reciprocal for the slab test only (never for the hit): no infinities / NaNs enter the box test.
 HRD float safeInv(float d)
 {
@@ -73,59 +148,12 @@ HRD void traverse(const SceneDev &S, v3 o, v3 d, float tmin, float tmax, uint32_
     const float oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
     float tlim = tmax; // shrinks to the closest hit so far (closest-hit rays only)
 
-#define HR_PUSH(v)                          \
-    do {                                    \
-        if (sp < kStackLDS)                 \
-            stackLane[sp * 64] = (v);       \
-        else                                \
-            ovf[sp - kStackLDS] = (v);      \
-        ++sp;                               \
-    } while (0)
-#define HR_POP()                                                                   \
-    do {                                                                           \
-        if (sp == 0)                                                               \
-            cur = kSentinel;                                                       \
-        else {                                                                     \
-            --sp;                                                                  \
-            cur = (sp < kStackLDS) ? stackLane[sp * 64] : ovf[sp - kStackLDS];     \
-        }                                                                          \
-    } while (0)
-
+    const RayK rk{idx, idy, idz, oix, oiy, oiz};
     while (cur != kSentinel) {
         // ---- inner nodes: descend until this lane holds a leaf (cur < 0) or runs out of work
         while (cur >= 0 && cur != kSentinel) {
-            const Node &n = S.nodes[cur];
-            const float4 na = n.a, nb = n.b, nc = n.c;
-            const int4 nd = n.d;
             if (STATS) ++nodeVisits;
-            // slab test of both children; t = plane * (1/d) - o * (1/d)
-            float t0 = __builtin_fmaf(na.x, idx, -oix), t1 = __builtin_fmaf(na.w, idx, -oix);
-            float t2 = __builtin_fmaf(na.y, idy, -oiy), t3 = __builtin_fmaf(nb.x, idy, -oiy);
-            float t4 = __builtin_fmaf(na.z, idz, -oiz), t5 = __builtin_fmaf(nb.y, idz, -oiz);
-            float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
-                                        __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
-            float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
-                                        __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
-            t0 = __builtin_fmaf(nb.z, idx, -oix), t1 = __builtin_fmaf(nc.y, idx, -oix);
-            t2 = __builtin_fmaf(nb.w, idy, -oiy), t3 = __builtin_fmaf(nc.z, idy, -oiy);
-            t4 = __builtin_fmaf(nc.x, idz, -oiz), t5 = __builtin_fmaf(nc.w, idz, -oiz);
-            float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
-                                        __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
-            float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
-                                        __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            if (h0 && h1) {
-                const bool firstIs0 = tn0 <= tn1;
-                const int nearC = firstIs0 ? nd.x : nd.y, farC = firstIs0 ? nd.y : nd.x;
-                HR_PUSH(farC);
-                cur = nearC;
-            } else if (h0) {
-                cur = nd.x;
-            } else if (h1) {
-                cur = nd.y;
-            } else {
-                HR_POP();
-            }
+            nodeStep4(S.nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
         }
         // ---- leaf: 1..4 triangles
         if (cur < 0) {
@@ -172,8 +200,6 @@ HRD void traverse(const SceneDev &S, v3 o, v3 d, float tmin, float tmax, uint32_
             HR_POP();
         }
     }
-#undef HR_PUSH
-#undef HR_POP
 }
 
 } // namespace hr

@@ -7,13 +7,19 @@
 namespace hr {
 
 // ---- acceleration structure -------------------------------------------------------------------
-// Binary BVH node holding BOTH child boxes: one 64-byte, 64-byte-aligned record = four dwordx4 loads.
-//   a = (lo0.x lo0.y lo0.z hi0.x)  b = (hi0.y hi0.z lo1.x lo1.y)  c = (lo1.z hi1.x hi1.y hi1.z)
-//   d = (child0, child1, -, -)   child >= 0: node index; child < 0: leaf ~(first | (count-1) << 28)
-struct alignas(64) Node {
-    float4 a, b, c;
-    int4 d;
+// 4-wide BVH node, child boxes quantised to 8 bits per plane against the node's own box: one 64-byte,
+// 64-byte-aligned record = four dwordx4 loads for FOUR child boxes (16 B per child instead of 32 B).
+//   a = (origin.x, origin.y, origin.z, exponent bits ex | ey << 8 | ez << 16)   scale_k = as_float(e_k << 23)
+//   b = child references c0..c3: >= 0 node index; < 0 leaf ~(first | (count-1) << 28); kEmptyChild = no child
+//   c = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   byte j of each dword belongs to child j
+//   d = (qhi.y[4], qhi.z[4], -, -)
+// child box = origin + q * scale, with qlo rounded down and qhi rounded up (conservative).
+struct alignas(64) Node4 {
+    float4 a;
+    int4 b;
+    uint4 c, d;
 };
+static const int kEmptyChild = 0x7FFFFFFF;
 
 // World-space triangle in BVH leaf order, 48 bytes = three dwordx4 loads:
 //   p = (v0.x v0.y v0.z e1.x)  q = (e1.y e1.z e2.x e2.y)  r = (e2.z, prim id, flags, -)
@@ -64,7 +70,7 @@ enum MissKind { MISS_NONE = 0, MISS_ENV = 1, MISS_DIR = 2, MISS_POINT = 3, MISS_
 
 // ---- per-scene constant block (device copy) ---------------------------------------------------
 struct SceneDev {
-    const Node *nodes;
+    const Node4 *nodes;
     const Tri *tris;
     const TriAttr *attrs;
     const TriAttrExt *attrsExt; // may be null
