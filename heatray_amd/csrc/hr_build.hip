@@ -17,7 +17,6 @@
 
 namespace hr {
 
-static const int kLeafMax = 4;
 
 #define HR_CHECK(expr)                  \
     do {                                \
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(256) void k_refit_round(const KNode *__restrict__ n
     stamp[i] = round;
 }
 
-__global__ __launch_bounds__(256) void k_flag_internal(const KNode *__restrict__ nodes, int nInternal, uint32_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void k_flag_internal(const KNode *__restrict__ nodes, int nInternal, int kLeafMax, uint32_t *__restrict__ flags)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nInternal) return;
@@ -354,7 +353,7 @@ HRD uint32_t quantExponent(float ext)
 
 __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ knodes, const Box6 *__restrict__ leafBox,
                                                    const Box6 *__restrict__ nodeBox, int *__restrict__ binOf, uint32_t levelStart,
-                                                   uint32_t levelEnd, uint32_t *__restrict__ counter, Node4 *__restrict__ out)
+                                                   uint32_t levelEnd, int kLeafMax, uint32_t *__restrict__ counter, Node4 *__restrict__ out)
 {
     const uint32_t i = levelStart + blockIdx.x * 256 + threadIdx.x;
     if (i >= levelEnd) return;
@@ -432,7 +431,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
     out[i] = nd;
 }
 
-int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, BuildResult *out)
+int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, int kLeafMax, BuildResult *out)
 {
     out->nodes = nullptr, out->tris = nullptr, out->nNodes = 0, out->rootLeafCount = 0;
     if (n == 0) return 0;
@@ -491,7 +490,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         }
         if (rootStamp == 0) rc = 3;
         // upper bound of the 4-wide node count: binary nodes with more than kLeafMax triangles
-        hipLaunchKernelGGL(k_flag_internal, dim3(gi), dim3(256), 0, st, knodes, nInternal, flags);
+        hipLaunchKernelGGL(k_flag_internal, dim3(gi), dim3(256), 0, st, knodes, nInternal, kLeafMax, flags);
         hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, flags, (uint32_t)nInternal, total);
         uint32_t nMax = 0;
         HR_CHECK(hipMemcpyAsync(&nMax, total, 4, hipMemcpyDeviceToHost, st));
@@ -507,8 +506,8 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         uint32_t levelStart = 0, levelEnd = 1;
         for (int level = 0; level < 64 && levelEnd > levelStart; ++level) {
             const uint32_t cnt = levelEnd - levelStart;
-            hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, total,
-                               out->nodes);
+            hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, kLeafMax,
+                               total, out->nodes);
             uint32_t newEnd = 0;
             HR_CHECK(hipMemcpyAsync(&newEnd, total, 4, hipMemcpyDeviceToHost, st));
             HR_CHECK(hipStreamSynchronize(st));

@@ -6,6 +6,7 @@
 #include "hr_kernels.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -142,7 +143,9 @@ struct hr_ctx {
     }
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
-    LaunchCfg cfg() const { return LaunchCfg{stream, numCUs, 8, 8, collectStats}; }
+    // tuning knobs (defaults measured on MI355X; HR_TUNE="leaf=1,tri=4,refill=8,blocks=8,depth=12" overrides for experiments)
+    int tuneLeaf = 1, tuneTri = 4, tuneRefill = 8, tuneBlocks = 8, tuneDepth = kMaxSegs;
+    LaunchCfg cfg() const { return LaunchCfg{stream, numCUs, tuneBlocks, 8, collectStats}; }
 };
 
 #define FAIL(ctx, code, msg)  \
@@ -226,13 +229,22 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         return HR_ERR_DEVICE;
     }
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char *t = getenv("HR_TUNE")) {
+        auto get = [&](const char *key, int &dst) {
+            const char *p = strstr(t, key);
+            if (p) dst = atoi(p + strlen(key));
+        };
+        get("leaf=", c->tuneLeaf), get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
+        if (c->tuneLeaf < 1 || c->tuneLeaf > 4) c->tuneLeaf = 1;
+        if (c->tuneDepth < 1 || c->tuneDepth > kMaxSegs) c->tuneDepth = kMaxSegs;
+    }
     if (hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess || hipMalloc(&c->dTables, sizeof(StepTable) * kTableRing) != hipSuccess ||
-        hipMalloc(&c->dStats, sizeof(Stats)) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess ||
+        hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess ||
         hipMalloc(&c->dZero, 64) != hipSuccess) {
         delete c;
         return HR_ERR_DEVICE;
     }
-    hipMemset(c->dStats, 0, sizeof(Stats));
+    hipMemset(c->dStats, 0, sizeof(Stats) * kStatSlots);
     hipMemset(c->dZero, 0, 64);
     *out = c;
     return HR_OK;
@@ -483,7 +495,7 @@ int hr_scene_commit(hr_ctx *c)
         const float diag = sqrtf(ex * ex + ey * ey + ez * ez);
         const float pad = 1e-5f * diag;
         BuildResult br{};
-        const int rc = buildLBVH(c->stream, trisPrim, nTris, lo, hi, pad, &br);
+        const int rc = buildLBVH(c->stream, trisPrim, nTris, lo, hi, pad, c->tuneLeaf, &br);
         hipFree(dF), hipFree(dI), hipFree(dG), hipFree(trisPrim);
         if (rc != 0) {
             hipFree(br.nodes), hipFree(br.tris);
@@ -740,7 +752,7 @@ int hr_clear(hr_ctx *c)
     int rc = drainPipeline(c);
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->fb(), 0, (size_t)c->W * c->H * 4 * sizeof(float), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats) * kStatSlots, c->stream));
     c->drainTimes();
     for (int k = 0; k < HR_KERNEL_COUNT; ++k) c->kernelMs[k] = 0.0f, c->kernelLaunches[k] = 0;
     return HR_OK;
@@ -813,6 +825,7 @@ static int macroStep(hr_ctx *c, const hr_pass_params *inject)
         for (int b = a; b > 0 && c->slots[order[b]].order < c->slots[order[b - 1]].order; --b) std::swap(order[b], order[b - 1]);
     if (n == 0) return HR_OK;
     tbl.nSeg = n;
+    tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
     int injectedSeg = -1;
     for (int k = 0; k < n; ++k) {
         hr_ctx::PassSlot &ps = c->slots[order[k]];
@@ -882,7 +895,7 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     if (c->frame.nOwnedTiles == 0) return HR_OK;
     // pipeline depth: a pass occupies depth+2 macro steps; passes that may need extra stages run alone
     int depth = c->hasPassthrough ? 1 : pp->max_ray_depth + 2;
-    if (depth > kMaxSegs) depth = kMaxSegs;
+    if (depth > c->tuneDepth) depth = c->tuneDepth;
     if (depth > c->maxSlots) depth = c->maxSlots;
     while (activePasses(c) >= depth) {
         rc = macroStep(c, nullptr);
@@ -908,9 +921,15 @@ int hr_get_stats(hr_ctx *c, hr_pass_stats *out)
         int rc = drainPipeline(c);
         if (rc) return rc;
     }
-    Stats s;
-    HIP_TRY(c, hipMemcpyAsync(&s, c->dStats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream));
-    QUIESCE(c);
+    std::vector<Stats> parts(kStatSlots);
+    HIP_TRY(c, hipMemcpyAsync(parts.data(), c->dStats, sizeof(Stats) * kStatSlots, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Stats s{};
+    for (const Stats &p : parts) {
+        s.paths += p.paths, s.raysClosest += p.raysClosest, s.raysAny += p.raysAny, s.shadedHits += p.shadedHits;
+        s.accumulates += p.accumulates, s.nodeVisits += p.nodeVisits, s.triTests += p.triTests;
+        s.nodeVisitsAny += p.nodeVisitsAny, s.triTestsAny += p.triTestsAny;
+    }
     std::memset(out, 0, sizeof(*out));
     out->paths = s.paths, out->rays_closest = s.raysClosest, out->rays_any = s.raysAny, out->shaded_hits = s.shadedHits;
     out->accumulates = s.accumulates, out->node_visits = s.nodeVisits, out->tri_tests = s.triTests;

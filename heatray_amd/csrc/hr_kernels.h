@@ -13,6 +13,9 @@ struct FrameDev {
 
 struct HitRec; // hr_trace.h
 
+// Device counters are kept in kStatSlots copies (a workgroup adds to slot blockIdx.x % kStatSlots) so that the adds of a
+// launch spread over many addresses instead of serialising on one; hr_get_stats sums the copies.
+static const int kStatSlots = 4096;
 struct Stats {
     unsigned long long paths, raysClosest, raysAny, shadedHits, accumulates, nodeVisits, triTests, nodeVisitsAny, triTestsAny;
 };
@@ -45,7 +48,8 @@ static const int kMaxSegs = 12;
 struct StepTable {
     uint32_t traceHead; // work cursor of the persistent trace kernel (reset with every table upload)
     int32_t nSeg;
-    int32_t pad[2];
+    int32_t refillLanes;   // refill a wave from the work pool once this many lanes are idle
+    int32_t triPhaseLanes; // run the triangle phase once this many lanes are blocked on a postponed leaf
     SegDev seg[kMaxSegs];
 };
 
@@ -81,7 +85,8 @@ struct BuildResult {
 void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t nTris, Tri *trisPrimOrder, TriAttr *attrs, TriAttrExt *ext,
                     uint32_t *boundsOrdered);
 // Full LBVH build from assembled triangles; allocates scratch internally; returns device arrays (hipMalloc).
-int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad, BuildResult *out);
+int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad, int leafMax,
+              BuildResult *out);
 
 void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, int radial, float2 *out);
 void launchMultiscatterLUT(hipStream_t st, const float2 *sobol4096, float *out128x128);

@@ -42,6 +42,29 @@ HRD uint32_t waveReserve(bool want, uint32_t *counter)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Block-level compaction: one global atomic per workgroup.  Every thread of the block must call it.
+// `scratch` is 2 + (blockDim/64) words of LDS.
+HRD uint32_t blockReserve(bool want, uint32_t *counter, uint32_t *scratch)
+{
+    const uint32_t lane = laneId(), wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const unsigned long long mask = __ballot(want);
+    if (lane == 0) scratch[2 + wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < nWaves; ++w) {
+            const uint32_t c = scratch[2 + w];
+            scratch[2 + w] = tot; // exclusive prefix
+            tot += c;
+        }
+        scratch[0] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = scratch[0] + scratch[2 + wave] + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    __syncthreads(); // scratch may be reused by the next call
+    return slot;
+}
+
 HRD uint32_t waveSum(uint32_t v)
 {
 #pragma unroll
@@ -78,13 +101,16 @@ HRD bool ownedPixel(const FrameDev &fr, uint32_t gid, int &x, int &y)
 }
 
 // ------------------------------------------------------------------------------------------ raygen
-__global__ __launch_bounds__(kBlock) void k_raygen(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, int segIdx, FrameDev fr,
-                                                   Stats *stats)
+static const int kRaygenBlock = 1024; // one queue-slot reservation (global atomic) per 1024 pixels
+__global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, int segIdx, FrameDev fr,
+                                                         Stats *stats)
 {
+    __shared__ uint32_t scratch[2 + kRaygenBlock / 64];
     const SceneDev &S = *Sp;
+    stats += blockIdx.x & (kStatSlots - 1);
     const SegDev &seg = tbl->seg[segIdx];
     int x = 0, y = 0;
-    const bool inFrame = ownedPixel(fr, blockIdx.x * kBlock + threadIdx.x, x, y);
+    const bool inFrame = ownedPixel(fr, blockIdx.x * kRaygenBlock + threadIdx.x, x, y);
     const uint32_t pixel = (uint32_t)(y * fr.W + x);
     Ray r;
     r.valid = false;
@@ -92,7 +118,7 @@ __global__ __launch_bounds__(kBlock) void k_raygen(const SceneDev *__restrict__ 
     if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
     // the pass's sample starts at zero; perspective.rlsl:60 accumulate(vec4(0,0,0,1)) for sampled pixels
     if (inFrame) reinterpret_cast<float4 *>(seg.passbuf)[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
-    const uint32_t slot = waveReserve(active, seg.qCountIn);
+    const uint32_t slot = blockReserve(active, seg.qCountIn, scratch);
     if (active) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
     const uint32_t n = waveSum(active ? 1u : 0u);
     if (laneId() == 0 && n) atomicAdd(&stats->paths, (unsigned long long)n);
@@ -136,12 +162,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     __shared__ int stack[kWavesPerBlock][kStackLDS][64];
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
     const SceneDev &S = *Sp;
+    stats += blockIdx.x & (kStatSlots - 1);
     buildSegStarts(tbl, segStart, false);
     const int nSeg2 = 2 * tbl->nSeg;
     const uint32_t total = segStart[nSeg2];
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
     int *stackLane = &stack[wave][0][lane];
     const unsigned long long ltMask = (1ull << lane) - 1ull;
+    const int kRefill = tbl->refillLanes, kTriPhase = tbl->triPhaseLanes;
 
     // ---- per-lane traversal state (one ray per lane, refilled from the work pool when a lane finishes)
     int cur = kSentinel, sp = 0;
@@ -167,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         bool idle = (item == 0xFFFFFFFFu);
         unsigned long long idleMask = __ballot(idle);
         int nIdle = __popcll(idleMask);
-        if (!exhausted && (nIdle >= kRefillLanes || nIdle == 64)) {
+        if (!exhausted && (nIdle >= kRefill || nIdle == 64)) {
             for (int round = 0; round < 2 && nIdle > 0; ++round) {
                 if (poolLo == poolHi) { // reserve another chunk of the global index space
                     uint32_t base = 0;
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         // ---------------- triangle phase: run it once enough lanes wait for it, or when nobody can descend any more
         const unsigned long long blockedMask = __ballot(pend != 0 && (cur < 0 || cur == kSentinel));
         const unsigned long long nodeMask = __ballot(cur >= 0 && cur != kSentinel);
-        if (blockedMask != 0ull && (__popcll(blockedMask) >= kTriPhaseLanes || nodeMask == 0ull)) {
+        if (blockedMask != 0ull && (__popcll(blockedMask) >= kTriPhase || nodeMask == 0ull)) {
             if (pend != 0) {
                 const int enc = ~pend;
                 const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
@@ -328,19 +356,23 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
 }
 
 // ------------------------------------------------------------------------------------------- shade
-__global__ __launch_bounds__(kBlock) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
+static const int kShadeBlock = 512; // queue slots are reserved once per workgroup and pass (fewer same-address atomics)
+__global__ __launch_bounds__(kShadeBlock) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
+    __shared__ uint32_t scratch[2 + kShadeBlock / 64];
+    __shared__ int segRange[2];
     const SceneDev &S = *Sp;
+    stats += blockIdx.x & (kStatSlots - 1);
     buildSegStarts(tbl, segStart, true);
     const int nSeg = tbl->nSeg;
     const uint32_t total = segStart[2 * nSeg];
     const uint32_t lane = laneId();
     uint32_t nShaded = 0, nAccum = 0;
-    // Waves take 64 consecutive work items; a batch may straddle two passes, so the compaction ballots are
-    // done per pass.  The trip count is wave-uniform.
-    for (uint32_t base = (blockIdx.x * kBlock + (threadIdx.x & ~63u)); base < total; base += gridDim.x * kBlock) {
-        const uint32_t i = base + lane;
+    // Workgroups take kShadeBlock consecutive work items; a batch may straddle passes, so the compaction is done per
+    // pass present in the batch.  The trip count is uniform over the workgroup (barriers inside).
+    for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock) {
+        const uint32_t i = base + threadIdx.x;
         const bool live = i < total;
         int sI = 0;
         if (live)
@@ -387,21 +419,26 @@ __global__ __launch_bounds__(kBlock) void k_shade(const SceneDev *__restrict__ S
             nAccum += sh.nAccum;
         }
         // per-pass compaction of the emitted rays
-        // work items ascend with the lane index, so the passes present in this batch are a contiguous range
-        const int sLo = __shfl(sI, 0);
-        const int sHi = __shfl(sI, __popcll(__ballot(live)) - 1);
+        // work items ascend with the thread index, so the passes present in this batch are a contiguous range
+        if (threadIdx.x == 0) segRange[0] = sI;
+        {
+            const uint32_t lastLive = (total - base < (uint32_t)kShadeBlock ? total - base : (uint32_t)kShadeBlock) - 1u;
+            if (threadIdx.x == lastLive) segRange[1] = sI;
+        }
+        __syncthreads();
+        const int sLo = segRange[0], sHi = segRange[1];
         for (int s = sLo; s <= sHi; ++s) {
             const SegDev &sg = tbl->seg[s];
             const bool mine = live && sI == s;
             const bool wantS = mine && nee.valid;
-            const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
+            const uint32_t sSlot = blockReserve(wantS, sg.sCountOut, scratch);
             if (wantS) {
                 sg.sq.A[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
                 sg.sq.B[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
                 sg.sq.C[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
             }
             const bool wantQ = mine && next.valid;
-            const uint32_t qSlot = waveReserve(wantQ, sg.qCountOut);
+            const uint32_t qSlot = blockReserve(wantQ, sg.qCountOut, scratch);
             if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
         }
     }
@@ -449,7 +486,7 @@ void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl,
 {
     const int threads = ownedThreads(fr);
     if (threads <= 0) return;
-    hipLaunchKernelGGL(k_raygen, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, S, tbl, segIdx, fr, stats);
+    hipLaunchKernelGGL(k_raygen, dim3((threads + kRaygenBlock - 1) / kRaygenBlock), dim3(kRaygenBlock), 0, cfg.stream, S, tbl, segIdx, fr, stats);
 }
 
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbuf)
@@ -471,7 +508,7 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, StepTable *tbl, Stats 
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats)
 {
     const int grid = cfg.numCUs * cfg.shadeBlocksPerCU;
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, cfg.stream, S, tbl, stats);
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
 }
 
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,

@@ -15,8 +15,8 @@
 
 namespace hr {
 
-static const int kStackLDS = 24;   // entries per lane kept in LDS
-static const int kStackOvf = 40;   // private overflow (LBVH depth <= 30 + 28 index bits < 64)
+static const int kStackLDS = 16;   // entries per lane kept in LDS
+static const int kStackOvf = 80;   // private overflow: a 4-wide node pushes up to 3 entries per level, binary depth <= 58 -> <= 29 levels
 static const int kSentinel = 0x7FFFFFFF;
 static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
 static const int kFetchChunk = 256; // work items a wave reserves per global atomic
@@ -72,16 +72,19 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
     const float bz = __uint_as_float(((eb >> 16) & 0xFFu) << 23) * rk.idz;
     const float ax = __builtin_fmaf(a.x, rk.idx, -rk.oix), ay = __builtin_fmaf(a.y, rk.idy, -rk.oiy), az = __builtin_fmaf(a.z, rk.idz, -rk.oiz);
     const int rr[4] = {refs.x, refs.y, refs.z, refs.w};
+    // the sign of the direction decides which quantised plane is the entry and which the exit plane of each slab
+    // (chosen once per node on whole dwords: byte j belongs to child j)
+    const uint32_t nX = rk.idx < 0.0f ? qc.w : qc.x, fX = rk.idx < 0.0f ? qc.x : qc.w;
+    const uint32_t nY = rk.idy < 0.0f ? qd.x : qc.y, fY = rk.idy < 0.0f ? qc.y : qd.x;
+    const uint32_t nZ = rk.idz < 0.0f ? qd.y : qc.z, fZ = rk.idz < 0.0f ? qc.z : qd.y;
     uint32_t key[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float t0 = __builtin_fmaf((float)byteOf(qc.x, c), bx, ax), t1 = __builtin_fmaf((float)byteOf(qc.w, c), bx, ax);
-        const float t2 = __builtin_fmaf((float)byteOf(qc.y, c), by, ay), t3 = __builtin_fmaf((float)byteOf(qd.x, c), by, ay);
-        const float t4 = __builtin_fmaf((float)byteOf(qc.z, c), bz, az), t5 = __builtin_fmaf((float)byteOf(qd.y, c), bz, az);
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0, t1), __builtin_fminf(t2, t3)),
-                                         __builtin_fmaxf(__builtin_fminf(t4, t5), tmin));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0, t1), __builtin_fmaxf(t2, t3)),
-                                         __builtin_fminf(__builtin_fmaxf(t4, t5), tlim));
+        const float tnx = __builtin_fmaf((float)byteOf(nX, c), bx, ax), tfx = __builtin_fmaf((float)byteOf(fX, c), bx, ax);
+        const float tny = __builtin_fmaf((float)byteOf(nY, c), by, ay), tfy = __builtin_fmaf((float)byteOf(fY, c), by, ay);
+        const float tnz = __builtin_fmaf((float)byteOf(nZ, c), bz, az), tfz = __builtin_fmaf((float)byteOf(fZ, c), bz, az);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
         // entry distance (>= tmin >= 0, so its bits order like the value) with the child slot in the two low bits
         key[c] = (tn <= tf && rr[c] != kEmptyChild) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
     }
