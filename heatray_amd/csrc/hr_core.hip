@@ -850,7 +850,7 @@ static int macroStep(hr_ctx *c, const hr_pass_params *inject)
         c->timeEnd();
     }
     c->timeBegin(HR_KERNEL_TRACE);
-    launchTrace(cfg, c->dScene, dTbl, c->dStats);
+    launchTrace(cfg, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
     c->timeEnd();
     c->timeBegin(HR_KERNEL_SHADE);
     launchShade(cfg, c->dScene, dTbl, c->dStats);

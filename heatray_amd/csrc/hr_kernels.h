@@ -56,7 +56,7 @@ struct StepTable {
 // ---- hr_render.hip
 void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, int segIdx, const FrameDev &fr, Stats *stats);
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbuf);
-void launchTrace(const LaunchCfg &cfg, const SceneDev *S, StepTable *tbl, Stats *stats);
+void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,
                       int anyHit, hr_hit *out);

@@ -157,7 +157,8 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ Sp, StepTable *__restrict__ tbl, Stats *stats)
+__global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
+                                                  StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ int stack[kWavesPerBlock][kStackLDS][64];
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                     ++nvC;
             }
             const RayK rk{idx, idy, idz, oix, oiy, oiz};
-            nodeStep4(S.nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
+            nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny);
         }
         // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
         // postponed it is blocked until the wave runs the triangle phase
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                 const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
                 pend = 0;
                 for (int k = 0; k < count; ++k) {
-                    const Tri &tr = S.tris[first + k];
+                    const Tri &tr = tris[first + k];
                     const float4 tp = tr.p, tq = tr.q, trr = tr.r;
                     if (STATS) {
                         if (isAny)
@@ -496,13 +497,13 @@ void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbu
     hipLaunchKernelGGL(k_resolve, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, fr, passbuf);
 }
 
-void launchTrace(const LaunchCfg &cfg, const SceneDev *S, StepTable *tbl, Stats *stats)
+void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats)
 {
     const int grid = cfg.numCUs * cfg.traceBlocksPerCU;
     if (cfg.collectStats)
-        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, tbl, stats);
+        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
     else
-        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, tbl, stats);
+        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
 }
 
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats)

@@ -59,7 +59,8 @@ HRD void cswap(uint32_t &a, uint32_t &b)
 
 // One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that
 // is hit and push the others farthest first (so the nearer one pops first); pop when nothing is hit.
-HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim)
+HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim,
+                   bool anyHit = false)
 {
     const Node4 &n = nodes[cur];
     const float4 a = n.a;
@@ -88,7 +89,9 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
         // entry distance (>= tmin >= 0, so its bits order like the value) with the child slot in the two low bits
         key[c] = (tn <= tf && rr[c] != kEmptyChild) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
     }
+    // occlusion rays stop at the first hit whatever the order; the sort only moves the misses (0xFFFFFFFF) to the end either way
     cswap(key[0], key[1]), cswap(key[2], key[3]), cswap(key[0], key[2]), cswap(key[1], key[3]), cswap(key[1], key[2]);
+    (void)anyHit;
 #pragma unroll
     for (int j = 3; j >= 1; --j) {
         if (key[j] != 0xFFFFFFFFu) {
