@@ -54,41 +54,53 @@ def build_scene(name, width, height, passes):
 
 
 def cpu_baseline(sc, budget_s, lut):
-    """The CPU oracle (kind "port") on the host cores, on a bounded sample: a 1/16 interleaved tile shard
-    of the same frame, as many passes as fit the time budget."""
+    """The CPU oracle (kind "port") on the host cores, on a bounded sample of the same workload: an interleaved
+    1/world shard of the frame's 32x32 tiles, rendered for as many passes as fit the time budget (the shard is
+    sized from a one-pass probe so that the leg takes about `budget_s` seconds)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     n_tiles = ((sc.width + 31) // 32) * ((sc.height + 31) // 32)
-    world = max(1, min(16, n_tiles))
-    eng = oracle_lib.engine(rank=0, world=world, tile_size=32)
-    t0 = time.perf_counter()
-    sc.apply(eng, lut=lut)
-    build_s = time.perf_counter() - t0
-    passes, t0 = 0, time.perf_counter()
-    while True:
-        eng.render_pass(sc.options.pass_params(passes))
-        passes += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or passes >= sc.options.max_render_passes:
-            break
-    st = eng.stats()
-    rays = st.rays_closest + st.rays_any
     cores = os.cpu_count() or 1
-    v_closest = (st.node_visits - st.node_visits_any) / max(st.rays_closest, 1)
-    t_closest = (st.tri_tests - st.tri_tests_any) / max(st.rays_closest, 1)
+    max_passes = sc.options.max_render_passes
+
+    def run(world, budget):
+        eng = oracle_lib.engine(rank=0, world=world, tile_size=32)
+        t0 = time.perf_counter()
+        sc.apply(eng, lut=lut)
+        build_s = time.perf_counter() - t0
+        eng.render_pass(sc.options.pass_params(0))  # untimed: first touch of the BVH
+        eng.clear()
+        passes, t0 = 0, time.perf_counter()
+        while True:
+            eng.render_pass(sc.options.pass_params(passes))
+            passes += 1
+            el = time.perf_counter() - t0
+            if el > budget or passes >= max_passes:
+                break
+        return eng.stats(), passes, el, build_s
+
+    world = max(1, min(64, n_tiles))
+    st, passes, el, build_s = run(world, 1.0)  # probe
+    per_pass_full = el / passes * world
+    # shard so that max_passes passes take about budget_s (at least 1/64, at most the whole frame)
+    world = int(max(1, min(64, round(per_pass_full * max_passes / max(budget_s, 1e-3)))))
+    st, passes, el, build_s = run(world, budget_s)
+    rays = st.rays_closest + st.rays_any
     return {
         "value": rays / el / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
         "sample": f"1/{world} of the frame's 32x32 tiles (interleaved), {passes} passes, {rays} rays in {el:.1f} s "
                   f"(+{build_s:.1f} s scene/BVH build), OpenMP over tiles on {cores} threads",
         "per_core": rays / el / 1e6 / cores,
-        "V_closest": v_closest, "T_closest": t_closest,
+        "V": (st.node_visits - st.node_visits_any) / max(st.rays_closest, 1),
+        "T": (st.tri_tests - st.tri_tests_any) / max(st.rays_closest, 1),
+        "V_any": st.node_visits_any / max(st.rays_any, 1), "T_any": st.tri_tests_any / max(st.rays_any, 1),
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=0)
@@ -163,30 +175,43 @@ def main():
         assert bool((a[owned] == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
         assert bool(torch.isfinite(fb).all())
 
-        # ---- V, T of the roofline model: one extra counted pass on this rank's shard (outside the timed region)
-        V = T = None
+        # ---- cpu_baseline leg (N = 1 only): also yields V, T of the roofline model measured by the oracle on the spec BVH
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            lut, _ = eng.generate_multiscatter_lut()
+            cpu = cpu_baseline(sc, args.cpu_seconds, lut)
+
+        # ---- the product's own traversal counters (4-wide quantised BVH), one extra counted pass outside the timed region
+        gpu_counts = None
         if not args.no_stats_pass:
             se = core.create_engine(device_id=local_rank, rank=rank, world=world, tile_size=32, stream=stream, collect_stats=True)
             sc.apply(se)
             se.render_pass(sc.options.pass_params(args.warmup))
             ss = se.stats()
-            V = (ss.node_visits - ss.node_visits_any) / max(ss.rays_closest, 1)
-            T = (ss.tri_tests - ss.tri_tests_any) / max(ss.rays_closest, 1)
-            V_any = ss.node_visits_any / max(ss.rays_any, 1)
-            T_any = ss.tri_tests_any / max(ss.rays_any, 1)
-            H = ss.shaded_hits / max(ss.rays_closest + ss.rays_any, 1)
-            A = ss.accumulates / max(ss.rays_closest + ss.rays_any, 1)
+            gpu_counts = {"node4_visits_per_closest_ray": (ss.node_visits - ss.node_visits_any) / max(ss.rays_closest, 1),
+                          "tri_tests_per_closest_ray": (ss.tri_tests - ss.tri_tests_any) / max(ss.rays_closest, 1),
+                          "node4_visits_per_occlusion_ray": ss.node_visits_any / max(ss.rays_any, 1),
+                          "tri_tests_per_occlusion_ray": ss.tri_tests_any / max(ss.rays_any, 1),
+                          "shaded_hit_fraction_H": ss.shaded_hits / max(ss.rays_closest + ss.rays_any, 1),
+                          "accumulate_fraction_A": ss.accumulates / max(ss.rays_closest + ss.rays_any, 1)}
             se.close()
 
         # ---- roofline of the dominant kernel: k_trace (closest-hit + occlusion traversal in one launch).
-        # Algorithmic bytes per ray in that kernel: 48 B ray read (origin/tmax, dir, src prim)
-        # + 16 B result (hit record, or the pass-buffer RMW of an unoccluded occlusion ray)
-        # + 64 B per BVH node visited + 48 B per triangle tested.
+        # ALGORITHMIC bytes per ray (SURVEY §8d / DESIGN.md §Roofline), defined on the spec BVH (binary LBVH, two-box
+        # 64-byte nodes, <= 4 triangles per leaf) so the figure does not depend on this implementation's tree:
+        #   48 B ray read + 16 B result + 64 B x V (nodes visited) + 48 B x T (triangles tested),
+        # with V and T measured by the CPU oracle on the same scene (cpu_baseline leg); the committed figures of
+        # profiles/vt_spec.json are used when that leg is skipped.
         ms_trace, n_trace = kt["trace"]
         roofline = None
-        if V is not None and n_trace:
-            bytes_closest = 48.0 + 16.0 + 64.0 * V + 48.0 * T
-            bytes_any = 48.0 + 16.0 + 64.0 * V_any + 48.0 * T_any
+        vt = cpu
+        if vt is None:
+            vpath = os.path.join(ROOT, "profiles", "vt_spec.json")
+            if os.path.exists(vpath):
+                vt = json.load(open(vpath)).get(args.workload)
+        if vt is not None and n_trace:
+            bytes_closest = 48.0 + 16.0 + 64.0 * vt["V"] + 48.0 * vt["T"]
+            bytes_any = 48.0 + 16.0 + 64.0 * vt["V_any"] + 48.0 * vt["T_any"]
             total_bytes = bytes_closest * float(st.rays_closest) + bytes_any * float(st.rays_any)
             avg_ms = ms_trace / n_trace
             achieved = total_bytes / n_trace / (avg_ms * 1e-3) / 1e9
@@ -199,12 +224,8 @@ def main():
                         "algorithmic_bytes_per_launch": total_bytes / n_trace,
                         "algorithmic_bytes_per_closest_ray": bytes_closest, "algorithmic_bytes_per_occlusion_ray": bytes_any,
                         "rays_per_launch": float(st.rays_closest + st.rays_any) / n_trace,
-                        "V": V, "T": T, "V_any": V_any, "T_any": T_any}
-
-        cpu = None
-        if world == 1 and args.cpu_seconds > 0:
-            lut, _ = eng.generate_multiscatter_lut()
-            cpu = cpu_baseline(sc, args.cpu_seconds, lut)
+                        "V": vt["V"], "T": vt["T"], "V_any": vt["V_any"], "T_any": vt["T_any"],
+                        "vt_source": "cpu oracle, this run" if vt is cpu else "profiles/vt_spec.json"}
 
         mrays = total_rays / elapsed / 1e6
         out = {
@@ -221,7 +242,7 @@ def main():
             "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,
                       "rays_per_path": total_rays / max(total_paths, 1.0), "bvh_build_ms": info.build_ms,
                       "kernel_ms_rank0": {k: v[0] for k, v in kt.items()}, "kernel_launches_rank0": {k: v[1] for k, v in kt.items()},
-                      "shaded_hit_fraction_H": None if V is None else H, "accumulate_fraction_A": None if V is None else A},
+                      "gpu_traversal_counters": gpu_counts},
         }
         print(json.dumps(out))
     if world > 1:

@@ -24,6 +24,9 @@
 
 namespace hr {
 
+#ifndef HR_NODE_STEPS
+#define HR_NODE_STEPS 4 // inner-node steps per round of the trace loop
+#endif
 static const int kBlock = 256;
 static const int kWavesPerBlock = kBlock / 64;
 
@@ -249,22 +252,25 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         }
 
         const bool isAny = (segIdx & 1) != 0;
-        // ---------------- one inner-node step for every lane that holds an inner node
-        if (cur >= 0 && cur != kSentinel) {
-            if (STATS) {
-                if (isAny)
-                    ++nvA;
-                else
-                    ++nvC;
+        // ---------------- inner-node steps for every lane that holds an inner node
+#pragma unroll
+        for (int rep = 0; rep < HR_NODE_STEPS; ++rep) {
+            if (cur >= 0 && cur != kSentinel) {
+                if (STATS) {
+                    if (isAny)
+                        ++nvA;
+                    else
+                        ++nvC;
+                }
+                const RayK rk{idx, idy, idz, oix, oiy, oiz};
+                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny);
             }
-            const RayK rk{idx, idy, idz, oix, oiy, oiz};
-            nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny);
-        }
-        // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
-        // postponed it is blocked until the wave runs the triangle phase
-        if (cur < 0 && pend == 0) {
-            pend = cur;
-            HR_POP();
+            // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
+            // postponed it is blocked until the wave runs the triangle phase
+            if (cur < 0 && pend == 0) {
+                pend = cur;
+                HR_POP();
+            }
         }
         // ---------------- triangle phase: run it once enough lanes wait for it, or when nobody can descend any more
         const unsigned long long blockedMask = __ballot(pend != 0 && (cur < 0 || cur == kSentinel));

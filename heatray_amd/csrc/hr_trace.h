@@ -15,7 +15,7 @@
 
 namespace hr {
 
-static const int kStackLDS = 16;   // entries per lane kept in LDS
+static const int kStackLDS = 16;   // entries per lane kept in LDS (power of two)
 static const int kStackOvf = 80;   // private overflow: a 4-wide node pushes up to 3 entries per level, binary depth <= 58 -> <= 29 levels
 static const int kSentinel = 0x7FFFFFFF;
 static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
@@ -89,22 +89,39 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
         // entry distance (>= tmin >= 0, so its bits order like the value) with the child slot in the two low bits
         key[c] = (tn <= tf && rr[c] != kEmptyChild) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
     }
-    // occlusion rays stop at the first hit whatever the order; the sort only moves the misses (0xFFFFFFFF) to the end either way
+    // sorting network: ascending entry distance, misses (0xFFFFFFFF) last
     cswap(key[0], key[1]), cswap(key[2], key[3]), cswap(key[0], key[2]), cswap(key[1], key[3]), cswap(key[1], key[2]);
     (void)anyHit;
+    int ref[4];
 #pragma unroll
-    for (int j = 3; j >= 1; --j) {
-        if (key[j] != 0xFFFFFFFFu) {
-            const uint32_t sl = key[j] & 3u;
-            const int ref = (sl & 2u) ? ((sl & 1u) ? rr[3] : rr[2]) : ((sl & 1u) ? rr[1] : rr[0]);
-            HR_PUSH(ref);
-        }
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t sl = key[j] & 3u;
+        ref[j] = (sl & 2u) ? ((sl & 1u) ? rr[3] : rr[2]) : ((sl & 1u) ? rr[1] : rr[0]);
     }
-    if (key[0] != 0xFFFFFFFFu) {
-        const uint32_t sl = key[0] & 3u;
-        cur = (sl & 2u) ? ((sl & 1u) ? rr[3] : rr[2]) : ((sl & 1u) ? rr[1] : rr[0]);
+    if (sp <= kStackLDS - 3) {
+        // common case, branch-free: store the three farther children farthest first and advance the stack pointer only
+        // past the ones that were hit (hits are a prefix of the sorted order, so a skipped slot is simply overwritten)
+        stackLane[sp * 64] = ref[3];
+        sp += (key[3] != 0xFFFFFFFFu) ? 1 : 0;
+        stackLane[sp * 64] = ref[2];
+        sp += (key[2] != 0xFFFFFFFFu) ? 1 : 0;
+        stackLane[sp * 64] = ref[1];
+        sp += (key[1] != 0xFFFFFFFFu) ? 1 : 0;
+        const bool any = key[0] != 0xFFFFFFFFu;
+        const bool empty = !any && sp == 0;
+        sp -= (!any && sp > 0) ? 1 : 0;
+        const int popped = stackLane[(sp & (kStackLDS - 1)) * 64]; // sp <= kStackLDS: stays inside the LDS part (value unused when sp == kStackLDS)
+        cur = any ? ref[0] : (empty ? kSentinel : popped);
     } else {
-        HR_POP();
+        // deep stack: entries beyond kStackLDS live in the private overflow area
+#pragma unroll
+        for (int j = 3; j >= 1; --j)
+            if (key[j] != 0xFFFFFFFFu) HR_PUSH(ref[j]);
+        if (key[0] != 0xFFFFFFFFu) {
+            cur = ref[0];
+        } else {
+            HR_POP();
+        }
     }
 }
 
