@@ -1,0 +1,81 @@
+#include "EnvironmentLight.h"
+
+#if __has_include(<Utility/TextureLoader.h>)
+#include <Utility/TextureLoader.h> // the application's stb / FreeImage loader (untouched reference code)
+#define HR_HOST_HAS_TEXTURE_LOADER 1
+#endif
+
+#include <assert.h>
+#include <cmath>
+#include <stdio.h>
+
+EnvironmentLight::EnvironmentLight(const std::string_view name)
+: Light(name, Light::Type::kEnvironment)
+{
+}
+
+// EnvironmentLight.cpp:30-46 of the reference.
+void EnvironmentLight::changeImageSource(const std::string_view path, bool builtInMap)
+{
+    assert(!path.empty());
+    std::string fullPath = builtInMap ? std::string("Resources/Environments/") + std::string(path) : std::string(path);
+    if (m_textureSourcePath != fullPath) {
+#if defined(HR_HOST_HAS_TEXTURE_LOADER)
+        m_texture = util::loadTexture(fullPath);
+        m_textureSourcePath = fullPath;
+#else
+        fprintf(stderr, "EnvironmentLight: no image loader in this build, cannot load %s (use setTexture)\n", fullPath.c_str());
+#endif
+    }
+}
+
+void EnvironmentLight::setTexture(std::shared_ptr<openrl::Texture> texture, const std::string_view sourceName)
+{
+    m_texture = std::move(texture);
+    m_textureSourcePath = std::string(sourceName);
+}
+
+// EnvironmentLight.cpp:48-72 of the reference: a 1x1 RGB texture.
+void EnvironmentLight::enableSolidColor(const glm::vec3& color)
+{
+    if ((m_textureSourcePath != SOLID_COLOR) || (m_solidColor != color)) {
+        openrl::Texture::Descriptor desc;
+        desc.dataType = RL_FLOAT;
+        desc.format = RL_RGB;
+        desc.internalFormat = RL_RGB;
+        desc.width = 1;
+        desc.height = 1;
+
+        openrl::Texture::Sampler sampler;
+        sampler.magFilter = RL_LINEAR;
+        sampler.minFilter = RL_LINEAR;
+        sampler.wrapS = RL_CLAMP_TO_EDGE;
+        sampler.wrapT = RL_CLAMP_TO_EDGE;
+
+        const float texel[3] = { color.x, color.y, color.z };
+        m_texture = openrl::Texture::create(texel, desc, sampler, false);
+
+        m_textureSourcePath = std::string(SOLID_COLOR);
+        m_solidColor = color;
+    }
+}
+
+void EnvironmentLight::rotate(const float theta_radians)
+{
+    m_thetaRotation = theta_radians;
+}
+
+void EnvironmentLight::setExposure(const float exposureCompensation)
+{
+    m_exposureCompensation = exposureCompensation;
+}
+
+// EnvironmentLight.cpp:84-98 of the reference: exposure compensation is applied as 2^stops.
+void EnvironmentLight::copyToLightBuffer(hr_lights* block)
+{
+    assert(block);
+    block->env_enabled = 1;
+    block->env_texture = m_texture ? m_texture->id() : HR_TEX_NONE;
+    block->env_exposure = std::pow(2.0f, m_exposureCompensation);
+    block->env_theta_rotation = m_thetaRotation;
+}

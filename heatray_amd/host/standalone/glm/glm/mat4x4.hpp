@@ -1,0 +1,3 @@
+// mini glm forwarding header (standalone builds only), see glm.hpp
+#pragma once
+#include "glm.hpp"
