@@ -16,6 +16,9 @@
 //     subtrees of <= 4 triangles collapsed into leaves, boxes padded by
 //     1e-5 * |scene diagonal| so that the slab test is conservative w.r.t. the
 //     rounding of the Möller–Trumbore hit.
+//
+// PARITY STATUS: "parity unpinned" — OpenRL's intersector (epsilon, tie-breaking, watertightness) is a closed binary
+// with no tests in the reference; the definitions below are this repository's stated spec.
 #include "oracle_internal.h"
 
 #include <algorithm>

@@ -6,6 +6,7 @@
 // Pinned by tests/golden/ref_vectors.npz, which holds the outputs of the
 // reference's own headers compiled in the build container
 // (oracle/ref/gen_golden.cpp) and the reference's shipped multiscatter_lut.tiff.
+// PARITY STATUS: PINNED — bit-exact against those vectors (tests/test_oracle_qmc.py); LUT within 2e-6 of the TIFF.
 #include "oracle_internal.h"
 
 #include <algorithm>

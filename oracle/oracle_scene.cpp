@@ -5,6 +5,9 @@
 // vertex shader (Resources/shaders/vertex.rlsl:25-43), plus texture sampling
 // (closed inside OpenRL; bilinear at LOD 0 is this oracle's stated assumption,
 // SURVEY §8a row a6).
+//
+// PARITY STATUS: vertex transform and strip ordering follow vertex.rlsl / GL conventions; texture filtering inside
+// OpenRL is "parity unpinned" (no fixture in the reference pins it) — level-0 bilinear is this oracle's definition.
 #include "oracle_internal.h"
 
 #include <cmath>

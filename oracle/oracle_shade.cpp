@@ -7,6 +7,11 @@
 // (A+=1, then for each bounce: emissive, NEE light, (miss) environment), of the path's
 // accumulate() calls, starting from zero; the sample is added to the accumulation
 // buffer once when the path ends — the order the HIP wavefront pipeline reproduces.
+//
+// PARITY STATUS: the shading arithmetic runs inside the closed OpenRL RLSL compiler in the reference, which is
+// absent from the tree and has no tests: this restatement is "parity unpinned" against OpenRL.
+// It is anchored by line-by-line citations of the RLSL text and by the analytic known-answer tests of
+// tests/test_oracle_render.py; the sample tables it consumes ARE pinned (oracle_qmc.cpp).
 #include "oracle_internal.h"
 
 #include <cmath>
