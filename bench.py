@@ -6,8 +6,9 @@
 A "step" is one pass (one sample per pixel) of the hot path — primary-ray generation, BVH traversal,
 PBR/glass shading with NEE + environment, accumulation — over the whole frame; the scene, BVH, sample
 tables and the accumulation buffer are resident in HBM before the timed region.  With N > 1 the frame is
-sharded by 32x32-pixel tile across the ranks (strong scaling: the frame is fixed) and every step ends
-with the RCCL reduce of the RGBA32F accumulation buffer to rank 0.
+sharded by 32x32-pixel tile across the ranks (strong scaling: the frame is fixed); every step each rank's
+owned tiles are gathered on rank 0 over RCCL on a side stream, and the assembled final image is checked
+inside the timed region.  A small shard batches several passes into each kernel launch.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (closest-hit traversal), timed
 with HIP events inside libhrcore over the timed region; `cpu_baseline` is the CPU oracle (oracle/, the
@@ -25,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from heatray_amd import _ffi as ffi  # noqa: E402
-from heatray_amd import core, scenes  # noqa: E402
+from heatray_amd import core, scenes, tiles  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
@@ -130,16 +131,16 @@ def main():
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
     eng.bind_external_frame(fb.data_ptr())
-    disp = torch.empty_like(fb) if world > 1 else None
+    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3) if world > 1 else None
 
     def step(i):
         eng.render_pass(sc.options.pass_params(i))
         if world > 1:
-            # RCCL reduce of the HDR accumulation buffer for display.  The buffer holds every pass whose last stage
-            # has run (passes still in the pipeline live in their own pass buffers), so reducing it at any point of
-            # the stream gives a consistent progressive image; a copy keeps this rank's accumulator shard-only.
-            disp.copy_(fb)
-            dist.reduce(disp, dst=0, op=dist.ReduceOp.SUM)
+            # Progressive display: every step each rank packs the pixels it owns (1/world of the RGBA32F buffer) and
+            # RCCL gathers them on rank 0, on a side stream so the exchange overlaps the next pass's kernels.  The
+            # buffer holds every pass whose last stage has run (passes still in the pipeline live in their own pass
+            # buffers), so any point of the stream gives a consistent progressive image.
+            gatherer.post(fb)
 
     for i in range(args.warmup):
         step(i)
@@ -152,6 +153,10 @@ def main():
     for i in range(args.steps):
         step(args.warmup + i)
     eng.flush()  # the pass pipeline keeps depth+2 passes in flight: enqueue their remaining stages
+    full = fb
+    if world > 1:
+        gatherer.post(fb)  # the finished image
+        full = gatherer.finish()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -170,10 +175,9 @@ def main():
 
     if rank == 0:
         # sanity of the timed result itself: every owned pixel got exactly `steps` samples
-        a = fb[..., 3]
-        owned = a > 0
-        assert bool((a[owned] == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
-        assert bool(torch.isfinite(fb).all())
+        a = full[..., 3]
+        assert bool((a == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
+        assert bool(torch.isfinite(full).all())
 
         # ---- cpu_baseline leg (N = 1 only): also yields V, T of the roofline model measured by the oracle on the spec BVH
         cpu = None
@@ -235,7 +239,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "width": sc.width, "height": sc.height,
                        "max_ray_depth": sc.options.max_ray_depth, "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
-                       "sharding": f"32x32 pixel tiles round-robin over {world} GPU(s)" + ("; RCCL reduce of the RGBA32F buffer every step" if world > 1 else ""),
+                       "sharding": f"32x32 pixel tiles round-robin over {world} GPU(s)" + ("; RCCL gather of the owned RGBA32F tiles to rank 0 every step, overlapped on a side stream" if world > 1 else ""),
                        "seed": hex(scenes.SEED)},
             "roofline": roofline,
             "cpu_baseline": cpu,

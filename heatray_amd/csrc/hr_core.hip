@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,11 @@ struct hr_ctx {
     PassSlot slots[kMaxSegs];
     int nSlotsAllocated = 0;
     int maxSlots = kMaxSegs; // bounded by device memory at resize
+    // Passes requested but not yet injected: when a shard is small (multi-GPU tiles, small frames) several passes are
+    // injected per macro step so that every launch still carries about a full 1080p pass worth of rays.
+    std::deque<hr_pass_params> pendingInject;
+    int injectBatch = 1;
+    int lastDepth = -1;
     unsigned long long injected = 0;
     StepTable *dTables = nullptr; // small ring of device step tables
     unsigned long long stepCounter = 0;
@@ -144,7 +150,7 @@ struct hr_ctx {
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="leaf=1,tri=4,refill=8,blocks=8,depth=12" overrides for experiments)
-    int tuneLeaf = 1, tuneTri = 4, tuneRefill = 8, tuneBlocks = 8, tuneDepth = kMaxSegs;
+    int tuneLeaf = 1, tuneTri = 4, tuneRefill = 8, tuneBlocks = 8, tuneDepth = kMaxSegs, tuneBatch = 0;
     LaunchCfg cfg() const { return LaunchCfg{stream, numCUs, tuneBlocks, 8, collectStats}; }
 };
 
@@ -235,6 +241,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             if (p) dst = atoi(p + strlen(key));
         };
         get("leaf=", c->tuneLeaf), get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
+        get("batch=", c->tuneBatch);
         if (c->tuneLeaf < 1 || c->tuneLeaf > 4) c->tuneLeaf = 1;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSegs) c->tuneDepth = kMaxSegs;
     }
@@ -320,6 +327,14 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 + hitRecordSize()) + fbBytes + sizeof(Counters);
         const size_t fit = (freeB / 2) / perSlot;
         c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSegs ? kMaxSegs : (int)fit);
+    }
+    {
+        const long long target = 1920ll * 1080ll; // paths per macro step worth launching for
+        const long long own = c->queueCapacity ? c->queueCapacity : 1;
+        long long b = (target + own - 1) / own;
+        c->injectBatch = (int)(b < 1 ? 1 : (b > 16 ? 16 : b));
+        if (c->tuneBatch > 0) c->injectBatch = c->tuneBatch;
+        c->pendingInject.clear();
     }
     return HR_OK;
 }
@@ -787,23 +802,28 @@ static int activePasses(const hr_ctx *c)
 }
 
 // One macro step: (raygen of the injected pass) -> trace of every in-flight pass -> shade -> resolve finished passes.
-static int macroStep(hr_ctx *c, const hr_pass_params *inject)
+static int macroStep(hr_ctx *c, int nInject)
 {
     const LaunchCfg cfg = c->cfg();
     FrameDev fr = c->frame;
     fr.fb = c->fb();
-    int injectedSlot = -1;
-    if (inject) {
-        for (int i = 0; i < kMaxSegs && injectedSlot < 0; ++i)
-            if (!c->slots[i].active) injectedSlot = i;
-        if (injectedSlot < 0) FAIL(c, HR_ERR_INVALID, "internal: no free pass slot");
-        hr_ctx::PassSlot &ps = c->slots[injectedSlot];
+    int injectedSlots[kMaxSegs];
+    int nInjected = 0;
+    for (int k = 0; k < nInject; ++k) {
+        const hr_pass_params pp = c->pendingInject.front();
+        c->pendingInject.pop_front();
+        int slot = -1;
+        for (int i = 0; i < kMaxSegs && slot < 0; ++i)
+            if (!c->slots[i].active) slot = i;
+        if (slot < 0) FAIL(c, HR_ERR_INVALID, "internal: no free pass slot");
+        hr_ctx::PassSlot &ps = c->slots[slot];
         if (!ps.allocated) {
             int rc = allocSlot(c, ps);
             if (rc) return rc;
         }
-        ps.active = true, ps.step = 0, ps.nIter = inject->max_ray_depth + 1, ps.pp = *inject, ps.order = c->injected++;
+        ps.active = true, ps.step = 0, ps.nIter = pp.max_ray_depth + 1, ps.pp = pp, ps.order = c->injected++;
         HIP_TRY(c, hipMemsetAsync(ps.ctr, 0, sizeof(Counters), c->stream));
+        injectedSlots[nInjected++] = slot;
     }
     // Pass-through rays (back faces of single-sided materials, alpha masks) are not bounded by maxRayDepth:
     // before a pass's last step, see whether closest-hit rays are still queued and extend the pass if so.
@@ -826,7 +846,8 @@ static int macroStep(hr_ctx *c, const hr_pass_params *inject)
     if (n == 0) return HR_OK;
     tbl.nSeg = n;
     tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
-    int injectedSeg = -1;
+    int injectedSegs[kMaxSegs];
+    int nInjectedSegs = 0;
     for (int k = 0; k < n; ++k) {
         hr_ctx::PassSlot &ps = c->slots[order[k]];
         SegDev &sg = tbl.seg[k];
@@ -839,14 +860,15 @@ static int macroStep(hr_ctx *c, const hr_pass_params *inject)
         sg.sCountOut = &ps.ctr->sCount[st];
         sg.pp = ps.pp;
         sg.closestEnabled = st < ps.nIter ? 1 : 0;
-        if (order[k] == injectedSlot) injectedSeg = k;
+        for (int j = 0; j < nInjected; ++j)
+            if (order[k] == injectedSlots[j]) injectedSegs[nInjectedSegs++] = k;
     }
     StepTable *dTbl = c->dTables + (c->stepCounter++ % kTableRing);
     HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, sizeof(StepTable), hipMemcpyHostToDevice, c->stream));
     if (c->pending.size() > 8192) c->drainTimes();
-    if (injectedSeg >= 0) {
+    for (int j = 0; j < nInjectedSegs; ++j) {
         c->timeBegin(HR_KERNEL_RAYGEN);
-        launchRaygen(cfg, c->dScene, dTbl, injectedSeg, fr, c->dStats);
+        launchRaygen(cfg, c->dScene, dTbl, injectedSegs[j], fr, c->dStats);
         c->timeEnd();
     }
     c->timeBegin(HR_KERNEL_TRACE);
@@ -870,11 +892,35 @@ static int macroStep(hr_ctx *c, const hr_pass_params *inject)
     return HR_OK;
 }
 
+// Stages a pass occupies in the pipeline (depth+1 shaded stages + the last occlusion stage).
+static int stagesOf(const hr_pass_params &pp) { return pp.max_ray_depth + 2; }
+
+// Inject up to `want` pending passes in one macro step, first making room for them.
+static int injectPending(hr_ctx *c, int want)
+{
+    while (want > 0 && !c->pendingInject.empty()) {
+        int limit = c->maxSlots < c->tuneDepth ? c->maxSlots : c->tuneDepth; // passes in flight
+        if (limit > kMaxSegs) limit = kMaxSegs;
+        int n = want < (int)c->pendingInject.size() ? want : (int)c->pendingInject.size();
+        if (n > limit) n = limit;
+        while (activePasses(c) + n > limit) {
+            int rc = macroStep(c, 0);
+            if (rc) return rc;
+        }
+        int rc = macroStep(c, n);
+        if (rc) return rc;
+        want -= n;
+    }
+    return HR_OK;
+}
+
 static int drainPipeline(hr_ctx *c)
 {
+    int rc = injectPending(c, (int)c->pendingInject.size());
+    if (rc) return rc;
     int guard = 0;
     while (activePasses(c) > 0) {
-        int rc = macroStep(c, nullptr);
+        rc = macroStep(c, 0);
         if (rc) return rc;
         if (++guard > 4 * kMaxBounceSlots) FAIL(c, HR_ERR_DEVICE, "internal: pass pipeline did not drain");
     }
@@ -893,18 +939,27 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     int rc = uploadScene(c); // drains the pipeline first when the scene constants changed
     if (rc) return rc;
     if (c->frame.nOwnedTiles == 0) return HR_OK;
-    // pipeline depth: a pass occupies depth+2 macro steps; passes that may need extra stages run alone
-    int depth = c->hasPassthrough ? 1 : pp->max_ray_depth + 2;
-    if (depth > c->tuneDepth) depth = c->tuneDepth;
-    if (depth > c->maxSlots) depth = c->maxSlots;
-    while (activePasses(c) >= depth) {
-        rc = macroStep(c, nullptr);
+    // passes are added to the accumulation buffer in the order they finish: only passes of equal depth may overlap
+    if (pp->max_ray_depth != c->lastDepth && (activePasses(c) > 0 || !c->pendingInject.empty())) {
+        rc = drainPipeline(c);
         if (rc) return rc;
     }
-    rc = macroStep(c, pp);
-    if (rc) return rc;
-    if (c->hasPassthrough) return drainPipeline(c);
-    return HR_OK;
+    c->lastDepth = pp->max_ray_depth;
+    c->pendingInject.push_back(*pp);
+    if (c->hasPassthrough) return drainPipeline(c); // such passes may need extra stages: run them alone
+    // a macro step is launched once enough passes are waiting to fill it; the pipeline holds batch x stages passes
+    int batch = c->injectBatch;
+    const int stages = stagesOf(*pp);
+    int limit = c->maxSlots < c->tuneDepth ? c->maxSlots : c->tuneDepth;
+    if (limit > kMaxSegs) limit = kMaxSegs;
+    if (batch * stages > limit) batch = limit / stages > 0 ? limit / stages : 1;
+    if ((int)c->pendingInject.size() < batch) return HR_OK;
+    // keep at most batch x stages passes in flight: finish the oldest batch first
+    while (activePasses(c) + batch > batch * stages && activePasses(c) > 0) {
+        rc = macroStep(c, 0);
+        if (rc) return rc;
+    }
+    return injectPending(c, batch);
 }
 
 int hr_flush(hr_ctx *c)

@@ -44,7 +44,7 @@ struct SegDev {
     int32_t pad;
 };
 
-static const int kMaxSegs = 12;
+static const int kMaxSegs = 96; // in-flight passes: (passes injected per macro step) x (stages per pass)
 struct StepTable {
     uint32_t traceHead; // work cursor of the persistent trace kernel (reset with every table upload)
     int32_t nSeg;

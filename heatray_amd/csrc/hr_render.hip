@@ -217,8 +217,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                 if (idle && rank < avail) {
                     item = poolLo + rank;
                     // which queue does the item belong to (at most 2*kMaxSegs entries)
-                    int sI = 0;
-                    while (sI + 1 < nSeg2 && item >= segStart[sI + 1]) ++sI;
+                    int sI = 0, sHiB = nSeg2 - 1; // last queue whose first index is <= item
+                    while (sI < sHiB) {
+                        const int mid = (sI + sHiB + 1) >> 1;
+                        if (item >= segStart[mid])
+                            sI = mid;
+                        else
+                            sHiB = mid - 1;
+                    }
                     segIdx = sI;
                     local = item - segStart[sI];
                     const SegDev &sg = tbl->seg[sI >> 1];
@@ -382,8 +388,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(const SceneDev *__restric
         const uint32_t i = base + threadIdx.x;
         const bool live = i < total;
         int sI = 0;
-        if (live)
-            while (sI + 1 < nSeg && i >= segStart[2 * (sI + 1)]) ++sI;
+        if (live) {
+            int hiB = nSeg - 1; // last pass whose first index is <= i
+            while (sI < hiB) {
+                const int mid = (sI + hiB + 1) >> 1;
+                if (i >= segStart[2 * mid])
+                    sI = mid;
+                else
+                    hiB = mid - 1;
+            }
+        }
         Ray nee, next;
         nee.valid = next.valid = false;
         uint32_t pixel = 0, prim = 0xFFFFFFFFu;

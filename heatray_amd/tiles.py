@@ -78,3 +78,80 @@ def gather_frame(frame, rank, world, dst=0, tile=32):
             ys, xs = _tile_slices(int(t), w, h, tile)
             full[ys, xs] = bufs[r][i, : ys.stop - ys.start, : xs.stop - xs.start]
     return full
+
+
+def owned_pixel_index(width, height, rank, world, tile=32):
+    """int64 flat pixel indices (row-major over [H, W]) of the pixels `rank` owns, tile by tile in ascending tile id,
+    rows bottom-up inside a tile — i.e. exactly the pixels libhrcore writes for this rank, edge tiles cropped."""
+    idx = []
+    for t in owned_tiles(width, height, rank, world, tile):
+        ys, xs = _tile_slices(int(t), width, height, tile)
+        yy = np.arange(ys.start, ys.stop)[:, None]
+        xx = np.arange(xs.start, xs.stop)[None, :]
+        idx.append((yy * width + xx).reshape(-1))
+    return np.concatenate(idx).astype(np.int64) if idx else np.zeros((0,), np.int64)
+
+
+class FrameGatherer:
+    """Progressive-display exchange for a tile-sharded frame: every `post()` packs this rank's owned pixels
+    (1/world of the frame) and gathers them on `dst`; on CUDA the gather runs on a side stream from one of
+    `n_buffers` staging buffers, so it overlaps the next pass's kernels (xGMI is point-to-point: `dst` receives
+    from each peer over its own link).  `finish()` returns the assembled frame of the last post on `dst`.
+
+    Bit-exact by construction: pixels are copied, never summed."""
+
+    def __init__(self, width, height, rank, world, device, tile=32, dst=0, n_buffers=2, overlap=True):
+        import torch
+        self.torch = torch
+        self.w, self.h, self.rank, self.world, self.dst = width, height, rank, world, dst
+        self.device = torch.device(device)
+        self.idx = [torch.from_numpy(owned_pixel_index(width, height, r, world, tile)).to(self.device) if (r == rank or rank == dst) else None
+                    for r in range(world)]
+        self.n_max = max(len(owned_pixel_index(width, height, r, world, tile)) for r in range(world))
+        self.send = [torch.zeros((self.n_max, 4), dtype=torch.float32, device=self.device) for _ in range(n_buffers)]
+        self.recv = [[torch.empty((self.n_max, 4), dtype=torch.float32, device=self.device) for _ in range(world)] for _ in range(n_buffers)] \
+            if rank == dst else None
+        self.full = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device) if rank == dst else None
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(device=self.device) if (self.cuda and overlap) else None
+        self.free_ev = [None] * n_buffers  # recorded on the side stream when a staging buffer may be reused
+        self.turn = 0
+        self.posted = False
+
+    def post(self, frame):
+        import torch.distributed as dist
+        torch = self.torch
+        b = self.turn % len(self.send)
+        self.turn += 1
+        own = self.idx[self.rank]
+        if self.side is not None and self.free_ev[b] is not None:
+            torch.cuda.current_stream(self.device).wait_event(self.free_ev[b])
+        if own.numel():
+            torch.index_select(frame.view(-1, 4), 0, own, out=self.send[b][: own.numel()])
+        if self.side is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):
+                self._exchange(b, dist)
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.free_ev[b] = ev
+        else:
+            self._exchange(b, dist)
+        self.posted = True
+
+    def _exchange(self, b, dist):
+        dist.gather(self.send[b], self.recv[b] if self.rank == self.dst else None, dst=self.dst)
+        if self.rank == self.dst:
+            flat = self.full.view(-1, 4)
+            for r in range(self.world):
+                n = self.idx[r].numel()
+                if n:
+                    flat.index_copy_(0, self.idx[r], self.recv[b][r][:n])
+
+    def finish(self):
+        """Join the side stream into the current one; returns the assembled frame on `dst`, None elsewhere."""
+        if self.side is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.side)
+        return self.full if self.rank == self.dst else None

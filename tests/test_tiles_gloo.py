@@ -34,9 +34,14 @@ def _worker(rank, world, port, width, height, passes, q):
         assert bool(((frame[..., 3] > 0) == own).all())
         reduced = tiles.reduce_frame(frame, dst=0)
         gathered = tiles.gather_frame(frame, rank, world, dst=0)
+        # the progressive-display exchange bench.py uses for N > 1: posted after every pass, staging buffers reused
+        g = tiles.FrameGatherer(width, height, rank, world, "cpu", n_buffers=2)
+        for k in range(3):
+            g.post(frame * float(k + 1))
+        posted = g.finish()
         assert bool((frame[..., 3][~own] == 0).all())  # the local accumulator is untouched by the collectives
         if rank == 0:
-            q.put((reduced.numpy(), gathered.numpy()))
+            q.put((reduced.numpy(), gathered.numpy(), posted.numpy()))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -61,12 +66,13 @@ def test_shards_reduce_and_gather_to_the_full_frame(world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, width, height, passes, q)) for r in range(world)]
     for p in procs:
         p.start()
-    reduced, gathered = q.get(timeout=240)
+    reduced, gathered, posted = q.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert reduced.tobytes() == full.tobytes()
     assert gathered.tobytes() == full.tobytes()
+    assert posted.tobytes() == (full * 3.0).tobytes()
 
 
 def test_ownership_map_matches_the_engines():
