@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--shard-of", type=int, default=0, help="tuning aid, single process: render only rank 0's tiles of a W-way "
+                    "sharded frame (no collective); the JSON line is marked emulated and is not a benchmark result")
     ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
     args = ap.parse_args()
 
@@ -123,10 +125,12 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
+    emulated = args.shard_of > 1 and world == 1
+    eng_world = args.shard_of if emulated else world
     passes_total = args.warmup + args.steps
     sc = build_scene(args.workload, args.width, args.height, max(32, passes_total))
     stream = torch.cuda.current_stream().cuda_stream
-    eng = core.create_engine(device_id=local_rank, rank=rank, world=world, tile_size=32, stream=stream, time_kernels=True)
+    eng = core.create_engine(device_id=local_rank, rank=rank, world=eng_world, tile_size=32, stream=stream, time_kernels=True)
     sc.apply(eng)  # tables and LUT are generated on the device
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
@@ -176,6 +180,8 @@ def main():
     if rank == 0:
         # sanity of the timed result itself: every owned pixel got exactly `steps` samples
         a = full[..., 3]
+        if emulated:
+            a = a[torch.from_numpy(tiles.owner_map(sc.width, sc.height, eng_world) == 0).to(dev)]
         assert bool((a == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
         assert bool(torch.isfinite(full).all())
 
@@ -188,7 +194,7 @@ def main():
         # ---- the product's own traversal counters (4-wide quantised BVH), one extra counted pass outside the timed region
         gpu_counts = None
         if not args.no_stats_pass:
-            se = core.create_engine(device_id=local_rank, rank=rank, world=world, tile_size=32, stream=stream, collect_stats=True)
+            se = core.create_engine(device_id=local_rank, rank=rank, world=eng_world, tile_size=32, stream=stream, collect_stats=True)
             sc.apply(se)
             se.render_pass(sc.options.pass_params(args.warmup))
             ss = se.stats()
@@ -248,6 +254,9 @@ def main():
                       "kernel_ms_rank0": {k: v[0] for k, v in kt.items()}, "kernel_launches_rank0": {k: v[1] for k, v in kt.items()},
                       "gpu_traversal_counters": gpu_counts},
         }
+        if emulated:
+            out["emulated_shard_of"] = eng_world
+            out["metric"] += f" [EMULATED rank 0 of {eng_world}, not a benchmark result]"
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

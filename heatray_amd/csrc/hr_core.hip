@@ -35,6 +35,9 @@ struct Geom {
 
 } // namespace
 
+static const int kMaxGroups = 4;
+static const int kMaxSlots = 2 * kMaxSegs; // passes in flight over all groups
+
 struct hr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -54,6 +57,11 @@ struct hr_ctx {
     // the pass buffer of one pass.
     struct PassSlot {
         bool allocated = false, active = false;
+        bool finished = false;   // every stage has been enqueued; the slot is held until its turn to resolve comes
+        bool everResolved = false;
+        int group = 0;           // pipeline group (worker stream) the pass runs on
+        hipEvent_t evFinal = nullptr;    // recorded on the worker stream after the pass's last stage
+        hipEvent_t evResolved = nullptr; // recorded on the caller's stream after the pass buffer was added to the frame
         int step = 0, nIter = 0;
         unsigned long long order = 0; // injection order (passes resolve in this order)
         hr_pass_params pp{};
@@ -63,17 +71,33 @@ struct hr_ctx {
         float *passbuf = nullptr;
         Counters *ctr = nullptr;
     };
-    PassSlot slots[kMaxSegs];
+    PassSlot slots[kMaxSlots];
     int nSlotsAllocated = 0;
-    int maxSlots = kMaxSegs; // bounded by device memory at resize
+    int maxSlots = kMaxSlots; // bounded by device memory at resize
+    // Pipeline groups: independent pass pipelines on their own HIP streams, stepped alternately, so that the tail of one
+    // group's persistent trace kernel (waves running dry) is back-filled by the other group's kernels.  Resolves run on
+    // the caller's stream, strictly in pass order.
+    struct Group {
+        hipStream_t stream = nullptr;
+        StepTable *dTables = nullptr;   // ring of device step tables
+        StepTable *hTables = nullptr;   // pinned staging ring
+        hipEvent_t tableCopied[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool tableUsed[4] = {false, false, false, false};
+        unsigned long long stepCounter = 0;
+        hipEvent_t evUser = nullptr;    // caller-stream state this group has to wait for
+        bool needUserSync = true;
+    };
+    Group groups[kMaxGroups];
+    int nGroups = 1; // measured on MI355X: 2-3 groups are within noise of 1 (the trace kernel has no long tail once
+                     // work is fetched in 64-ray chunks), so the default keeps one group; HR_TUNE="groups=2" for experiments
+    int nextGroup = 0;
+    unsigned long long nextResolveOrder = 0;
     // Passes requested but not yet injected: when a shard is small (multi-GPU tiles, small frames) several passes are
     // injected per macro step so that every launch still carries about a full 1080p pass worth of rays.
     std::deque<hr_pass_params> pendingInject;
     int injectBatch = 1;
     int lastDepth = -1;
     unsigned long long injected = 0;
-    StepTable *dTables = nullptr; // small ring of device step tables
-    unsigned long long stepCounter = 0;
     uint32_t *dZero = nullptr;    // a zero word (occlusion count of a pass's first step)
 
     // scene (host mirror)
@@ -121,21 +145,23 @@ struct hr_ctx {
         }
         return e;
     }
-    void timeBegin(int kind)
+    void timeBegin(int kind, hipStream_t st)
     {
         if (!timeKernels) return;
         Timed t{kind, getEvent(), getEvent()};
-        hipEventRecord(t.e0, stream);
+        hipEventRecord(t.e0, st);
         pending.push_back(t);
     }
-    void timeEnd()
+    void timeEnd(hipStream_t st)
     {
         if (!timeKernels) return;
-        hipEventRecord(pending.back().e1, stream);
+        hipEventRecord(pending.back().e1, st);
     }
     void drainTimes()
     {
         if (pending.empty()) return;
+        for (int g = 0; g < nGroups; ++g)
+            if (groups[g].stream) hipStreamSynchronize(groups[g].stream);
         hipStreamSynchronize(stream);
         for (Timed &t : pending) {
             float ms = 0.0f;
@@ -150,8 +176,8 @@ struct hr_ctx {
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="leaf=1,tri=4,refill=8,blocks=8,depth=12" overrides for experiments)
-    int tuneLeaf = 1, tuneTri = 4, tuneRefill = 8, tuneBlocks = 8, tuneDepth = kMaxSegs, tuneBatch = 0;
-    LaunchCfg cfg() const { return LaunchCfg{stream, numCUs, tuneBlocks, 8, collectStats}; }
+    int tuneLeaf = 1, tuneTri = 4, tuneRefill = 8, tuneBlocks = 6, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64;
+    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, 8, collectStats}; }
 };
 
 #define FAIL(ctx, code, msg)  \
@@ -195,6 +221,8 @@ static void freeQueues(hr_ctx *c)
         for (int i = 0; i < 2; ++i) hipFree(ps.q[i].A), hipFree(ps.q[i].B), hipFree(ps.q[i].C), hipFree(ps.q[i].D);
         hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C);
         hipFree(ps.hits), hipFree(ps.passbuf), hipFree(ps.ctr);
+        if (ps.evFinal) hipEventDestroy(ps.evFinal);
+        if (ps.evResolved) hipEventDestroy(ps.evResolved);
         ps = hr_ctx::PassSlot();
     }
     c->nSlotsAllocated = 0;
@@ -241,11 +269,22 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             if (p) dst = atoi(p + strlen(key));
         };
         get("leaf=", c->tuneLeaf), get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
-        get("batch=", c->tuneBatch);
+        get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
         if (c->tuneLeaf < 1 || c->tuneLeaf > 4) c->tuneLeaf = 1;
-        if (c->tuneDepth < 1 || c->tuneDepth > kMaxSegs) c->tuneDepth = kMaxSegs;
+        get("groups=", c->nGroups);
+        if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
+        if (c->nGroups < 1 || c->nGroups > kMaxGroups) c->nGroups = 1;
     }
-    if (hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess || hipMalloc(&c->dTables, sizeof(StepTable) * kTableRing) != hipSuccess ||
+    bool groupsOk = true;
+    for (int g = 0; g < c->nGroups; ++g) {
+        hr_ctx::Group &G = c->groups[g];
+        groupsOk = groupsOk && hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking) == hipSuccess;
+        groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
+        groupsOk = groupsOk && hipEventCreateWithFlags(&G.evUser, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
         hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess ||
         hipMalloc(&c->dZero, 64) != hipSuccess) {
         delete c;
@@ -271,7 +310,15 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->fbInternal);
     if (c->pinned) hipHostFree(c->pinned);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
-    hipFree(c->dScene), hipFree(c->dTables), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero);
+    hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero);
+    for (hr_ctx::Group &G : c->groups) {
+        if (G.stream) hipStreamDestroy(G.stream);
+        hipFree(G.dTables);
+        if (G.hTables) hipHostFree(G.hTables);
+        if (G.evUser) hipEventDestroy(G.evUser);
+        for (hipEvent_t e : G.tableCopied)
+            if (e) hipEventDestroy(e);
+    }
     delete c;
     return HR_OK;
 }
@@ -322,11 +369,11 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
     c->queueCapacity = (uint32_t)f.nOwnedTiles * (uint32_t)(c->tile * c->tile);
     // how many passes may be in flight: each slot holds two ray queues, an occlusion queue, hit records and a pass buffer
     size_t freeB = 0, totalB = 0;
-    c->maxSlots = kMaxSegs;
+    c->maxSlots = kMaxSlots;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 + hitRecordSize()) + fbBytes + sizeof(Counters);
         const size_t fit = (freeB / 2) / perSlot;
-        c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSegs ? kMaxSegs : (int)fit);
+        c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
     }
     {
         const long long target = 1920ll * 1080ll; // paths per macro step worth launching for
@@ -789,9 +836,19 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
     HIP_TRY(c, hipMalloc(&ps.hits, cap * hitRecordSize()));
     HIP_TRY(c, hipMalloc(&ps.passbuf, (size_t)c->W * c->H * 4 * sizeof(float)));
     HIP_TRY(c, hipMalloc(&ps.ctr, sizeof(Counters)));
+    HIP_TRY(c, hipEventCreateWithFlags(&ps.evFinal, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&ps.evResolved, hipEventDisableTiming));
     ps.allocated = true;
     c->nSlotsAllocated++;
     return HR_OK;
+}
+
+// passes that hold a slot: in flight, or finished and waiting for their turn to resolve
+static int occupiedSlots(const hr_ctx *c, int group = -1)
+{
+    int n = 0;
+    for (const hr_ctx::PassSlot &ps : c->slots) n += ((ps.active || ps.finished) && (group < 0 || ps.group == group)) ? 1 : 0;
+    return n;
 }
 
 static int activePasses(const hr_ctx *c)
@@ -801,51 +858,90 @@ static int activePasses(const hr_ctx *c)
     return n;
 }
 
-// One macro step: (raygen of the injected pass) -> trace of every in-flight pass -> shade -> resolve finished passes.
-static int macroStep(hr_ctx *c, int nInject)
+// Finished passes are added to the frame on the caller's stream, strictly in pass order (float addition order is
+// part of the arithmetic contract), whatever order the groups finished them in.
+static int resolveReady(hr_ctx *c)
 {
-    const LaunchCfg cfg = c->cfg();
     FrameDev fr = c->frame;
     fr.fb = c->fb();
+    const LaunchCfg cfg = c->cfg(c->stream);
+    for (;;) {
+        hr_ctx::PassSlot *next = nullptr;
+        for (hr_ctx::PassSlot &ps : c->slots)
+            if ((ps.active || ps.finished) && ps.order == c->nextResolveOrder) next = &ps;
+        if (!next || !next->finished) return HR_OK;
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, next->evFinal, 0));
+        c->timeBegin(HR_KERNEL_RESOLVE, c->stream);
+        launchResolve(cfg, fr, next->passbuf);
+        c->timeEnd(c->stream);
+        HIP_TRY(c, hipEventRecord(next->evResolved, c->stream));
+        next->finished = false, next->everResolved = true;
+        c->nextResolveOrder++;
+    }
+}
+
+// One macro step of pipeline group g: (raygen of the injected passes) -> trace of every in-flight pass of the group ->
+// shade; passes whose last stage this was become `finished`.
+static int macroStep(hr_ctx *c, int g, int nInject)
+{
+    hr_ctx::Group &G = c->groups[g];
+    const LaunchCfg cfg = c->cfg(G.stream);
+    FrameDev fr = c->frame;
+    fr.fb = c->fb();
+    if (G.needUserSync) { // state set up on the caller's stream (scene, tables, cleared buffers) must be visible
+        HIP_TRY(c, hipEventRecord(G.evUser, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(G.stream, G.evUser, 0));
+        G.needUserSync = false;
+    }
     int injectedSlots[kMaxSegs];
     int nInjected = 0;
     for (int k = 0; k < nInject; ++k) {
         const hr_pass_params pp = c->pendingInject.front();
         c->pendingInject.pop_front();
         int slot = -1;
-        for (int i = 0; i < kMaxSegs && slot < 0; ++i)
-            if (!c->slots[i].active) slot = i;
+        for (int i = 0; i < kMaxSlots && slot < 0; ++i) // prefer slots that already own memory
+            if (!c->slots[i].active && !c->slots[i].finished && c->slots[i].allocated) slot = i;
+        for (int i = 0; i < kMaxSlots && slot < 0; ++i)
+            if (!c->slots[i].active && !c->slots[i].finished) slot = i;
         if (slot < 0) FAIL(c, HR_ERR_INVALID, "internal: no free pass slot");
         hr_ctx::PassSlot &ps = c->slots[slot];
         if (!ps.allocated) {
             int rc = allocSlot(c, ps);
             if (rc) return rc;
         }
-        ps.active = true, ps.step = 0, ps.nIter = pp.max_ray_depth + 1, ps.pp = pp, ps.order = c->injected++;
-        HIP_TRY(c, hipMemsetAsync(ps.ctr, 0, sizeof(Counters), c->stream));
+        if (ps.everResolved) HIP_TRY(c, hipStreamWaitEvent(G.stream, ps.evResolved, 0)); // the pass buffer is free again
+        ps.active = true, ps.finished = false, ps.group = g, ps.step = 0, ps.nIter = pp.max_ray_depth + 1, ps.pp = pp;
+        ps.order = c->injected++;
+        HIP_TRY(c, hipMemsetAsync(ps.ctr, 0, sizeof(Counters), G.stream));
         injectedSlots[nInjected++] = slot;
     }
     // Pass-through rays (back faces of single-sided materials, alpha masks) are not bounded by maxRayDepth:
     // before a pass's last step, see whether closest-hit rays are still queued and extend the pass if so.
     if (c->hasPassthrough) {
         for (hr_ctx::PassSlot &ps : c->slots) {
-            if (!ps.active || ps.step != ps.nIter || ps.nIter >= kMaxBounceSlots - 2) continue;
+            if (!ps.active || ps.group != g || ps.step != ps.nIter || ps.nIter >= kMaxBounceSlots - 2) continue;
             uint32_t remaining = 0;
-            HIP_TRY(c, hipMemcpyAsync(&remaining, &ps.ctr->qCount[ps.nIter], 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&remaining, &ps.ctr->qCount[ps.nIter], 4, hipMemcpyDeviceToHost, G.stream));
+            HIP_TRY(c, hipStreamSynchronize(G.stream));
             if (remaining > 0) ps.nIter = ps.nIter + 4 < kMaxBounceSlots - 2 ? ps.nIter + 4 : kMaxBounceSlots - 2;
         }
     }
-    // table of the in-flight passes, oldest first
-    StepTable tbl{};
-    int order[kMaxSegs], n = 0;
-    for (int i = 0; i < kMaxSegs; ++i)
-        if (c->slots[i].active) order[n++] = i;
+    // table of the group's in-flight passes, oldest first
+    int order[kMaxSlots], n = 0;
+    for (int i = 0; i < kMaxSlots; ++i)
+        if (c->slots[i].active && c->slots[i].group == g) order[n++] = i;
     for (int a = 1; a < n; ++a)
         for (int b = a; b > 0 && c->slots[order[b]].order < c->slots[order[b - 1]].order; --b) std::swap(order[b], order[b - 1]);
     if (n == 0) return HR_OK;
+    if (n > kMaxSegs) FAIL(c, HR_ERR_INVALID, "internal: too many passes in one group");
+    const int ring = (int)(G.stepCounter++ % kTableRing);
+    if (G.tableUsed[ring]) HIP_TRY(c, hipEventSynchronize(G.tableCopied[ring])); // staging entry free again (4 steps old)
+    StepTable &tbl = G.hTables[ring];
+    tbl.traceHead = 0;
     tbl.nSeg = n;
     tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
+    tbl.fetchMax = c->tuneFetchMax > 0 ? c->tuneFetchMax : 1, tbl.fetchMin = c->tuneFetchMin > 0 ? c->tuneFetchMin : 1;
+    tbl.pad0 = tbl.pad1 = 0;
     int injectedSegs[kMaxSegs];
     int nInjectedSegs = 0;
     for (int k = 0; k < n; ++k) {
@@ -863,67 +959,99 @@ static int macroStep(hr_ctx *c, int nInject)
         for (int j = 0; j < nInjected; ++j)
             if (order[k] == injectedSlots[j]) injectedSegs[nInjectedSegs++] = k;
     }
-    StepTable *dTbl = c->dTables + (c->stepCounter++ % kTableRing);
-    HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, sizeof(StepTable), hipMemcpyHostToDevice, c->stream));
+    StepTable *dTbl = G.dTables + ring;
+    const size_t tblBytes = offsetof(StepTable, seg) + (size_t)n * sizeof(SegDev);
+    HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, tblBytes, hipMemcpyHostToDevice, G.stream));
+    HIP_TRY(c, hipEventRecord(G.tableCopied[ring], G.stream));
+    G.tableUsed[ring] = true;
     if (c->pending.size() > 8192) c->drainTimes();
     for (int j = 0; j < nInjectedSegs; ++j) {
-        c->timeBegin(HR_KERNEL_RAYGEN);
+        c->timeBegin(HR_KERNEL_RAYGEN, G.stream);
         launchRaygen(cfg, c->dScene, dTbl, injectedSegs[j], fr, c->dStats);
-        c->timeEnd();
+        c->timeEnd(G.stream);
     }
-    c->timeBegin(HR_KERNEL_TRACE);
+    c->timeBegin(HR_KERNEL_TRACE, G.stream);
     launchTrace(cfg, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
-    c->timeEnd();
-    c->timeBegin(HR_KERNEL_SHADE);
+    c->timeEnd(G.stream);
+    c->timeBegin(HR_KERNEL_SHADE, G.stream);
     launchShade(cfg, c->dScene, dTbl, c->dStats);
-    c->timeEnd();
+    c->timeEnd(G.stream);
     for (int k = 0; k < n; ++k) {
         hr_ctx::PassSlot &ps = c->slots[order[k]];
         if (ps.step >= ps.nIter) {
-            c->timeBegin(HR_KERNEL_RESOLVE);
-            launchResolve(cfg, fr, ps.passbuf);
-            c->timeEnd();
-            ps.active = false;
+            ps.active = false, ps.finished = true;
+            HIP_TRY(c, hipEventRecord(ps.evFinal, G.stream));
         } else {
             ps.step++;
         }
     }
     HIP_TRY(c, hipGetLastError());
-    return HR_OK;
+    return resolveReady(c);
 }
 
 // Stages a pass occupies in the pipeline (depth+1 shaded stages + the last occlusion stage).
 static int stagesOf(const hr_pass_params &pp) { return pp.max_ray_depth + 2; }
 
-// Inject up to `want` pending passes in one macro step, first making room for them.
-static int injectPending(hr_ctx *c, int want)
+// Advance the group that holds the oldest in-flight pass by one macro step (keeps passes finishing in order).
+static int stepOldest(hr_ctx *c)
 {
-    while (want > 0 && !c->pendingInject.empty()) {
-        int limit = c->maxSlots < c->tuneDepth ? c->maxSlots : c->tuneDepth; // passes in flight
-        if (limit > kMaxSegs) limit = kMaxSegs;
-        int n = want < (int)c->pendingInject.size() ? want : (int)c->pendingInject.size();
-        if (n > limit) n = limit;
-        while (activePasses(c) + n > limit) {
-            int rc = macroStep(c, 0);
-            if (rc) return rc;
-        }
-        int rc = macroStep(c, n);
+    const hr_ctx::PassSlot *oldest = nullptr;
+    for (const hr_ctx::PassSlot &ps : c->slots)
+        if (ps.active && (!oldest || ps.order < oldest->order)) oldest = &ps;
+    if (!oldest) return resolveReady(c);
+    return macroStep(c, oldest->group, 0);
+}
+
+static int slotLimit(const hr_ctx *c)
+{
+    int limit = c->maxSlots < c->tuneDepth ? c->maxSlots : c->tuneDepth; // passes in flight, all groups
+    return limit < 1 ? 1 : (limit > kMaxSlots ? kMaxSlots : limit);
+}
+
+// Inject n pending passes into the next group (round robin), first making room for them.
+static int injectBatch(hr_ctx *c, int n, int perGroupLimit)
+{
+    const int g = c->nextGroup;
+    c->nextGroup = (g + 1) % c->nGroups;
+    int guard = 0;
+    while ((occupiedSlots(c, g) + n > perGroupLimit || occupiedSlots(c) + n > slotLimit(c)) && occupiedSlots(c) > 0) {
+        int rc = stepOldest(c);
         if (rc) return rc;
-        want -= n;
+        if (++guard > 64 * kMaxBounceSlots) FAIL(c, HR_ERR_DEVICE, "internal: pass pipeline did not make room");
     }
-    return HR_OK;
+    return macroStep(c, g, n);
+}
+
+static int batchFor(const hr_ctx *c, int stages)
+{
+    int batch = c->injectBatch;
+    int perGroup = slotLimit(c) / c->nGroups;
+    if (perGroup > kMaxSegs) perGroup = kMaxSegs;
+    if (batch * stages > perGroup) batch = perGroup / stages;
+    return batch < 1 ? 1 : batch;
 }
 
 static int drainPipeline(hr_ctx *c)
 {
-    int rc = injectPending(c, (int)c->pendingInject.size());
-    if (rc) return rc;
+    while (!c->pendingInject.empty()) {
+        const int stages = stagesOf(c->pendingInject.front());
+        const int batch = batchFor(c, stages);
+        const int n = (int)c->pendingInject.size() < batch ? (int)c->pendingInject.size() : batch;
+        int perGroup = batch * stages;
+        int rc = injectBatch(c, n, perGroup);
+        if (rc) return rc;
+    }
     int guard = 0;
     while (activePasses(c) > 0) {
-        rc = macroStep(c, 0);
+        int rc = stepOldest(c);
         if (rc) return rc;
-        if (++guard > 4 * kMaxBounceSlots) FAIL(c, HR_ERR_DEVICE, "internal: pass pipeline did not drain");
+        if (++guard > 64 * kMaxBounceSlots) FAIL(c, HR_ERR_DEVICE, "internal: pass pipeline did not drain");
     }
+    int rc = resolveReady(c);
+    if (rc) return rc;
+    if (occupiedSlots(c) > 0) FAIL(c, HR_ERR_DEVICE, "internal: finished passes left unresolved");
+    // whatever the caller does next on its stream (clear, scene edits, new tables) has to be seen by the groups
+    for (int g = 0; g < c->nGroups; ++g) c->groups[g].needUserSync = true;
     return HR_OK;
 }
 
@@ -939,27 +1067,19 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     int rc = uploadScene(c); // drains the pipeline first when the scene constants changed
     if (rc) return rc;
     if (c->frame.nOwnedTiles == 0) return HR_OK;
-    // passes are added to the accumulation buffer in the order they finish: only passes of equal depth may overlap
-    if (pp->max_ray_depth != c->lastDepth && (activePasses(c) > 0 || !c->pendingInject.empty())) {
+    // only passes of equal depth overlap (keeps the groups in lockstep; order is enforced by resolveReady regardless)
+    if (pp->max_ray_depth != c->lastDepth && (occupiedSlots(c) > 0 || !c->pendingInject.empty())) {
         rc = drainPipeline(c);
         if (rc) return rc;
     }
     c->lastDepth = pp->max_ray_depth;
     c->pendingInject.push_back(*pp);
     if (c->hasPassthrough) return drainPipeline(c); // such passes may need extra stages: run them alone
-    // a macro step is launched once enough passes are waiting to fill it; the pipeline holds batch x stages passes
-    int batch = c->injectBatch;
+    // a macro step is launched once enough passes are waiting to fill it; each group holds batch x stages passes
     const int stages = stagesOf(*pp);
-    int limit = c->maxSlots < c->tuneDepth ? c->maxSlots : c->tuneDepth;
-    if (limit > kMaxSegs) limit = kMaxSegs;
-    if (batch * stages > limit) batch = limit / stages > 0 ? limit / stages : 1;
+    const int batch = batchFor(c, stages);
     if ((int)c->pendingInject.size() < batch) return HR_OK;
-    // keep at most batch x stages passes in flight: finish the oldest batch first
-    while (activePasses(c) + batch > batch * stages && activePasses(c) > 0) {
-        rc = macroStep(c, 0);
-        if (rc) return rc;
-    }
-    return injectPending(c, batch);
+    return injectBatch(c, batch, batch * stages);
 }
 
 int hr_flush(hr_ctx *c)
@@ -1046,7 +1166,7 @@ int hr_debug_trace(hr_ctx *c, int32_t n, const float *o, const float *d, const f
         HIP_TRY(c, hipMalloc(&dS, (size_t)n * 4));
         HIP_TRY(c, hipMemcpy(dS, skip, (size_t)n * 4, hipMemcpyHostToDevice));
     }
-    launchDebugTrace(c->cfg(), c->dScene, n, dO, dD, dT, dS, anyHit, dH);
+    launchDebugTrace(c->cfg(c->stream), c->dScene, n, dO, dD, dT, dS, anyHit, dH);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipMemcpy(out, dH, (size_t)n * sizeof(hr_hit), hipMemcpyDeviceToHost);
     hipFree(dO), hipFree(dD), hipFree(dT), hipFree(dS), hipFree(dH);

@@ -174,6 +174,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     int *stackLane = &stack[wave][0][lane];
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const int kRefill = tbl->refillLanes, kTriPhase = tbl->triPhaseLanes;
+    const uint32_t fetchMax = (uint32_t)tbl->fetchMax, fetchMin = (uint32_t)tbl->fetchMin;
+    const uint32_t wavesTimes2 = 2u * gridDim.x * kWavesPerBlock;
+    uint32_t lastBase = 0; // wave-uniform: where the global cursor stood at this wave's previous reservation
 
     // ---- per-lane traversal state (one ray per lane, refilled from the work pool when a lane finishes)
     int cur = kSentinel, sp = 0;
@@ -202,15 +205,19 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         if (!exhausted && (nIdle >= kRefill || nIdle == 64)) {
             for (int round = 0; round < 2 && nIdle > 0; ++round) {
                 if (poolLo == poolHi) { // reserve another chunk of the global index space
+                    // chunk ~ (work left) / (2 x waves), from the cursor value this wave saw last (any size is valid)
+                    uint32_t chunk = (total - lastBase) / wavesTimes2;
+                    chunk = chunk > fetchMax ? fetchMax : (chunk < fetchMin ? fetchMin : chunk);
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&tbl->traceHead, (uint32_t)kFetchChunk);
+                    if (lane == 0) base = atomicAdd(&tbl->traceHead, chunk);
                     base = __shfl(base, 0);
                     if (base >= total) {
                         exhausted = true;
                         break;
                     }
+                    lastBase = base;
                     poolLo = base;
-                    poolHi = (base + kFetchChunk < total) ? base + kFetchChunk : total;
+                    poolHi = (base + chunk < total) ? base + chunk : total;
                 }
                 const uint32_t avail = poolHi - poolLo;
                 const uint32_t rank = (uint32_t)__popcll(idleMask & ltMask);

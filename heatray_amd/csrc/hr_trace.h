@@ -19,7 +19,6 @@ static const int kStackLDS = 16;   // entries per lane kept in LDS (power of two
 static const int kStackOvf = 80;   // private overflow: a 4-wide node pushes up to 3 entries per level, binary depth <= 58 -> <= 29 levels
 static const int kSentinel = 0x7FFFFFFF;
 static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
-static const int kFetchChunk = 256; // work items a wave reserves per global atomic
 static const int kTriPhaseLanes = 20; // run the triangle phase once this many lanes are blocked on a postponed leaf
 
 struct HitRec {
