@@ -8,7 +8,7 @@ import os
 from ._ffi import ABI_SYMBOLS, Engine, EngineError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("HRCORE_LIB", os.path.join(_HERE, "csrc", "libhrcore.so"))  # HRCORE_LIB: A/B builds in experiments
+LIB_PATH = os.environ.get("HRCORE_LIB") or os.path.join(_HERE, "csrc", "libhrcore.so")  # HRCORE_LIB: A/B builds in experiments
 _LIB = None
 
 

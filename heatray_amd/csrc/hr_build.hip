@@ -323,17 +323,11 @@ __global__ __launch_bounds__(256) void k_refit_round(const KNode *__restrict__ n
     stamp[i] = round;
 }
 
-__global__ __launch_bounds__(256) void k_flag_internal(const KNode *__restrict__ nodes, int nInternal, int kLeafMax, uint32_t *__restrict__ flags)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nInternal) return;
-    flags[i] = (nodes[i].last - nodes[i].first + 1 > kLeafMax) ? 1u : 0u;
-}
-
 // Collapse the binary tree into 4-wide nodes, one tree level per launch.  binOf[i] is the binary (Karras)
 // node that 4-wide node i stands for.  Starting from its two children, the inner child with the largest
-// surface area is replaced by its own two children until four children exist (or none can be opened);
-// subtrees of <= kLeafMax triangles are leaves.  New 4-wide nodes are appended through an atomic counter.
+// surface area is replaced by its own two children until four children exist (or none can be opened).
+// Leaves hold ONE triangle.  The inner children of a node are appended together through one atomic reservation
+// (siblings become neighbours in memory), and so are its triangles, which are copied to their final place.
 HRD float boxArea(const Box6 &b)
 {
     const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
@@ -353,7 +347,8 @@ HRD uint32_t quantExponent(float ext)
 
 __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ knodes, const Box6 *__restrict__ leafBox,
                                                    const Box6 *__restrict__ nodeBox, int *__restrict__ binOf, uint32_t levelStart,
-                                                   uint32_t levelEnd, int kLeafMax, uint32_t *__restrict__ counter, Node4 *__restrict__ out)
+                                                   uint32_t levelEnd, uint32_t *__restrict__ counter, uint32_t *__restrict__ leafCounter,
+                                                   const Tri *__restrict__ sorted, Tri *__restrict__ finalTris, Node4 *__restrict__ out)
 {
     const uint32_t i = levelStart + blockIdx.x * 256 + threadIdx.x;
     if (i >= levelEnd) return;
@@ -367,8 +362,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
         float bestArea = -1.0f;
         for (int c = 0; c < n; ++c) {
             const int ref = cand[c];
-            if (ref < 0) continue;
-            if (knodes[ref].last - knodes[ref].first + 1 <= kLeafMax) continue;
+            if (ref < 0) continue; // a single triangle
             const float a = boxArea(nodeBox[ref]);
             if (a > bestArea) bestArea = a, pick = c;
         }
@@ -377,29 +371,28 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
         cand[pick] = knodes[ref].left;
         cand[n++] = knodes[ref].right;
     }
+    // inner children first, triangles after them (the order of the children inside a node is free)
+    int ord[4];
+    int nInner = 0;
+    for (int c = 0; c < n; ++c)
+        if (cand[c] >= 0) ord[nInner++] = cand[c];
+    int nValid = nInner;
+    for (int c = 0; c < n; ++c)
+        if (cand[c] < 0) ord[nValid++] = cand[c];
+    const int nLeaf = nValid - nInner;
+    const uint32_t innerBase = nInner ? atomicAdd(counter, (uint32_t)nInner) : 0u;
+    const uint32_t leafBase = nLeaf ? atomicAdd(leafCounter, (uint32_t)nLeaf) : 0u;
     Box6 cb[4];
-    int child[4];
     Box6 nb;
     for (int k = 0; k < 3; ++k) nb.lo[k] = __builtin_inff(), nb.hi[k] = -__builtin_inff();
-    for (int c = 0; c < 4; ++c) {
-        child[c] = kEmptyChild;
-        if (c >= n) continue;
-        const int ref = cand[c];
-        int first, last;
+    for (int c = 0; c < nValid; ++c) {
+        const int ref = ord[c];
         if (ref < 0) {
-            first = last = ~ref;
             cb[c] = leafBox[~ref];
+            finalTris[leafBase + (uint32_t)(c - nInner)] = sorted[~ref];
         } else {
-            first = knodes[ref].first, last = knodes[ref].last;
             cb[c] = nodeBox[ref];
-        }
-        const int count = last - first + 1;
-        if (count <= kLeafMax) {
-            child[c] = ~(first | ((count - 1) << 28));
-        } else {
-            const uint32_t j = atomicAdd(counter, 1u);
-            binOf[j] = ref;
-            child[c] = (int)j;
+            binOf[innerBase + (uint32_t)c] = ref;
         }
         for (int k = 0; k < 3; ++k) nb.lo[k] = fmin_(nb.lo[k], cb[c].lo[k]), nb.hi[k] = fmax_(nb.hi[k], cb[c].hi[k]);
     }
@@ -412,8 +405,8 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
     uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
     for (int c = 0; c < 4; ++c) {
         for (int k = 0; k < 3; ++k) {
-            uint32_t lo8 = 255u, hi8 = 0u; // empty child: inverted box, never hit
-            if (c < n) {
+            uint32_t lo8 = 255u, hi8 = 0u; // no child: inverted box (the traversal also checks the child count)
+            if (c < nValid) {
                 const float fl = floor_((cb[c].lo[k] - nb.lo[k]) * inv[k]);
                 const float fh = __builtin_ceilf((cb[c].hi[k] - nb.lo[k]) * inv[k]);
                 lo8 = (uint32_t)fmin_(fmax_(fl, 0.0f), 255.0f);
@@ -423,22 +416,25 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
             qhi[k] |= hi8 << (8 * c);
         }
     }
+    // child j >= nInner is triangle leafBase + (j - nInner): reference ~(leafBase - nInner + j) = ~(leafBase - nInner) - j
+    const int leafKey = ~((int)leafBase - nInner);
     Node4 nd;
-    nd.a = make_float4(nb.lo[0], nb.lo[1], nb.lo[2], __uint_as_float(e[0] | (e[1] << 8) | (e[2] << 16)));
-    nd.b = make_int4(child[0], child[1], child[2], child[3]);
-    nd.c = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
-    nd.d = make_uint4(qhi[1], qhi[2], 0u, 0u);
+    nd.a = make_float4(nb.lo[0], nb.lo[1], nb.lo[2],
+                       __uint_as_float(e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)nInner << 24) | ((uint32_t)nValid << 27)));
+    nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+    nd.c = make_uint4(qhi[1], qhi[2], innerBase, (uint32_t)leafKey);
+    nd.d = make_uint4(0u, 0u, 0u, 0u);
     out[i] = nd;
 }
 
-int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, int kLeafMax, BuildResult *out)
+int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, BuildResult *out)
 {
     out->nodes = nullptr, out->tris = nullptr, out->nNodes = 0, out->rootLeafCount = 0;
     if (n == 0) return 0;
     if (n >= (1u << 28)) return 2;
     const uint32_t nBlocks = (n + kSortTile - 1) / kSortTile;
-    uint32_t *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr, *blockHist = nullptr, *flags = nullptr, *stamp = nullptr,
-             *total = nullptr;
+    uint32_t *keysA = nullptr, *keysB = nullptr, *valsA = nullptr, *valsB = nullptr, *blockHist = nullptr, *stamp = nullptr, *total = nullptr;
+    Tri *finalTris = nullptr;
     KNode *knodes = nullptr;
     Box6 *leafBox = nullptr, *nodeBox = nullptr;
     Tri *sorted = nullptr;
@@ -449,7 +445,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     HR_CHECK(hipMalloc(&blockHist, 4ull * 256 * nBlocks));
     HR_CHECK(hipMalloc(&sorted, sizeof(Tri) * (size_t)n));
     HR_CHECK(hipMalloc(&leafBox, sizeof(Box6) * (size_t)n));
-    HR_CHECK(hipMalloc(&total, 4));
+    HR_CHECK(hipMalloc(&total, 8)); // [0] nodes appended, [1] triangles placed
     const v3 vlo(lo[0], lo[1], lo[2]);
     const v3 ext(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
     const uint32_t g256 = (n + 255) / 256;
@@ -464,7 +460,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     }
     hipLaunchKernelGGL(k_gather_tris, dim3(g256), dim3(256), 0, st, trisPrim, valsA, n, sorted, pad, leafBox);
     int rc = 0;
-    if (n <= (uint32_t)kLeafMax) {
+    if (n <= 1u) { // a single triangle: the root is a leaf
         out->rootLeafCount = (int)n;
     } else {
         const int nInternal = (int)n - 1;
@@ -472,7 +468,6 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         HR_CHECK(hipMalloc(&knodes, sizeof(KNode) * (size_t)nInternal));
         HR_CHECK(hipMalloc(&nodeBox, sizeof(Box6) * (size_t)nInternal));
         HR_CHECK(hipMalloc(&stamp, 4ull * nInternal));
-        HR_CHECK(hipMalloc(&flags, 4ull * nInternal));
         HR_CHECK(hipMemsetAsync(stamp, 0, 4ull * nInternal, st));
         hipLaunchKernelGGL(k_karras, dim3(gi), dim3(256), 0, st, keysA, (int)n, knodes);
         // tree height <= 30 key bits + 28 index bits; check the root every 16 rounds
@@ -489,25 +484,20 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
             HR_CHECK(hipStreamSynchronize(st));
         }
         if (rootStamp == 0) rc = 3;
-        // upper bound of the 4-wide node count: binary nodes with more than kLeafMax triangles
-        hipLaunchKernelGGL(k_flag_internal, dim3(gi), dim3(256), 0, st, knodes, nInternal, kLeafMax, flags);
-        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, st, flags, (uint32_t)nInternal, total);
-        uint32_t nMax = 0;
-        HR_CHECK(hipMemcpyAsync(&nMax, total, 4, hipMemcpyDeviceToHost, st));
-        HR_CHECK(hipStreamSynchronize(st));
-        if (nMax == 0) nMax = 1;
+        const uint32_t nMax = (uint32_t)nInternal; // every 4-wide node stands for one binary inner node
+        HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)n));
         int *binOf = nullptr;
         HR_CHECK(hipMalloc(&out->nodes, sizeof(Node4) * (size_t)nMax));
         HR_CHECK(hipMalloc(&binOf, 4ull * nMax));
         const int rootBin = 0;
-        const uint32_t one = 1;
+        const uint32_t init[2] = {1u, 0u};
         HR_CHECK(hipMemcpyAsync(binOf, &rootBin, 4, hipMemcpyHostToDevice, st));
-        HR_CHECK(hipMemcpyAsync(total, &one, 4, hipMemcpyHostToDevice, st));
+        HR_CHECK(hipMemcpyAsync(total, init, 8, hipMemcpyHostToDevice, st));
         uint32_t levelStart = 0, levelEnd = 1;
         for (int level = 0; level < 64 && levelEnd > levelStart; ++level) {
             const uint32_t cnt = levelEnd - levelStart;
-            hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, kLeafMax,
-                               total, out->nodes);
+            hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, total,
+                               total + 1, sorted, finalTris, out->nodes);
             uint32_t newEnd = 0;
             HR_CHECK(hipMemcpyAsync(&newEnd, total, 4, hipMemcpyDeviceToHost, st));
             HR_CHECK(hipStreamSynchronize(st));
@@ -520,14 +510,18 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         }
         hipFree(binOf);
         out->nNodes = (int)levelEnd;
+        uint32_t placed = 0;
+        HR_CHECK(hipMemcpyAsync(&placed, total + 1, 4, hipMemcpyDeviceToHost, st));
+        HR_CHECK(hipStreamSynchronize(st));
+        if (placed != n && rc == 0) rc = 5; // every triangle is the leaf of exactly one node
     }
-    out->tris = sorted;
+    out->tris = finalTris ? finalTris : sorted;
     HR_CHECK(hipStreamSynchronize(st));
     hipFree(keysA), hipFree(keysB), hipFree(valsA), hipFree(valsB), hipFree(blockHist), hipFree(leafBox), hipFree(total);
     if (knodes) hipFree(knodes);
     if (nodeBox) hipFree(nodeBox);
     if (stamp) hipFree(stamp);
-    if (flags) hipFree(flags);
+    if (finalTris) hipFree(sorted);
     if (hipGetLastError() != hipSuccess) return 1;
     return rc;
 }

@@ -175,8 +175,8 @@ struct hr_ctx {
     }
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
-    // tuning knobs (defaults measured on MI355X; HR_TUNE="leaf=1,tri=4,refill=8,blocks=8,depth=12" overrides for experiments)
-    int tuneLeaf = 1, tuneTri = 4, tuneRefill = 8, tuneBlocks = 6, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64;
+    // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
+    int tuneTri = 4, tuneRefill = 8, tuneBlocks = 6, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64;
     LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, 8, collectStats}; }
 };
 
@@ -268,9 +268,8 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             const char *p = strstr(t, key);
             if (p) dst = atoi(p + strlen(key));
         };
-        get("leaf=", c->tuneLeaf), get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
+        get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        if (c->tuneLeaf < 1 || c->tuneLeaf > 4) c->tuneLeaf = 1;
         get("groups=", c->nGroups);
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->nGroups < 1 || c->nGroups > kMaxGroups) c->nGroups = 1;
@@ -557,7 +556,7 @@ int hr_scene_commit(hr_ctx *c)
         const float diag = sqrtf(ex * ex + ey * ey + ez * ez);
         const float pad = 1e-5f * diag;
         BuildResult br{};
-        const int rc = buildLBVH(c->stream, trisPrim, nTris, lo, hi, pad, c->tuneLeaf, &br);
+        const int rc = buildLBVH(c->stream, trisPrim, nTris, lo, hi, pad, &br);
         hipFree(dF), hipFree(dI), hipFree(dG), hipFree(trisPrim);
         if (rc != 0) {
             hipFree(br.nodes), hipFree(br.tris);

@@ -88,7 +88,7 @@ struct BuildResult {
 void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t nTris, Tri *trisPrimOrder, TriAttr *attrs, TriAttrExt *ext,
                     uint32_t *boundsOrdered);
 // Full LBVH build from assembled triangles; allocates scratch internally; returns device arrays (hipMalloc).
-int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad, int leafMax,
+int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad,
               BuildResult *out);
 
 void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, int radial, float2 *out);

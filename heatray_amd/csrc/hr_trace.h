@@ -15,7 +15,10 @@
 
 namespace hr {
 
-static const int kStackLDS = 16;   // entries per lane kept in LDS (power of two)
+#ifndef HR_STACK_LDS
+#define HR_STACK_LDS 16
+#endif
+static const int kStackLDS = HR_STACK_LDS; // entries per lane kept in LDS
 static const int kStackOvf = 80;   // private overflow: a 4-wide node pushes up to 3 entries per level, binary depth <= 58 -> <= 29 levels
 static const int kSentinel = 0x7FFFFFFF;
 static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
@@ -58,25 +61,38 @@ HRD void cswap(uint32_t &a, uint32_t &b)
 
 // One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that
 // is hit and push the others farthest first (so the nearer one pops first); pop when nothing is hit.
+// Nodes below index nTop (the top levels: nodes are numbered level by level) are read from the workgroup's LDS copy
+// instead of through the vector memory pipeline.
 HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim,
-                   bool anyHit = false)
+                   bool anyHit = false, const float4 *top = nullptr, int nTop = 0)
 {
-    const Node4 &n = nodes[cur];
-    const float4 a = n.a;
-    const int4 refs = n.b;
-    const uint4 qc = n.c, qd = n.d;
-    const uint32_t eb = __float_as_uint(a.w);
+    float4 a;
+    uint4 qb, qc;
+    if (cur < nTop) {
+        const float4 *p = top + cur * 4;
+        const float4 t1 = p[1], t2 = p[2];
+        a = p[0];
+        qb = make_uint4(__float_as_uint(t1.x), __float_as_uint(t1.y), __float_as_uint(t1.z), __float_as_uint(t1.w));
+        qc = make_uint4(__float_as_uint(t2.x), __float_as_uint(t2.y), __float_as_uint(t2.z), __float_as_uint(t2.w));
+    } else {
+        const Node4 &n = nodes[cur];
+        a = n.a;
+        qb = n.b;
+        qc = n.c;
+    }
+    const uint32_t meta = __float_as_uint(a.w);
+    const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
+    const int innerBase = (int)qc.z, leafKey = (int)qc.w;
     // t = (origin + q * scale - o) / d = q * (scale / d) + (origin / d - o / d)
-    const float bx = __uint_as_float((eb & 0xFFu) << 23) * rk.idx;
-    const float by = __uint_as_float(((eb >> 8) & 0xFFu) << 23) * rk.idy;
-    const float bz = __uint_as_float(((eb >> 16) & 0xFFu) << 23) * rk.idz;
+    const float bx = __uint_as_float((meta & 0xFFu) << 23) * rk.idx;
+    const float by = __uint_as_float(((meta >> 8) & 0xFFu) << 23) * rk.idy;
+    const float bz = __uint_as_float(((meta >> 16) & 0xFFu) << 23) * rk.idz;
     const float ax = __builtin_fmaf(a.x, rk.idx, -rk.oix), ay = __builtin_fmaf(a.y, rk.idy, -rk.oiy), az = __builtin_fmaf(a.z, rk.idz, -rk.oiz);
-    const int rr[4] = {refs.x, refs.y, refs.z, refs.w};
     // the sign of the direction decides which quantised plane is the entry and which the exit plane of each slab
     // (chosen once per node on whole dwords: byte j belongs to child j)
-    const uint32_t nX = rk.idx < 0.0f ? qc.w : qc.x, fX = rk.idx < 0.0f ? qc.x : qc.w;
-    const uint32_t nY = rk.idy < 0.0f ? qd.x : qc.y, fY = rk.idy < 0.0f ? qc.y : qd.x;
-    const uint32_t nZ = rk.idz < 0.0f ? qd.y : qc.z, fZ = rk.idz < 0.0f ? qc.z : qd.y;
+    const uint32_t nX = rk.idx < 0.0f ? qb.w : qb.x, fX = rk.idx < 0.0f ? qb.x : qb.w;
+    const uint32_t nY = rk.idy < 0.0f ? qc.x : qb.y, fY = rk.idy < 0.0f ? qb.y : qc.x;
+    const uint32_t nZ = rk.idz < 0.0f ? qc.y : qb.z, fZ = rk.idz < 0.0f ? qb.z : qc.y;
     uint32_t key[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -86,7 +102,7 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
         const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
         const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
         // entry distance (>= tmin >= 0, so its bits order like the value) with the child slot in the two low bits
-        key[c] = (tn <= tf && rr[c] != kEmptyChild) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+        key[c] = (tn <= tf && (uint32_t)c < nValid) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
     }
     // sorting network: ascending entry distance, misses (0xFFFFFFFF) last
     cswap(key[0], key[1]), cswap(key[2], key[3]), cswap(key[0], key[2]), cswap(key[1], key[3]), cswap(key[1], key[2]);
@@ -94,8 +110,8 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
     int ref[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t sl = key[j] & 3u;
-        ref[j] = (sl & 2u) ? ((sl & 1u) ? rr[3] : rr[2]) : ((sl & 1u) ? rr[1] : rr[0]);
+        const int sl = (int)(key[j] & 3u);
+        ref[j] = ((uint32_t)sl < nInner) ? innerBase + sl : leafKey - sl; // (a miss computes a value nobody uses)
     }
     if (sp <= kStackLDS - 3) {
         // common case, branch-free: store the three farther children farthest first and advance the stack pointer only
@@ -109,7 +125,7 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
         const bool any = key[0] != 0xFFFFFFFFu;
         const bool empty = !any && sp == 0;
         sp -= (!any && sp > 0) ? 1 : 0;
-        const int popped = stackLane[(sp & (kStackLDS - 1)) * 64]; // sp <= kStackLDS: stays inside the LDS part (value unused when sp == kStackLDS)
+        const int popped = stackLane[(sp < kStackLDS - 1 ? sp : kStackLDS - 1) * 64]; // stays inside the LDS part (value unused when sp == kStackLDS)
         cur = any ? ref[0] : (empty ? kSentinel : popped);
     } else {
         // deep stack: entries beyond kStackLDS live in the private overflow area

@@ -8,18 +8,21 @@ namespace hr {
 
 // ---- acceleration structure -------------------------------------------------------------------
 // 4-wide BVH node, child boxes quantised to 8 bits per plane against the node's own box: one 64-byte,
-// 64-byte-aligned record = four dwordx4 loads for FOUR child boxes (16 B per child instead of 32 B).
-//   a = (origin.x, origin.y, origin.z, exponent bits ex | ey << 8 | ez << 16)   scale_k = as_float(e_k << 23)
-//   b = child references c0..c3: >= 0 node index; < 0 leaf ~(first | (count-1) << 28); kEmptyChild = no child
-//   c = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   byte j of each dword belongs to child j
-//   d = (qhi.y[4], qhi.z[4], -, -)
+// 64-byte-aligned record (never straddles a cache line) of which THREE dwordx4 loads are used.
+//   a = (origin.x, origin.y, origin.z, meta)    meta = ex | ey << 8 | ez << 16 | nInner << 24 | nValid << 27,
+//                                               scale_k = as_float(e_k << 23)
+//   b = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   byte j of each dword belongs to child j
+//   c = (qhi.y[4], qhi.z[4], innerBase, leafKey)
+//   d = unused
 // child box = origin + q * scale, with qlo rounded down and qhi rounded up (conservative).
+// Children 0 .. nInner-1 are the inner nodes innerBase + j: the children of one node are allocated together, so
+// siblings — which a ray tends to visit together — share 128-byte cache lines.  Children nInner .. nValid-1 are single
+// triangles, also stored together: the reference of child j is ~(triangle index) = leafKey - j.
+// A reference >= 0 is a node index; < 0 is a leaf ~(first | (count-1) << 28) (count > 1 only for a root leaf).
 struct alignas(64) Node4 {
     float4 a;
-    int4 b;
-    uint4 c, d;
+    uint4 b, c, d;
 };
-static const int kEmptyChild = 0x7FFFFFFF;
 
 // World-space triangle in BVH leaf order, 48 bytes = three dwordx4 loads:
 //   p = (v0.x v0.y v0.z e1.x)  q = (e1.y e1.z e2.x e2.y)  r = (e2.z, prim id, flags, -)

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel trace + separate PMC passes of the default bench.
+#   tools/profile.sh <tag> [bench args...]      -> gpurun_out/prof_<tag>/{trace,fetch,write,tcc,sq}/  + bench_<tag>.json
+# Afterwards, in the repo:  python tools/summarize_profile.py <tag>   -> profiles/<tag>_*
+set -e
+tag="$1"; shift
+ARGS="--cpu-seconds 0 --no-stats-pass --warmup 0 $*"
+ROOT="$PWD"
+OUT="$ROOT/gpurun_out/prof_$tag"
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+cd "$ROOT"
+python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
+echo "[profile] plain bench done"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+echo "[profile] kernel trace done"
+for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum" "sq:SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
+  name="${pass%%:*}"; ctrs="${pass#*:}"
+  rocprofv3 --kernel-trace --pmc $ctrs -d "$OUT/$name" -o "$name" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.err" || { echo "[profile] pass $name failed"; tail -5 "$OUT/$name.err"; }
+  echo "[profile] pmc pass $name done"
+done
+# keep the merge small: only the csv summaries travel back
+find "$OUT" -type f ! -name '*.csv' ! -name '*.json' ! -name '*.err' -delete
+find "$OUT" -name '*kernel_trace.csv' -size +20M -delete
+du -sh "$OUT"

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_sweep.sh "leaf=4,tri=20" "leaf=2,tri=20" ...   (runs bench per HR_TUNE setting, prints one line each)
+# usage: tools/sweep.sh "leaf=4,tri=20" "leaf=2,tri=20" ...   (runs bench per HR_TUNE setting, prints one line each)
 for t in "$@"; do
   HR_TUNE="$t" python bench.py --cpu-seconds 0 --steps ${STEPS:-16} ${EXTRA} 2>/dev/null | python -c "
 import json,sys
