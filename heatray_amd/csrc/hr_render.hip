@@ -25,7 +25,7 @@
 namespace hr {
 
 #ifndef HR_NODE_STEPS
-#define HR_NODE_STEPS 4 // inner-node steps per round of the trace loop
+#define HR_NODE_STEPS 6 // inner-node steps per round of the trace loop
 #endif
 static const int kBlock = 256;
 static const int kWavesPerBlock = kBlock / 64;
@@ -159,37 +159,14 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
     __syncthreads();
 }
 
-#ifndef HR_TOP_NODES
-#define HR_TOP_NODES 341 // 1 + 4 + 16 + 64 + 256: five full levels of the 4-wide tree, 21.8 KB of LDS per workgroup
-#endif
-
-#ifdef HR_LANEPROF
-// Experiment builds only (tools/build_variant.sh ... -DHR_LANEPROF): where do k_trace's wave-instruction slots go?
-__device__ unsigned long long g_laneprof[16];
-#define LP_ADD(i, v) lp[i] += (unsigned long long)(v)
-#else
-#define LP_ADD(i, v)
-#endif
-
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
                                                   StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ int stack[kWavesPerBlock][kStackLDS][64];
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
-#if HR_TOP_NODES > 0
-    __shared__ float4 topNodes[HR_TOP_NODES * 4]; // the first levels of the tree (nodes are numbered level by level)
-#endif
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
-#if HR_TOP_NODES > 0
-    const int nTop = S.nNodes < HR_TOP_NODES ? S.nNodes : HR_TOP_NODES;
-    for (int i = threadIdx.x; i < nTop * 4; i += kBlock) topNodes[i] = reinterpret_cast<const float4 *>(nodes)[i];
-    const float4 *top = topNodes;
-#else
-    const int nTop = 0;
-    const float4 *top = nullptr;
-#endif
     buildSegStarts(tbl, segStart, false);
     const int nSeg2 = 2 * tbl->nSeg;
     const uint32_t total = segStart[nSeg2];
@@ -197,6 +174,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     int *stackLane = &stack[wave][0][lane];
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const int kRefill = tbl->refillLanes, kTriPhase = tbl->triPhaseLanes;
+    const uint32_t fetchMax = (uint32_t)tbl->fetchMax, fetchMin = (uint32_t)tbl->fetchMin;
+    const uint32_t wavesTimes2 = 2u * gridDim.x * kWavesPerBlock;
+    uint32_t lastBase = 0; // wave-uniform: where the global cursor stood at this wave's previous reservation
 
     // ---- per-lane traversal state (one ray per lane, refilled from the work pool when a lane finishes)
     int cur = kSentinel, sp = 0;
@@ -212,93 +192,75 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     const float tmin = S.rayEps;
     const int rootRef = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
 
+    uint32_t poolLo = 0, poolHi = 0; // wave-uniform: indices this wave has reserved and not handed out yet
+    bool exhausted = false;          // wave-uniform: the global cursor ran past the end
     uint32_t nvC = 0, ntC = 0, nvA = 0, ntA = 0, nacc = 0;
 
-    // ---- staging: the wave's next (up to) 64 work items, loaded AHEAD of use.  A wave reserves 64 consecutive items
-    // with one atomic, every lane loads one of them (coalesced, nobody waits for the data yet), and idle lanes later pick
-    // staged rays up with cross-lane moves.  The reservation for the chunk after that is already in flight as well.
-    uint32_t stBase = 0, stCount = 0, stTaken = 0; // wave-uniform: first item, items staged, items handed out
-    bool more = true;                              // wave-uniform: the global cursor has not run past the end yet
-    uint32_t nextBase = 0;                         // lane 0: reservation issued ahead
-    float4 stA = make_float4(0, 0, 0, 0), stB = make_float4(0, 0, 0, 0);
-    uint32_t stSkip = 0, stLocal = 0;
-    int stSeg = 0;
-    if (lane == 0) nextBase = atomicAdd(&tbl->traceHead, 64u);
-    auto stage = [&]() {
-        const uint32_t base = (uint32_t)__shfl((int)nextBase, 0);
-        stTaken = 0;
-        if (base >= total) {
-            more = false;
-            stCount = 0;
-            return;
-        }
-        stBase = base;
-        stCount = (total - base < 64u) ? total - base : 64u;
-        if (lane < stCount) {
-            const uint32_t it = base + lane;
-            int sI = 0, sHiB = nSeg2 - 1; // last queue whose first index is <= it (at most 2*kMaxSegs entries)
-            while (sI < sHiB) {
-                const int mid = (sI + sHiB + 1) >> 1;
-                if (it >= segStart[mid])
-                    sI = mid;
-                else
-                    sHiB = mid - 1;
-            }
-            stSeg = sI;
-            stLocal = it - segStart[sI];
-            const SegDev &sg = tbl->seg[sI >> 1];
-            if (sI & 1) { // occlusion ray
-                stA = sg.sq.A[stLocal], stB = sg.sq.B[stLocal];
-                stSkip = __float_as_uint(stB.w);
-            } else {
-                stA = sg.qin.A[stLocal], stB = sg.qin.B[stLocal];
-                stSkip = (uint32_t)sg.qin.D[stLocal].z;
-            }
-        }
-        if (lane == 0) nextBase = atomicAdd(&tbl->traceHead, 64u);
-    };
-    stage();
-
     int pend = 0; // postponed leaf (a negative leaf reference) or 0: the lane keeps descending while a leaf waits
-#ifdef HR_LANEPROF
-    unsigned long long lp[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
     for (;;) {
-        LP_ADD(7, 1);
-        // ---------------- refill idle lanes from the staged rays (persistent threads with dynamic fetch)
+        // ---------------- refill idle lanes (persistent threads with dynamic fetch)
         bool idle = (item == 0xFFFFFFFFu);
         unsigned long long idleMask = __ballot(idle);
         int nIdle = __popcll(idleMask);
-        if (stTaken < stCount && (nIdle >= kRefill || nIdle == 64)) {
-            LP_ADD(5, 1);
-            LP_ADD(6, nIdle);
-            const uint32_t avail = stCount - stTaken;
-            const uint32_t rank = (uint32_t)__popcll(idleMask & ltMask);
-            const uint32_t take = avail < (uint32_t)nIdle ? avail : (uint32_t)nIdle;
-            const int src = (int)((stTaken + rank) & 63u);
-            const float ax = __shfl(stA.x, src), ay = __shfl(stA.y, src), az = __shfl(stA.z, src), aw = __shfl(stA.w, src);
-            const float bx = __shfl(stB.x, src), by = __shfl(stB.y, src), bz = __shfl(stB.z, src);
-            const uint32_t sk = (uint32_t)__shfl((int)stSkip, src), lo = (uint32_t)__shfl((int)stLocal, src);
-            const int sg = __shfl(stSeg, src);
-            if (idle && rank < take) {
-                item = stBase + stTaken + rank;
-                segIdx = sg, local = lo, skipPrim = sk;
-                o = v3(ax, ay, az), d = v3(bx, by, bz);
-                tmax = aw, tlim = aw;
-                idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
-                oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
-                best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
-                sp = 0;
-                pend = 0;
-                cur = rootRef;
-                idle = false;
+        if (!exhausted && (nIdle >= kRefill || nIdle == 64)) {
+            for (int round = 0; round < 2 && nIdle > 0; ++round) {
+                if (poolLo == poolHi) { // reserve another chunk of the global index space
+                    // chunk ~ (work left) / (2 x waves), from the cursor value this wave saw last (any size is valid)
+                    uint32_t chunk = (total - lastBase) / wavesTimes2;
+                    chunk = chunk > fetchMax ? fetchMax : (chunk < fetchMin ? fetchMin : chunk);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&tbl->traceHead, chunk);
+                    base = __shfl(base, 0);
+                    if (base >= total) {
+                        exhausted = true;
+                        break;
+                    }
+                    lastBase = base;
+                    poolLo = base;
+                    poolHi = (base + chunk < total) ? base + chunk : total;
+                }
+                const uint32_t avail = poolHi - poolLo;
+                const uint32_t rank = (uint32_t)__popcll(idleMask & ltMask);
+                if (idle && rank < avail) {
+                    item = poolLo + rank;
+                    // which queue does the item belong to (at most 2*kMaxSegs entries)
+                    int sI = 0, sHiB = nSeg2 - 1; // last queue whose first index is <= item
+                    while (sI < sHiB) {
+                        const int mid = (sI + sHiB + 1) >> 1;
+                        if (item >= segStart[mid])
+                            sI = mid;
+                        else
+                            sHiB = mid - 1;
+                    }
+                    segIdx = sI;
+                    local = item - segStart[sI];
+                    const SegDev &sg = tbl->seg[sI >> 1];
+                    float4 a, b;
+                    if (sI & 1) { // occlusion ray
+                        a = sg.sq.A[local], b = sg.sq.B[local];
+                        skipPrim = __float_as_uint(b.w);
+                    } else {
+                        a = sg.qin.A[local], b = sg.qin.B[local];
+                        skipPrim = (uint32_t)sg.qin.D[local].z;
+                    }
+                    o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
+                    tmax = a.w, tlim = a.w;
+                    idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
+                    oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
+                    best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
+                    sp = 0;
+                    pend = 0;
+                    cur = rootRef;
+                    idle = false;
+                }
+                const uint32_t taken = avail < (uint32_t)nIdle ? avail : (uint32_t)nIdle;
+                poolLo += taken;
+                idleMask = __ballot(idle);
+                nIdle = __popcll(idleMask);
             }
-            stTaken += take;
-            if (stTaken == stCount && more) stage(); // loads and the next reservation fly while the wave traverses
-            nIdle -= (int)take;
         }
         if (nIdle == 64) { // nothing in flight (finished rays were retired at the end of the previous round)
-            if (stTaken == stCount && !more) break;
+            if (exhausted) break;
             continue;
         }
 
@@ -306,18 +268,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         // ---------------- inner-node steps for every lane that holds an inner node
 #pragma unroll
         for (int rep = 0; rep < HR_NODE_STEPS; ++rep) {
-#ifdef HR_LANEPROF
-            {
-                const unsigned long long am = __ballot(cur >= 0 && cur != kSentinel);
-                if (am) {
-                    LP_ADD(0, 1);
-                    LP_ADD(1, __popcll(am));
-                    if (__ballot(cur >= 0 && cur != kSentinel && sp > kStackLDS - 3)) LP_ADD(8, 1);
-                }
-                LP_ADD(10, __popcll(__ballot(item != 0xFFFFFFFFu)));
-                LP_ADD(11, 1);
-            }
-#endif
             if (cur >= 0 && cur != kSentinel) {
                 if (STATS) {
                     if (isAny)
@@ -326,7 +276,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                         ++nvC;
                 }
                 const RayK rk{idx, idy, idz, oix, oiy, oiz};
-                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny, top, nTop);
+                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny);
             }
             // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
             // postponed it is blocked until the wave runs the triangle phase
@@ -339,8 +289,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         const unsigned long long blockedMask = __ballot(pend != 0 && (cur < 0 || cur == kSentinel));
         const unsigned long long nodeMask = __ballot(cur >= 0 && cur != kSentinel);
         if (blockedMask != 0ull && (__popcll(blockedMask) >= kTriPhase || nodeMask == 0ull)) {
-            LP_ADD(2, 1);
-            LP_ADD(3, __popcll(__ballot(pend != 0)));
             if (pend != 0) {
                 const int enc = ~pend;
                 const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
@@ -387,15 +335,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
             }
         }
         // ---------------- retire finished rays
-#ifdef HR_LANEPROF
-        {
-            const unsigned long long rm = __ballot(cur == kSentinel && pend == 0 && item != 0xFFFFFFFFu);
-            if (rm) {
-                LP_ADD(9, 1);
-                LP_ADD(12, __popcll(rm));
-            }
-        }
-#endif
         if (cur == kSentinel && pend == 0 && item != 0xFFFFFFFFu) {
             const SegDev &sg = tbl->seg[segIdx >> 1];
             if (isAny) {
@@ -414,11 +353,6 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         }
     }
 
-#ifdef HR_LANEPROF
-    if (lane == 0)
-        for (int i = 0; i < 16; ++i)
-            if (lp[i]) atomicAdd(&g_laneprof[i], lp[i]);
-#endif
     nacc = waveSum(nacc);
     if (lane == 0 && nacc) atomicAdd(&stats->accumulates, (unsigned long long)nacc);
     if (STATS) {
@@ -615,16 +549,3 @@ void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const floa
 size_t hitRecordSize() { return sizeof(HitRec); }
 
 } // namespace hr
-
-#ifdef HR_LANEPROF
-extern "C" int hr_debug_laneprof(unsigned long long *out16, int reset)
-{
-    hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(hr::g_laneprof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[16] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(hr::g_laneprof), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-#endif

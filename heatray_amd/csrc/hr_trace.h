@@ -61,25 +61,12 @@ HRD void cswap(uint32_t &a, uint32_t &b)
 
 // One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that
 // is hit and push the others farthest first (so the nearer one pops first); pop when nothing is hit.
-// Nodes below index nTop (the top levels: nodes are numbered level by level) are read from the workgroup's LDS copy
-// instead of through the vector memory pipeline.
 HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim,
-                   bool anyHit = false, const float4 *top = nullptr, int nTop = 0)
+                   bool anyHit = false)
 {
-    float4 a;
-    uint4 qb, qc;
-    if (cur < nTop) {
-        const float4 *p = top + cur * 4;
-        const float4 t1 = p[1], t2 = p[2];
-        a = p[0];
-        qb = make_uint4(__float_as_uint(t1.x), __float_as_uint(t1.y), __float_as_uint(t1.z), __float_as_uint(t1.w));
-        qc = make_uint4(__float_as_uint(t2.x), __float_as_uint(t2.y), __float_as_uint(t2.z), __float_as_uint(t2.w));
-    } else {
-        const Node4 &n = nodes[cur];
-        a = n.a;
-        qb = n.b;
-        qc = n.c;
-    }
+    const Node4 &n = nodes[cur];
+    const float4 a = n.a;
+    const uint4 qb = n.b, qc = n.c;
     const uint32_t meta = __float_as_uint(a.w);
     const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
     const int innerBase = (int)qc.z, leafKey = (int)qc.w;
