@@ -176,8 +176,8 @@ struct hr_ctx {
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
-    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64;
-    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, 8, collectStats}; }
+    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64;
+    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats}; }
 };
 
 #define FAIL(ctx, code, msg)  \
@@ -269,7 +269,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             if (p) dst = atoi(p + strlen(key));
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
-        get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
+        get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
         get("groups=", c->nGroups);
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->nGroups < 1 || c->nGroups > kMaxGroups) c->nGroups = 1;

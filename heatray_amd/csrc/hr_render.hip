@@ -376,8 +376,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
 }
 
 // ------------------------------------------------------------------------------------------- shade
-static const int kShadeBlock = 512; // queue slots are reserved once per workgroup and pass (fewer same-address atomics)
-__global__ __launch_bounds__(kShadeBlock) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
+#ifndef HR_SHADE_BLOCK
+#define HR_SHADE_BLOCK 256
+#endif
+#ifndef HR_SHADE_MINBLOCKS
+#define HR_SHADE_MINBLOCKS 4 // <= 128 VGPRs: four 256-thread workgroups per CU (measured best on MI355X; 5+ spills)
+#endif
+static const int kShadeBlock = HR_SHADE_BLOCK; // queue slots are reserved once per workgroup and pass (fewer same-address atomics)
+__global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
     __shared__ uint32_t scratch[2 + kShadeBlock / 64];
