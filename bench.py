@@ -16,6 +16,7 @@ checker — used here only as the reported baseline leg) timed on a bounded tile
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -56,8 +57,8 @@ def build_scene(name, width, height, passes):
 
 def cpu_baseline(sc, budget_s, lut):
     """The CPU oracle (kind "port") on the host cores, on a bounded sample of the same workload: an interleaved
-    1/world shard of the frame's 32x32 tiles, rendered for as many passes as fit the time budget (the shard is
-    sized from a one-pass probe so that the leg takes about `budget_s` seconds)."""
+    1/world shard of the frame's 32x32 tiles (sized from a one-second probe), rendered pass after pass until
+    `budget_s` seconds of CPU work are done."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     n_tiles = ((sc.width + 31) // 32) * ((sc.height + 31) // 32)
@@ -73,18 +74,19 @@ def cpu_baseline(sc, budget_s, lut):
         eng.clear()
         passes, t0 = 0, time.perf_counter()
         while True:
-            eng.render_pass(sc.options.pass_params(passes))
+            eng.render_pass(sc.options.pass_params(passes % max_passes))  # sample indices stay inside the tables
             passes += 1
             el = time.perf_counter() - t0
-            if el > budget or passes >= max_passes:
+            if el > budget:
                 break
         return eng.stats(), passes, el, build_s
 
     world = max(1, min(64, n_tiles))
     st, passes, el, build_s = run(world, 1.0)  # probe
     per_pass_full = el / passes * world
-    # shard so that max_passes passes take about budget_s (at least 1/64, at most the whole frame)
-    world = int(max(1, min(64, round(per_pass_full * max_passes / max(budget_s, 1e-3)))))
+    # shard so that one pass takes at most a quarter of the budget (at least 1/64 of the frame, at most all of it),
+    # then render passes until the budget is used up
+    world = int(max(1, min(64, math.ceil(per_pass_full / max(budget_s / 4.0, 1e-3)))))
     st, passes, el, build_s = run(world, budget_s)
     rays = st.rays_closest + st.rays_any
     return {
