@@ -122,9 +122,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("HR_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a one-GPU box (not a benchmark)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # HR_BENCH_FORCE_EXCHANGE: rehearsal of the N > 1 control flow (process group, per-step tile gather, final assembly) in a
+    # single process — RCCL refuses two ranks on one device, so this is how the path is exercised on a one-GPU box
+    forced = bool(os.environ.get("HR_BENCH_FORCE_EXCHANGE")) and world == 1
+    exchange = world > 1 or forced
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    elif world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
     emulated = args.shard_of > 1 and world == 1
@@ -137,11 +147,11 @@ def main():
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
     eng.bind_external_frame(fb.data_ptr())
-    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3) if world > 1 else None
+    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3) if exchange else None
 
     def step(i):
         eng.render_pass(sc.options.pass_params(i))
-        if world > 1:
+        if exchange:
             # Progressive display: every step each rank packs the pixels it owns (1/world of the RGBA32F buffer) and
             # RCCL gathers them on rank 0, on a side stream so the exchange overlaps the next pass's kernels.  The
             # buffer holds every pass whose last stage has run (passes still in the pipeline live in their own pass
@@ -152,7 +162,7 @@ def main():
         step(i)
     eng.clear()  # resets the accumulation buffer, the device counters and the kernel timers
     torch.cuda.synchronize()
-    if world > 1:
+    if exchange:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -160,11 +170,11 @@ def main():
         step(args.warmup + i)
     eng.flush()  # the pass pipeline keeps depth+2 passes in flight: enqueue their remaining stages
     full = fb
-    if world > 1:
+    if exchange:
         gatherer.post(fb)  # the finished image
         full = gatherer.finish()
     torch.cuda.synchronize()
-    if world > 1:
+    if exchange:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -173,7 +183,7 @@ def main():
     kt = eng.kernel_times()
     rays = torch.tensor([float(st.rays_closest + st.rays_any), float(st.paths), float(st.rays_closest)], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if exchange:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
@@ -247,7 +257,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "width": sc.width, "height": sc.height,
                        "max_ray_depth": sc.options.max_ray_depth, "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
-                       "sharding": f"32x32 pixel tiles round-robin over {world} GPU(s)" + ("; RCCL gather of the owned RGBA32F tiles to rank 0 every step, overlapped on a side stream" if world > 1 else ""),
+                       "sharding": f"32x32 pixel tiles round-robin over {world} GPU(s)" + ("; RCCL gather of the owned RGBA32F tiles to rank 0 every step, overlapped on a side stream" if exchange else ""),
                        "seed": hex(scenes.SEED)},
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -260,7 +270,7 @@ def main():
             out["emulated_shard_of"] = eng_world
             out["metric"] += f" [EMULATED rank 0 of {eng_world}, not a benchmark result]"
         print(json.dumps(out))
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
 
