@@ -249,6 +249,22 @@ def main():
                         "V": vt["V"], "T": vt["T"], "V_any": vt["V_any"], "T_any": vt["T_any"],
                         "vt_source": "cpu oracle, this run" if vt is cpu else "profiles/vt_spec.json"}
 
+        # the display resolve, outside the timed region: device-side displayGL.frag -> RGBA8
+        disp_ms = None
+        if not emulated:
+            shown = torch.empty((sc.height, sc.width), dtype=torch.int32, device=dev)
+            P = ffi.display_params(tonemapping_enabled=True)
+            eng.display_device(shown.data_ptr(), P, ffi.HR_DISPLAY_RGBA8)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                eng.display_device(shown.data_ptr(), P, ffi.HR_DISPLAY_RGBA8)
+            e1.record()
+            torch.cuda.synchronize()
+            disp_ms = e0.elapsed_time(e1) / 10.0
+            if world == 1:
+                assert int(shown.view(torch.uint8).reshape(sc.height, sc.width, 4)[..., 3].min().item()) == 255
+
         mrays = total_rays / elapsed / 1e6
         out = {
             "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3") else f"Mrays/s ({args.workload})",
@@ -264,6 +280,7 @@ def main():
             "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,
                       "rays_per_path": total_rays / max(total_paths, 1.0), "bvh_build_ms": info.build_ms,
                       "kernel_ms_rank0": {k: v[0] for k, v in kt.items()}, "kernel_launches_rank0": {k: v[1] for k, v in kt.items()},
+                      "display_resolve_ms_rgba8": disp_ms,
                       "gpu_traversal_counters": gpu_counts},
         }
         if emulated:

@@ -116,6 +116,25 @@ class KernelTimes(C.Structure):
     _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4)]
 
 
+class DisplayParams(C.Structure):
+    """hr_display_params: HeatrayRenderer.h:104-117 PostProcessingParams as DisplayProgram::bind uploads them."""
+    _fields_ = [("tonemapping_enabled", C.c_int32), ("camera_exposure", C.c_float), ("brightness", C.c_float),
+                ("contrast", C.c_float), ("hue", C.c_float), ("saturation", C.c_float), ("vibrance", C.c_float),
+                ("red", C.c_float), ("green", C.c_float), ("blue", C.c_float), ("vignette_intensity", C.c_float),
+                ("vignette_falloff", C.c_float)]
+
+
+def display_params(tonemapping_enabled=False, exposure=0.0, brightness=0.0, contrast=1.0, hue=1.0, saturation=1.0,
+                   vibrance=0.0, red=1.0, green=1.0, blue=1.0, vignette_intensity=0.0, vignette_falloff=1.0):
+    """Defaults = the reference's PostProcessingParams defaults; camera_exposure = 2^exposure (computed in binary32 by
+    repeated doubling / halving for integral exposures, else through numpy's float32 power, as std::powf would)."""
+    return DisplayParams(int(bool(tonemapping_enabled)), float(np.float32(2.0) ** np.float32(exposure)), brightness, contrast, hue,
+                         saturation, vibrance, red, green, blue, vignette_intensity, vignette_falloff)
+
+
+HR_DISPLAY_RGBA8, HR_DISPLAY_RGBA32F, HR_DISPLAY_HDR_RGBA32F = 0, 1, 2
+
+
 class Hit(C.Structure):
     _fields_ = [("prim", C.c_int32), ("t", C.c_float), ("u", C.c_float), ("v", C.c_float)]
 
@@ -129,6 +148,7 @@ ABI_SYMBOLS = [
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
+    "display", "display_readback",
 ]
 
 
@@ -317,6 +337,22 @@ class Engine:
         w, h = C.c_int32(), C.c_int32()
         self._call("readback", C.byref(p), C.byref(w), C.byref(h))
         return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+
+    def display(self, params=None, fmt=HR_DISPLAY_RGBA8):
+        """Display resolve of the accumulation buffer -> numpy: uint8 [H, W, 4] (RGBA8) or float32 [H, W, 4]."""
+        params = params if params is not None else display_params()
+        dt, ch = (np.uint8, 4) if fmt == HR_DISPLAY_RGBA8 else (np.float32, 4)
+        p = C.c_void_p()
+        w, h = C.c_int32(), C.c_int32()
+        self._call("display_readback", C.byref(params), C.c_int32(fmt), C.byref(p), C.byref(w), C.byref(h))
+        n = w.value * h.value * ch
+        buf = (C.c_uint8 * n).from_address(p.value) if dt is np.uint8 else (C.c_float * n).from_address(p.value)
+        return np.frombuffer(buf, dtype=dt).reshape(h.value, w.value, ch).copy()
+
+    def display_device(self, device_ptr, params=None, fmt=HR_DISPLAY_RGBA8):
+        """Asynchronous display resolve into device memory (e.g. a torch tensor or a GL-interop buffer)."""
+        params = params if params is not None else display_params()
+        self._call("display", C.byref(params), C.c_int32(fmt), C.c_void_p(int(device_ptr)))
 
     def debug_trace(self, origins, dirs, tmax=None, skip_prim=None, any_hit=False):
         o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)

@@ -51,6 +51,8 @@ struct hr_ctx {
     float *fbInternal = nullptr, *fbExternal = nullptr;
     float *pinned = nullptr;
     size_t pinnedBytes = 0;
+    void *dDisplay = nullptr, *pinnedDisplay = nullptr; // display resolve: device staging + pinned host copy
+    size_t displayBytes = 0;
     FrameDev frame{};
     uint32_t queueCapacity = 0;
     // Pipeline of in-flight passes (hr_render.hip header): every slot owns the queues, hit records, counters and
@@ -308,6 +310,8 @@ int hr_ctx_destroy(hr_ctx *c)
     for (Texture &t : c->textures) hipFree(t.dpx);
     hipFree(c->fbInternal);
     if (c->pinned) hipHostFree(c->pinned);
+    hipFree(c->dDisplay);
+    if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
     hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero);
     for (hr_ctx::Group &G : c->groups) {
@@ -329,6 +333,48 @@ int hr_ctx_set_stream(hr_ctx *c, void *stream)
     ENTER(c);
     QUIESCE(c);
     c->stream = (hipStream_t)stream;
+    return HR_OK;
+}
+
+static size_t displayPixelBytes(int32_t format) { return format == HR_DISPLAY_RGBA8 ? 4 : 16; }
+
+int hr_display(hr_ctx *c, const hr_display_params *params, int32_t format, void *device_out)
+{
+    ENTER(c);
+    if (!params || !device_out) FAIL(c, HR_ERR_INVALID, "null argument");
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    if (format < HR_DISPLAY_RGBA8 || format > HR_DISPLAY_HDR_RGBA32F) FAIL(c, HR_ERR_INVALID, "unknown display format");
+    int rc = drainPipeline(c);
+    if (rc) return rc;
+    FrameDev fr = c->frame;
+    fr.fb = c->fb();
+    launchDisplay(c->cfg(c->stream), fr, *params, format, device_out);
+    HIP_TRY(c, hipGetLastError());
+    return HR_OK;
+}
+
+int hr_display_readback(hr_ctx *c, const hr_display_params *params, int32_t format, const void **pixels, int32_t *width, int32_t *height)
+{
+    ENTER(c);
+    if (!pixels) FAIL(c, HR_ERR_INVALID, "null output");
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    const size_t need = (size_t)c->W * c->H * 16;
+    if (c->displayBytes < need) {
+        hipFree(c->dDisplay);
+        if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
+        c->dDisplay = nullptr, c->pinnedDisplay = nullptr, c->displayBytes = 0;
+        HIP_TRY(c, hipMalloc(&c->dDisplay, need));
+        HIP_TRY(c, hipHostMalloc(&c->pinnedDisplay, need, hipHostMallocDefault));
+        c->displayBytes = need;
+    }
+    int rc = hr_display(c, params, format, c->dDisplay);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->W * c->H * displayPixelBytes(format);
+    HIP_TRY(c, hipMemcpyAsync(c->pinnedDisplay, c->dDisplay, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *pixels = c->pinnedDisplay;
+    if (width) *width = c->W;
+    if (height) *height = c->H;
     return HR_OK;
 }
 

@@ -59,6 +59,7 @@ struct StepTable {
 // ---- hr_render.hip
 void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, int segIdx, const FrameDev &fr, Stats *stats);
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbuf);
+void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out);
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,

@@ -191,4 +191,34 @@ HRD float exp_(float xx)
     return z * __uint_as_float((uint32_t)(n + 127) << 23);
 }
 
+// Cephes logf (single precision), x > 0 and normal (same operation order as oracle/oracle_math.h)
+HRD float log_(float xx)
+{
+    uint32_t bits = __float_as_uint(xx);
+    int e = (int)((bits >> 23) & 0xFFu) - 126; // xx = m * 2^e with m in [0.5, 1)
+    float x = __uint_as_float((bits & 0x807FFFFFu) | 0x3F000000u);
+    if (x < 0.707106781186547524f) {
+        e -= 1;
+        x = x + x - 1.0f;
+    } else {
+        x = x - 1.0f;
+    }
+    float z = x * x;
+    float y = ((((((((7.0376836292e-2f * x - 1.1514610310e-1f) * x + 1.1676998740e-1f) * x - 1.2420140846e-1f) * x + 1.4249322787e-1f) * x -
+                   1.6668057665e-1f) * x + 2.0000714765e-1f) * x - 2.4999993993e-1f) * x + 3.3333331174e-1f) * x * z;
+    const float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    z = x + y;
+    z = z + 0.693359375f * fe;
+    return z;
+}
+
+// pow of the display pipeline: exp(y * log(x)) for x > 0, 0 otherwise (see oracle/oracle_math.h)
+HRD float pow_(float x, float y)
+{
+    if (!(x > 1.17549435e-38f)) return 0.0f;
+    return exp_(y * log_(x));
+}
+
 } // namespace hr

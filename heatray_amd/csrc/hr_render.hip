@@ -19,6 +19,7 @@
 // live occlusion ray per pass, and the stages are stream-ordered), and k_resolve adds finished samples to
 // the accumulation buffer in pass order — reproducible bit for bit.
 #include "hr_kernels.h"
+#include "hr_display.h"
 #include "hr_shade.h"
 #include "hr_trace.h"
 
@@ -137,6 +138,32 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, const float *__
     float4 a = reinterpret_cast<float4 *>(fr.fb)[pixel];
     a.x = a.x + s.x, a.y = a.y + s.y, a.z = a.z + s.z, a.w = a.w + s.w;
     reinterpret_cast<float4 *>(fr.fb)[pixel] = a;
+}
+
+// ------------------------------------------------------------------------------------------ display
+// displayGL.frag on the accumulation buffer: one thread per pixel, row-major (coalesced 16-byte reads, 4- or 16-byte writes)
+__global__ __launch_bounds__(kBlock) void k_display(FrameDev fr, hr_display_params P, int format, void *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (uint32_t)(fr.W * fr.H)) return;
+    const int x = (int)(i % (uint32_t)fr.W), y = (int)(i / (uint32_t)fr.W);
+    const bool owned = (((y / fr.tile) * fr.tilesX + (x / fr.tile)) % fr.world) == fr.rank;
+    const float4 px = reinterpret_cast<const float4 *>(fr.fb)[i];
+    if (format == HR_DISPLAY_HDR_RGBA32F) { // saveScreenshot's HDR path (HeatrayRenderer.cpp:1633-1645)
+        float4 o = make_float4(0.0f, 0.0f, 0.0f, owned ? px.w : 0.0f);
+        if (owned && px.w != 0.0f) {
+            const float divisor = 1.0f / px.w;
+            o.x = px.x * divisor, o.y = px.y * divisor, o.z = px.z * divisor;
+        }
+        reinterpret_cast<float4 *>(out)[i] = o;
+        return;
+    }
+    float c[3] = {0.0f, 0.0f, 0.0f};
+    if (owned) displayFragment(px, ((float)x + 0.5f) / (float)fr.W, ((float)y + 0.5f) / (float)fr.H, P, c);
+    if (format == HR_DISPLAY_RGBA32F)
+        reinterpret_cast<float4 *>(out)[i] = make_float4(c[0], c[1], c[2], owned ? 1.0f : 0.0f);
+    else
+        reinterpret_cast<uint32_t *>(out)[i] = owned ? (toByte(c[0]) | (toByte(c[1]) << 8) | (toByte(c[2]) << 16) | 0xFF000000u) : 0u;
 }
 
 // -------------------------------------------------------------------------------------------- trace
@@ -543,6 +570,13 @@ void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, 
 {
     const int grid = cfg.numCUs * cfg.shadeBlocksPerCU;
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
+}
+
+void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out)
+{
+    const int n = fr.W * fr.H;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_display, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, fr, P, format, out);
 }
 
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,

@@ -14,6 +14,7 @@
 #include "RLTypes.h"
 
 #include <assert.h>
+#include <cmath>
 #include <memory>
 
 namespace openrl {
@@ -50,6 +51,36 @@ public:
     {
         assert(m_isMapped);
         m_isMapped = false;
+    }
+
+    // Extension: display-ready pixels straight from the device — displayGL.frag evaluated on the MI355X
+    // (divide by the sample count, ACES / colour controls / vignette / exposure, sRGB) instead of uploading the RGBA32F
+    // buffer through a PBO (HeatrayRenderer.cpp:328-344) and running the shader on the GL device.  Call it where
+    // setPixelData()/mapPixelData() are called (PassGenerator's worker thread, inside the completion callback).
+    // format: HR_DISPLAY_RGBA8 (4 x fewer bytes over PCIe), HR_DISPLAY_RGBA32F or HR_DISPLAY_HDR_RGBA32F (saveScreenshot).
+    // The pointer stays valid until the next resolveForDisplay(), resize or context destruction.
+    inline const void* resolveForDisplay(const hr_display_params& params, int32_t format = HR_DISPLAY_RGBA8)
+    {
+        const void* pixels = nullptr;
+        int32_t w = 0, h = 0;
+        if (HRFunc(hr_display_readback(currentContext(), &params, format, &pixels, &w, &h))) {
+            m_width = w;
+            m_height = h;
+        }
+        return pixels;
+    }
+
+    // PostProcessingParams (HeatrayRenderer.h:104-117) -> the uniforms DisplayProgram::bind uploads (HeatrayRenderer.h:222-248)
+    template <class PostProcessingParams>
+    static hr_display_params displayParams(const PostProcessingParams& p)
+    {
+        hr_display_params d{};
+        d.tonemapping_enabled = p.tonemapping_enabled ? 1 : 0;
+        d.camera_exposure = std::pow(2.0f, p.exposure);
+        d.brightness = p.brightness, d.contrast = p.contrast, d.hue = p.hue, d.saturation = p.saturation, d.vibrance = p.vibrance;
+        d.red = p.red, d.green = p.green, d.blue = p.blue;
+        d.vignette_intensity = p.vignetteIntensity, d.vignette_falloff = p.vignetteFalloff;
+        return d;
     }
 
     inline RLint size() const { return m_sizeInBytes; }

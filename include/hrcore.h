@@ -361,6 +361,34 @@ int hr_get_kernel_times(hr_ctx *ctx, hr_kernel_times *out);
 int hr_readback(hr_ctx *ctx, const float **rgba, int32_t *width, int32_t *height);
 int hr_synchronize(hr_ctx *ctx);
 
+/* ------------------------------------------------------------------ display resolve
+ * The step right after the path: the reference copies the RGBA32F accumulation buffer to the host
+ * (mapPixelData), uploads it through a PBO (HeatrayRenderer.cpp:328-344, 33 MB per displayed frame at 1080p)
+ * and runs Resources/shaders/displayGL.frag:74-151 on the GL device.  hr_display runs that fragment shader
+ * on the MI355X instead, straight from the accumulation buffer: divide by the sample count in alpha,
+ * optional ACES tonemapping, brightness / contrast, hue / saturation / vibrance, RGB levels, vignette,
+ * exposure, sRGB encoding — and hands over display-ready pixels (RGBA8: 4 x fewer bytes over PCIe). */
+typedef struct hr_display_params {            /* HeatrayRenderer.h:104-117 PostProcessingParams, as uploaded by */
+    int32_t tonemapping_enabled;              /* DisplayProgram::bind (HeatrayRenderer.h:222-248)               */
+    float camera_exposure;                    /* = 2^exposure (bind computes std::powf(2, exposure))             */
+    float brightness, contrast, hue, saturation, vibrance;
+    float red, green, blue;
+    float vignette_intensity, vignette_falloff;
+} hr_display_params;
+
+#define HR_DISPLAY_RGBA8 0       /* uint8 x 4, sRGB-encoded, alpha 255: what the GL framebuffer would hold        */
+#define HR_DISPLAY_RGBA32F 1     /* float x 4, the shader's fragColor before framebuffer conversion               */
+#define HR_DISPLAY_HDR_RGBA32F 2 /* float x 4, rgb * (1 / a), a unchanged: saveScreenshot's HDR path (.cpp:1624-1645) */
+
+/* Completes all enqueued passes, then writes width*height pixels (row 0 = bottom, like the accumulation
+ * buffer) to device memory `device_out` (asynchronous on the ctx stream). Pixels without samples (a == 0) give
+ * colour 0.  Pixels owned by other ranks of a tile-sharded frame are written as 0. */
+int hr_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *device_out);
+/* Same, into a pinned host buffer owned by the ctx (synchronous); valid until the next hr_display_readback /
+ * hr_frame_resize / hr_ctx_destroy.  Replaces the mapPixelData -> glBufferSubData upload of the HDR buffer. */
+int hr_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t format, const void **pixels, int32_t *width,
+                        int32_t *height);
+
 /* ------------------------------------------------------------------ debug */
 
 typedef struct hr_hit {

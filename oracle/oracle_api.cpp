@@ -15,6 +15,7 @@ using namespace ora;
 struct hr_ctx {
     Context c;
     int nThreads = 0;
+    std::vector<float> display; // ora_display_readback's buffer (16 bytes per pixel)
 };
 
 #define ORA_FAIL(ctx, code, msg) \
@@ -289,6 +290,26 @@ int ora_readback(hr_ctx *ctx, const float **rgba, int32_t *w, int32_t *h)
 {
     if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
     *rgba = ctx->c.fb.data();
+    if (w) *w = ctx->c.W;
+    if (h) *h = ctx->c.H;
+    return HR_OK;
+}
+int ora_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *out)
+{
+    if (!params || !out) ORA_FAIL(ctx, HR_ERR_INVALID, "null argument");
+    if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
+    if (format < HR_DISPLAY_RGBA8 || format > HR_DISPLAY_HDR_RGBA32F) ORA_FAIL(ctx, HR_ERR_INVALID, "unknown display format");
+    displayResolve(ctx->c, *params, format, out);
+    return HR_OK;
+}
+int ora_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t format, const void **pixels, int32_t *w, int32_t *h)
+{
+    if (!pixels) ORA_FAIL(ctx, HR_ERR_INVALID, "null output");
+    if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
+    ctx->display.resize((size_t)ctx->c.W * ctx->c.H * 4);
+    int rc = ora_display(ctx, params, format, ctx->display.data());
+    if (rc) return rc;
+    *pixels = ctx->display.data();
     if (w) *w = ctx->c.W;
     if (h) *h = ctx->c.H;
     return HR_OK;

@@ -114,4 +114,7 @@ bool alphaPasses(const Context &ctx, int prim, float u, float v); // alpha-mask 
 // ---- shading (oracle_shade.cpp) ----
 void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads);
 
+// oracle_display.cpp
+void displayResolve(const Context &ctx, const hr_display_params &P, int format, void *out);
+
 } // namespace ora

@@ -217,4 +217,38 @@ inline float exp_(float xx)
     return z * p;
 }
 
+// Cephes logf (single precision), x > 0 and normal; restated in plain float operations like exp_ above.
+inline float log_(float xx)
+{
+    uint32_t bits;
+    std::memcpy(&bits, &xx, 4);
+    int e = (int)((bits >> 23) & 0xFFu) - 126; // xx = m * 2^e with m in [0.5, 1)
+    bits = (bits & 0x807FFFFFu) | 0x3F000000u;
+    float x;
+    std::memcpy(&x, &bits, 4);
+    if (x < 0.707106781186547524f) {
+        e -= 1;
+        x = x + x - 1.0f;
+    } else {
+        x = x - 1.0f;
+    }
+    float z = x * x;
+    float y = ((((((((7.0376836292e-2f * x - 1.1514610310e-1f) * x + 1.1676998740e-1f) * x - 1.2420140846e-1f) * x + 1.4249322787e-1f) * x -
+                   1.6668057665e-1f) * x + 2.0000714765e-1f) * x - 2.4999993993e-1f) * x + 3.3333331174e-1f) * x * z;
+    const float fe = (float)e;
+    y = y + -2.12194440e-4f * fe;
+    y = y + -0.5f * z;
+    z = x + y;
+    z = z + 0.693359375f * fe;
+    return z;
+}
+
+// pow for the display pipeline (displayGL.frag: sRGB curves).  GLSL leaves pow's precision to the implementation; this
+// build defines it as exp(y * log(x)) for x > 0 and 0 for x <= 0 (y > 0 in every use).
+inline float pow_(float x, float y)
+{
+    if (!(x > 1.17549435e-38f)) return 0.0f;
+    return exp_(y * log_(x));
+}
+
 } // namespace ora

@@ -300,6 +300,13 @@ int main(int argc, char** argv)
 
     std::atomic<int> completed{0};
     std::vector<float> pixels;
+    std::vector<uint32_t> displayPixels;
+    // the viewer's PostProcessingParams (HeatrayRenderer.h:104-117), non-default values
+    struct {
+        bool tonemapping_enabled = true;
+        float exposure = 0.75f, brightness = 0.05f, contrast = 1.05f, hue = 1.0f, saturation = 1.3f, vibrance = 0.4f;
+        float red = 1.1f, green = 0.9f, blue = 1.0f, vignetteIntensity = 0.5f, vignetteFalloff = 0.4f;
+    } post;
     size_t lastIndex = 0;
     for (int p = 0; p < passes; ++p) {
         options.resetInternalState = (p == 0);
@@ -308,6 +315,10 @@ int main(int argc, char** argv)
             CHECK(results->width() == width && results->height() == height);
             const float* mapped = results->mapPixelData(); // left mapped, like the viewer does between frames
             pixels.assign(mapped, mapped + (size_t)width * height * 4);
+            // display-ready pixels from the device (the extension of SURVEY §8f row 1)
+            const uint32_t* shown = (const uint32_t*)results->resolveForDisplay(openrl::PixelPackBuffer::displayParams(post), HR_DISPLAY_RGBA8);
+            CHECK(shown != nullptr);
+            displayPixels.assign(shown, shown + (size_t)width * height);
             lastIndex = passIndex;
             CHECK(passTime >= 0.0f);
             completed++;
@@ -318,6 +329,9 @@ int main(int argc, char** argv)
 
     // dump what the oracle needs to replay this render exactly: the packed light block and the material rows
     dump(outDir + "/pixels.bin", pixels.data(), pixels.size() * sizeof(float));
+    dump(outDir + "/display.bin", displayPixels.data(), displayPixels.size() * sizeof(uint32_t));
+    const hr_display_params shownWith = openrl::PixelPackBuffer::displayParams(post);
+    dump(outDir + "/display_params.bin", &shownWith, sizeof(shownWith));
     dump(outDir + "/lights.bin", &renderer.scene()->lighting()->block(), sizeof(hr_lights));
     std::vector<hr_material> rows;
     std::vector<int32_t> rowIds;

@@ -79,3 +79,8 @@ def test_host_layer_render_matches_oracle(tmp_path, golden):
     assert (got[..., 3] == passes).all()
     nbad = int((got != want).any(axis=-1).sum())
     assert got.tobytes() == want.tobytes(), f"{nbad} differing pixels"
+    # PixelPackBuffer::resolveForDisplay (device-side displayGL.frag) of the same frame, with the test's PostProcessingParams
+    shown = np.fromfile(tmp_path / "display.bin", dtype=np.uint8).reshape(H, W, 4)
+    P = ffi.DisplayParams.from_buffer_copy(open(tmp_path / "display_params.bin", "rb").read())   # as the layer baked them
+    assert P.tonemapping_enabled == 1 and abs(P.camera_exposure - 2.0 ** 0.75) < 1e-6 and abs(P.vignette_falloff - 0.4) < 1e-7
+    assert shown.tobytes() == o.display(P, ffi.HR_DISPLAY_RGBA8).tobytes()

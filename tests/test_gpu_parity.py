@@ -375,3 +375,59 @@ def test_full_size_config3_properties(golden):
         own = ob[..., 3] > 0
         assert own.sum() in (32 * 32, 32 * 24)                 # 1080 = 33 * 32 + 24: the top tile row is cropped
         assert a[own].tobytes() == ob[own].tobytes()
+
+
+# ------------------------------------------------------------- display resolve
+DISPLAY_SETTINGS = [
+    dict(),                                                                     # the reference's defaults
+    dict(tonemapping_enabled=True),
+    dict(tonemapping_enabled=True, exposure=1.5, brightness=0.1, contrast=1.1, hue=0.9, saturation=1.7, vibrance=0.6,
+         red=1.2, green=0.8, blue=1.4, vignette_intensity=0.7, vignette_falloff=0.3),
+    dict(exposure=-3.0, brightness=-0.4, saturation=0.0, vignette_intensity=1.0, vignette_falloff=0.0),   # negative colours -> NaN paths
+]
+
+
+@pytest.mark.parametrize("k", range(len(DISPLAY_SETTINGS)))
+def test_display_resolve_bit_exact(golden, k):
+    sc = scenes.multi_material(200, 120, bounces=4, textured=True)
+    g, o, ge, oe = render_both(sc, 3, lut=golden["multiscatter_lut"])
+    assert g.tobytes() == o.tobytes()
+    P = ffi.display_params(**DISPLAY_SETTINGS[k])
+    for fmt in (ffi.HR_DISPLAY_RGBA8, ffi.HR_DISPLAY_RGBA32F, ffi.HR_DISPLAY_HDR_RGBA32F):
+        a, b = ge.display(P, fmt), oe.display(P, fmt)
+        assert a.shape == b.shape and a.dtype == b.dtype
+        assert a.tobytes() == b.tobytes(), f"display format {fmt}, settings {k}: {int((a != b).any(axis=-1).sum())} pixels differ"
+    rgba8 = ge.display(P, ffi.HR_DISPLAY_RGBA8)
+    assert (rgba8[..., 3] == 255).all()
+    if k == 0:
+        assert rgba8[..., :3].std() > 10          # an actual image, not a constant
+
+
+def test_display_resolve_device_output_shards_and_errors(golden):
+    import torch
+    sc = scenes.multi_material(100, 70, bounces=3)
+    P = ffi.display_params(tonemapping_enabled=True, exposure=0.5)
+    full = None
+    parts = []
+    for world, rank in [(1, 0), (3, 0), (3, 1), (3, 2)]:
+        e = core.create_engine(rank=rank, world=world, tile_size=32)
+        sc.apply(e, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        for s in range(2):
+            e.render_pass(sc.options.pass_params(s))    # display completes the pipeline by itself
+        out = torch.zeros((sc.height, sc.width), dtype=torch.int32, device="cuda")
+        e.display_device(out.data_ptr(), P, ffi.HR_DISPLAY_RGBA8)
+        e.synchronize()
+        img = out.cpu().numpy().view(np.uint8).reshape(sc.height, sc.width, 4)
+        assert img.tobytes() == e.display(P, ffi.HR_DISPLAY_RGBA8).tobytes()
+        if world == 1:
+            full = img
+        else:
+            parts.append(img)
+    # shards write only their own pixels: their images add up to the full one
+    assert (parts[0].astype(np.int32) + parts[1] + parts[2] == full).all()
+    e = core.create_engine()
+    with pytest.raises(ffi.EngineError):
+        e.display(P)                                      # no frame
+    e.resize(8, 8)
+    with pytest.raises(ffi.EngineError):
+        e.display(P, 7)                                   # unknown format
