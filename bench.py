@@ -36,7 +36,7 @@ WORKLOADS = {
     "c1": dict(desc="Cornell box (32 tris), 256x256, 4 bounces"),
     "c2": dict(desc="synthetic soup 50k tris, 16 PBR materials, 1 directional light, 1920x1080, 8 bounces"),
     "c3": dict(desc="synthetic soup 1M tris + 2048x1024 HDRI + NEE, 1920x1080, 8 bounces"),
-    "c5": dict(desc="soup 1M tris, 25% glass, 25% clearcoat, f/2.8 DoF, 3840x2160, 16 bounces"),
+    "c5": dict(desc="soup 1M tris, 25% glass, 25% clearcoat, f/2.8 pentagon-bokeh DoF, 3840x2160, 16 bounces"),
 }
 
 
@@ -51,6 +51,7 @@ def build_scene(name, width, height, passes):
         sc = scenes.triangle_soup(1_000_000, width or 3840, height or 2160, bounces=16, passes=passes, env=True,
                                   glass_fraction=0.25, clearcoat_fraction=0.25)
         sc.options.fstop = 2.8
+        sc.options.bokeh_shape = ffi.HR_BOKEH_PENTAGON  # deterministic pentagon sampler (heatray_amd/host.py::polygon_aperture)
         return sc
     raise SystemExit(f"unknown workload {name}")
 
@@ -100,6 +101,63 @@ def cpu_baseline(sc, budget_s, lut):
     }
 
 
+def convergence_leg(core, sc, dev, stream, cap, n_runs):
+    """BASELINE metric 2 (heatray_amd/convergence.py): err(n) is read off the accumulation buffer after every render_pass
+    WITHOUT draining the pipeline — the buffer always holds complete passes, in order, and its alpha says how many."""
+    import torch
+    from heatray_amd import convergence as cv
+    passes_before = sc.options.max_render_passes
+    sc.options.max_render_passes = cv.REFERENCE_PASSES          # sample tables long enough for the reference render
+    eng = core.create_engine(device_id=dev.index, stream=stream)
+    sc.apply(eng)
+    fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
+    eng.bind_external_frame(fb.data_ptr())
+    t0 = time.perf_counter()
+    for n in range(cv.REFERENCE_PASSES):
+        eng.render_pass(sc.options.pass_params(n))
+    eng.flush()
+    torch.cuda.synchronize()
+    ref = cv.normalised(fb).clone()
+    ref_norm = ref.double().norm()
+    t_ref = time.perf_counter() - t0
+    results, curves, t0 = [], [], time.perf_counter()
+    chunk = 64
+    for run in range(n_runs):
+        eng.set_seq_offsets(cv.offsets_table(eng, run, sc.width, sc.height))
+        eng.clear()
+        torch.cuda.synchronize()
+        found, issued, curve = None, 0, {}
+        while found is None and issued < cap:
+            errs = torch.full((chunk,), float("inf"), dtype=torch.float64, device=dev)
+            counts = torch.zeros((chunk,), dtype=torch.float32, device=dev)
+            for k in range(chunk):
+                eng.render_pass(sc.options.pass_params(issued))
+                issued += 1
+                errs[k] = (cv.normalised(fb).double() - ref.double()).norm() / ref_norm
+                counts[k] = fb[0, 0, 3]                               # complete passes in the buffer (same for every pixel)
+            e, c = errs.cpu().numpy(), counts.cpu().numpy()
+            for er, cn in zip(e, c):
+                n = int(cn)
+                if n > 0 and (n & (n - 1)) == 0:
+                    curve[n] = float(er)                               # err(n) at powers of two, for the report
+            hit = [(int(cn), float(er)) for er, cn in zip(e, c) if cn > 0 and er <= cv.THRESHOLD]
+            if hit:
+                found = min(hit)[0]
+        results.append(found)
+        curves.append(curve)
+    t_runs = time.perf_counter() - t0
+    sc.options.max_render_passes = passes_before
+    eng.close()
+    ns = sorted(set().union(*[set(c) for c in curves]))
+    med = {str(n): float(np.median([c[n] for c in curves if n in c])) for n in ns}
+    converged = [r for r in results if r is not None]
+    return {"p50": cv.p50(results, cap) if len(converged) * 2 > len(results) else None, "threshold_rel_l2": cv.THRESHOLD, "runs": results, "cap": cap,
+            "median_err_at_pass": med,
+            "reference_passes": cv.REFERENCE_PASSES, "reference_render_s": t_ref, "runs_s": t_runs,
+            "note": "p50 is null when fewer than half of the runs reached the threshold within the cap", "definition": "min n with ||I_n - I_ref|| / ||I_ref|| <= 0.02 on RGB/A; 16 runs = Sobol sequence index 0..15 of the "
+                          "SequenceOffsets table; I_ref = 8192 passes with index 0 (SURVEY 8d metric 2)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +169,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--shard-of", type=int, default=0, help="tuning aid, single process: render only rank 0's tiles of a W-way "
                     "sharded frame (no collective); the JSON line is marked emulated and is not a benchmark result")
+    ap.add_argument("--converge", action="store_true", help="also measure passes-to-converge p50 (BASELINE metric 2): an 8192-pass "
+                    "reference render + 16 runs, about a minute on c3; N = 1 only")
+    ap.add_argument("--converge-cap", type=int, default=4096, help="give up a convergence run after this many passes")
+    ap.add_argument("--converge-runs", type=int, default=16, help="number of runs (Sobol sequence indices 0..n-1 of the offsets table)")
     ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
     args = ap.parse_args()
 
@@ -265,6 +327,10 @@ def main():
             if world == 1:
                 assert int(shown.view(torch.uint8).reshape(sc.height, sc.width, 4)[..., 3].min().item()) == 255
 
+        conv = None
+        if args.converge and world == 1 and not emulated:
+            conv = convergence_leg(core, sc, dev, stream, args.converge_cap, args.converge_runs)
+
         mrays = total_rays / elapsed / 1e6
         out = {
             "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3") else f"Mrays/s ({args.workload})",
@@ -277,6 +343,7 @@ def main():
                        "seed": hex(scenes.SEED)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "passes_to_converge": conv,
             "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,
                       "rays_per_path": total_rays / max(total_paths, 1.0), "bvh_build_ms": info.build_ms,
                       "kernel_ms_rank0": {k: v[0] for k, v in kt.items()}, "kernel_launches_rank0": {k: v[1] for k, v in kt.items()},
