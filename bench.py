@@ -330,6 +330,13 @@ def main():
         conv = None
         if args.converge and world == 1 and not emulated:
             conv = convergence_leg(core, sc, dev, stream, args.converge_cap, args.converge_runs)
+            conv["measured_live"] = True
+        else:  # the leg takes minutes on c3: the committed measurement of the same workload is quoted instead
+            cpath = os.path.join(ROOT, "profiles", "converge.json")
+            if os.path.exists(cpath):
+                conv = json.load(open(cpath)).get(args.workload)
+                if conv is not None:
+                    conv["measured_live"] = False
 
         mrays = total_rays / elapsed / 1e6
         out = {
