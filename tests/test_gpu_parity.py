@@ -138,6 +138,83 @@ def test_traversal_vs_brute_force_oracle():
     assert g.debug_trace(org, d).tobytes() == o.debug_trace(org, d).tobytes()
 
 
+def _hostile_scene():
+    """Geometry that stresses the builder and the quantised boxes: exact duplicates (ties broken by triangle id), zero-area
+    and collinear triangles, axis-aligned flat sheets (zero-thickness boxes), needle triangles, tiny triangles far from a
+    huge one (12 orders of magnitude of extent), many triangles with identical centroids (identical Morton codes)."""
+    rng = np.random.default_rng(99)
+    tris = []
+    base = rng.uniform(-1, 1, (40, 3, 3)).astype(np.float32)
+    tris += [base, base.copy(), base[:10].copy()]                                   # duplicates, three deep
+    z = rng.uniform(-1, 1, (20, 3)).astype(np.float32)
+    tris.append(np.stack([z, z, z], axis=1))                                         # points (zero area)
+    tris.append(np.stack([z, z + np.float32(0.3), z + np.float32(0.6)], axis=1))     # collinear
+    sheet = rng.uniform(-1, 1, (60, 3, 3)).astype(np.float32)
+    sheet[:20, :, 0] = 0.25
+    sheet[20:40, :, 1] = -0.5
+    sheet[40:, :, 2] = 0.0
+    tris.append(sheet)                                                                # flat, axis-aligned
+    needle = rng.uniform(-1, 1, (30, 3, 3)).astype(np.float32)
+    needle[:, 2] = needle[:, 1] + np.float32(1e-6)
+    tris.append(needle)
+    tiny = (rng.uniform(-1, 1, (50, 3, 3)) * 1e-6 + np.array([0.3, 0.3, 0.3])).astype(np.float32)
+    tris.append(tiny)
+    tris.append(np.array([[[-4000, -4000, -3], [4000, -4000, -3], [0, 4000, -3]]], np.float32))   # huge
+    c = rng.uniform(-0.5, 0.5, (1, 1, 3)).astype(np.float32)
+    fan = (c + rng.uniform(-0.2, 0.2, (64, 3, 3)).astype(np.float32))
+    fan -= fan.mean(axis=1, keepdims=True) - c                                        # 64 triangles, one centroid
+    tris.append(fan.astype(np.float32))
+    pos = np.concatenate(tris).astype(np.float32)
+    sc = scenes.Scene("hostile", width=32, height=32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (pos.shape[0] * 3, 1))
+    sc.materials = scenes._material_palette(scenes.SplitMix64(1), 2)
+    sc.meshes.append(scenes.MeshData(pos.reshape(-1, 3), nrm, np.arange(pos.shape[0] * 3, dtype=np.uint32), material_id=0))
+    sc.lights.add_directional(color=(1, 1, 1), illuminance=10.0, phi=0.3, theta=0.5)
+    scenes._camera_for(sc, np.array([-1, -1, -1], np.float32), np.array([1, 1, 1], np.float32))
+    sc.options.max_ray_depth, sc.options.max_render_passes = 3, 8
+    sc.options.fstop = host.FSTOP_DISABLED
+    return sc, pos
+
+
+def test_hostile_geometry_hits_bit_exact(golden):
+    sc, pos = _hostile_scene()
+    g, o, ob = core.create_engine(), oracle_lib.engine(), oracle_lib.engine()
+    for e in (g, o, ob):
+        sc.apply(e, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    oracle_lib.load().ora_set_brute_force(ob._ctx, 1)
+    rng = np.random.default_rng(4)
+    n = 30000
+    org = rng.uniform(-1.5, 1.5, (n, 3)).astype(np.float32)
+    cent = pos.mean(axis=1)
+    aim = cent[rng.integers(0, cent.shape[0], n)] + rng.normal(scale=1e-3, size=(n, 3)).astype(np.float32) - org
+    d = (aim / np.maximum(np.linalg.norm(aim, axis=1, keepdims=True), 1e-20)).astype(np.float32)
+    d[: n // 10] = np.eye(3, dtype=np.float32)[rng.integers(0, 3, n // 10)] * rng.choice([-1.0, 1.0], (n // 10, 1)).astype(np.float32)  # axis-parallel rays
+    hg, ho, hb = g.debug_trace(org, d), o.debug_trace(org, d), ob.debug_trace(org, d)
+    assert (hb["prim"] >= 0).sum() > n // 4
+    assert ho.tobytes() == hb.tobytes()                       # the oracle's tree against its brute force
+    assert hg.tobytes() == hb.tobytes(), f"{(hg != hb).sum()} of {n} closest hits differ"
+    # duplicates: the winner is the smallest triangle id among equal distances
+    dup = hb["prim"][(hb["prim"] >= 0) & (hb["prim"] < 90)]
+    assert dup.size and (dup < 40).all()
+    tm = rng.uniform(0.01, 3.0, n).astype(np.float32)
+    ag = g.debug_trace(org, d, tmax=tm, skip_prim=hb["prim"], any_hit=True)
+    ab = ob.debug_trace(org, d, tmax=tm, skip_prim=hb["prim"], any_hit=True)
+    assert ag.tobytes() == ab.tobytes()
+    # and a render through the whole path
+    for s in range(3):
+        g.render_pass(sc.options.pass_params(s)), o.render_pass(sc.options.pass_params(s))
+    assert_parity(g.readback(), o.readback(), "hostile geometry render")
+
+
+def test_tiny_scenes_and_frames(golden):
+    # 1, 2 and 5 triangles (root leaf / a root with leaf children only), frames of 1x1, 33x17 and 1x64 pixels
+    for n_tris, (w, h) in [(1, (1, 1)), (2, (33, 17)), (5, (1, 64)), (1, (40, 24))]:
+        sc = scenes.triangle_soup(n_tris, width=w, height=h, bounces=2, passes=4, env=True)
+        g, o, ge, oe = render_both(sc, 3, lut=golden["multiscatter_lut"], device_tables=True)
+        assert_parity(g, o, f"{n_tris} triangles at {w}x{h}")
+        assert (g[..., 3] == 3).all()
+
+
 # --------------------------------------------------------------------------------- renders
 STAT_KEYS = ("paths", "rays_closest", "rays_any", "shaded_hits", "accumulates")
 
