@@ -415,6 +415,8 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
     __shared__ uint32_t scratch[2 + kShadeBlock / 64];
     __shared__ int segRange[2];
+    __shared__ uint32_t waveHits[kShadeBlock / 64];
+    __shared__ uint16_t order[kShadeBlock];
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
     buildSegStarts(tbl, segStart, true);
@@ -424,20 +426,52 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
     uint32_t nShaded = 0, nAccum = 0;
     // Workgroups take kShadeBlock consecutive work items; a batch may straddle passes, so the compaction is done per
     // pass present in the batch.  The trip count is uniform over the workgroup (barriers inside).
+    const uint32_t wave = threadIdx.x >> 6;
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    auto findSeg = [&](uint32_t item) { // last pass whose first index is <= item
+        int lo = 0, hiB = nSeg - 1;
+        while (lo < hiB) {
+            const int mid = (lo + hiB + 1) >> 1;
+            if (item >= segStart[2 * mid])
+                lo = mid;
+            else
+                hiB = mid - 1;
+        }
+        return lo;
+    };
     for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock) {
-        const uint32_t i = base + threadIdx.x;
-        const bool live = i < total;
-        int sI = 0;
-        if (live) {
-            int hiB = nSeg - 1; // last pass whose first index is <= i
-            while (sI < hiB) {
-                const int mid = (sI + hiB + 1) >> 1;
-                if (i >= segStart[2 * mid])
-                    sI = mid;
-                else
-                    hiB = mid - 1;
+        // ---- regroup the workgroup's items: rays that hit something first, misses after them, so that the long material
+        // shaders run on full waves instead of on the ~46 % of lanes that hit (the results do not depend on who shades what)
+        bool hit0 = false;
+        {
+            const uint32_t i0 = base + threadIdx.x;
+            if (i0 < total) {
+                const int s0 = findSeg(i0);
+                hit0 = tbl->seg[s0].hits[i0 - segStart[2 * s0]].prim != kMissPrim;
             }
         }
+        const unsigned long long hitMask = __ballot(hit0);
+        if (lane == 0) waveHits[wave] = (uint32_t)__popcll(hitMask);
+        __syncthreads();
+        uint32_t hitsBefore = 0, hitsTotal = 0;
+        for (uint32_t w = 0; w < (uint32_t)(kShadeBlock / 64); ++w) {
+            const uint32_t cnt = waveHits[w];
+            hitsBefore += (w < wave) ? cnt : 0u;
+            hitsTotal += cnt;
+        }
+        {
+            const uint32_t rankHit = (uint32_t)__popcll(hitMask & ltMask), rankMiss = lane - rankHit;
+            const uint32_t pos = hit0 ? hitsBefore + rankHit : hitsTotal + (wave * 64u - hitsBefore) + rankMiss;
+            order[pos] = (uint16_t)threadIdx.x;
+        }
+        if (threadIdx.x == 0) {
+            const uint32_t last = (total - base < (uint32_t)kShadeBlock ? total - base : (uint32_t)kShadeBlock) - 1u;
+            segRange[0] = findSeg(base), segRange[1] = findSeg(base + last);
+        }
+        __syncthreads();
+        const uint32_t i = base + order[threadIdx.x];
+        const bool live = i < total;
+        const int sI = live ? findSeg(i) : 0;
         Ray nee, next;
         nee.valid = next.valid = false;
         uint32_t pixel = 0, prim = 0xFFFFFFFFu;
@@ -479,14 +513,7 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
             }
             nAccum += sh.nAccum;
         }
-        // per-pass compaction of the emitted rays
-        // work items ascend with the thread index, so the passes present in this batch are a contiguous range
-        if (threadIdx.x == 0) segRange[0] = sI;
-        {
-            const uint32_t lastLive = (total - base < (uint32_t)kShadeBlock ? total - base : (uint32_t)kShadeBlock) - 1u;
-            if (threadIdx.x == lastLive) segRange[1] = sI;
-        }
-        __syncthreads();
+        // per-pass compaction of the emitted rays (the passes present in this batch are a contiguous range)
         const int sLo = segRange[0], sHi = segRange[1];
         for (int s = sLo; s <= sHi; ++s) {
             const SegDev &sg = tbl->seg[s];
