@@ -171,20 +171,39 @@ __global__ __launch_bounds__(kBlock) void k_display(FrameDev fr, hr_display_para
 // queue.  segStart[2k] / segStart[2k+1] are the first global indices of the two.
 HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxSegs+1 */, bool closestOnly)
 {
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        const int n = tbl->nSeg;
-        for (int k = 0; k < n; ++k) {
-            const SegDev &sg = tbl->seg[k];
-            segStart[2 * k] = acc;
-            acc += sg.closestEnabled ? *sg.qCountIn : 0u;
-            segStart[2 * k + 1] = acc;
-            acc += closestOnly ? 0u : *sg.sCountIn;
+    // Queue lengths are read by one thread per queue, all at once (a serial loop over up to 96 passes, two dependent
+    // global loads each, used to cost ~0.15 ms at the start of every launch on a small shard); then the first wave turns
+    // the lengths into exclusive prefix sums, four entries per lane.
+    const int n = tbl->nSeg;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const SegDev &sg = tbl->seg[k];
+        segStart[2 * k] = sg.closestEnabled ? *sg.qCountIn : 0u;
+        segStart[2 * k + 1] = closestOnly ? 0u : *sg.sCountIn;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int m = 2 * n; // entries to scan; entry m receives the total
+        const int first = (int)threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (first + j < m) ? segStart[first + j] : 0u;
+        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
         }
-        segStart[2 * n] = acc;
+        uint32_t acc = incl - sum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (first + j <= m) segStart[first + j] = acc;
+            acc += v[j];
+        }
     }
     __syncthreads();
 }
+
 
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
