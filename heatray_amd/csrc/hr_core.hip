@@ -61,6 +61,7 @@ struct hr_ctx {
         bool allocated = false, active = false;
         bool finished = false;   // every stage has been enqueued; the slot is held until its turn to resolve comes
         bool everResolved = false;
+        unsigned long long resolvedAt = 0; // value of nextResolveOrder when this slot's last pass was resolved
         int group = 0;           // pipeline group (worker stream) the pass runs on
         hipEvent_t evFinal = nullptr;    // recorded on the worker stream after the pass's last stage
         hipEvent_t evResolved = nullptr; // recorded on the caller's stream after the pass buffer was added to the frame
@@ -90,8 +91,9 @@ struct hr_ctx {
         bool needUserSync = true;
     };
     Group groups[kMaxGroups];
-    int nGroups = 1; // measured on MI355X: 2-3 groups are within noise of 1 (the trace kernel has no long tail once
-                     // work is fetched in 64-ray chunks), so the default keeps one group; HR_TUNE="groups=2" for experiments
+    int nGroups = 2;      // groups in use: chosen per frame size in hr_frame_resize unless HR_TUNE fixes it
+    int tuneGroups = 0;   // HR_TUNE="groups=N" (0 = automatic)
+    int tuneBlocksSet = 0; // HR_TUNE="blocks=N" given
     int nextGroup = 0;
     unsigned long long nextResolveOrder = 0;
     // Passes requested but not yet injected: when a shard is small (multi-GPU tiles, small frames) several passes are
@@ -162,7 +164,7 @@ struct hr_ctx {
     void drainTimes()
     {
         if (pending.empty()) return;
-        for (int g = 0; g < nGroups; ++g)
+        for (int g = 0; g < kMaxGroups; ++g)
             if (groups[g].stream) hipStreamSynchronize(groups[g].stream);
         hipStreamSynchronize(stream);
         for (Timed &t : pending) {
@@ -266,18 +268,23 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
     }
     c->numCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (const char *t = getenv("HR_TUNE")) {
+        auto find = [&](const char *key) -> const char * { // key at the start of the string or right after a comma
+            for (const char *p = strstr(t, key); p; p = strstr(p + 1, key))
+                if (p == t || p[-1] == ',') return p;
+            return nullptr;
+        };
         auto get = [&](const char *key, int &dst) {
-            const char *p = strstr(t, key);
-            if (p) dst = atoi(p + strlen(key));
+            if (const char *p = find(key)) dst = atoi(p + strlen(key));
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->nGroups);
+        get("groups=", c->tuneGroups);
+        c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
-        if (c->nGroups < 1 || c->nGroups > kMaxGroups) c->nGroups = 1;
+        if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
     }
     bool groupsOk = true;
-    for (int g = 0; g < c->nGroups; ++g) {
+    for (int g = 0; g < kMaxGroups; ++g) {
         hr_ctx::Group &G = c->groups[g];
         groupsOk = groupsOk && hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking) == hipSuccess;
         groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
@@ -426,6 +433,13 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         long long b = (target + own - 1) / own;
         c->injectBatch = (int)(b < 1 ? 1 : (b > 16 ? 16 : b));
         if (c->tuneBatch > 0) c->injectBatch = c->tuneBatch;
+        // Two pipeline groups (their steps alternate on two streams, so one group's trace tail and its shade / raygen run
+        // under the other group's trace) pay off while a pass fills the GPU reasonably: measured on MI355X +11..14 % on a
+        // full 1080p frame and on a 1/2 shard, +5 % on 1/4, -5 % on 1/8 (each group has its own pipeline fill and drain).
+        // With two resident trace kernels three workgroups per CU each are best, alone five.
+        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (c->injectBatch <= 4 ? 2 : 1);
+        c->nextGroup = 0;
+        if (!c->tuneBlocksSet) c->tuneBlocks = c->nGroups > 1 ? 3 : 5;
         c->pendingInject.clear();
     }
     return HR_OK;
@@ -896,6 +910,7 @@ static int occupiedSlots(const hr_ctx *c, int group = -1)
     return n;
 }
 
+static int slotLimit(const hr_ctx *c);
 static int activePasses(const hr_ctx *c)
 {
     int n = 0;
@@ -921,6 +936,7 @@ static int resolveReady(hr_ctx *c)
         c->timeEnd(c->stream);
         HIP_TRY(c, hipEventRecord(next->evResolved, c->stream));
         next->finished = false, next->everResolved = true;
+        next->resolvedAt = c->nextResolveOrder;
         c->nextResolveOrder++;
     }
 }
@@ -943,11 +959,23 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     for (int k = 0; k < nInject; ++k) {
         const hr_pass_params pp = c->pendingInject.front();
         c->pendingInject.pop_front();
-        int slot = -1;
-        for (int i = 0; i < kMaxSlots && slot < 0; ++i) // prefer slots that already own memory
-            if (!c->slots[i].active && !c->slots[i].finished && c->slots[i].allocated) slot = i;
-        for (int i = 0; i < kMaxSlots && slot < 0; ++i)
-            if (!c->slots[i].active && !c->slots[i].finished) slot = i;
+        // Reuse the free slot whose pass was resolved longest ago: the injection waits for that resolve, and a slot freed
+        // by the step just enqueued would chain this group's step behind the other group's (no overlap).  A slot resolved
+        // only recently is passed over for fresh memory while the slot budget allows.
+        int slot = -1, fresh = -1;
+        for (int i = 0; i < kMaxSlots; ++i) {
+            const hr_ctx::PassSlot &cand = c->slots[i];
+            if (cand.active || cand.finished) continue;
+            if (!cand.allocated) {
+                if (fresh < 0) fresh = i;
+            } else if (slot < 0 || cand.resolvedAt < c->slots[slot].resolvedAt) {
+                slot = i;
+            }
+        }
+        const unsigned long long recent = 2ull * (unsigned long long)c->nGroups * (unsigned long long)(nInject > 0 ? nInject : 1);
+        if (fresh >= 0 && c->nSlotsAllocated < slotLimit(c) && (slot < 0 || (c->nGroups > 1 && c->nextResolveOrder - c->slots[slot].resolvedAt < recent)))
+            slot = fresh;
+        if (slot < 0) slot = fresh;
         if (slot < 0) FAIL(c, HR_ERR_INVALID, "internal: no free pass slot");
         hr_ctx::PassSlot &ps = c->slots[slot];
         if (!ps.allocated) {
@@ -1096,7 +1124,7 @@ static int drainPipeline(hr_ctx *c)
     if (rc) return rc;
     if (occupiedSlots(c) > 0) FAIL(c, HR_ERR_DEVICE, "internal: finished passes left unresolved");
     // whatever the caller does next on its stream (clear, scene edits, new tables) has to be seen by the groups
-    for (int g = 0; g < c->nGroups; ++g) c->groups[g].needUserSync = true;
+    for (int g = 0; g < kMaxGroups; ++g) c->groups[g].needUserSync = true;
     return HR_OK;
 }
 
