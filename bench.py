@@ -308,6 +308,9 @@ def main():
                         "algorithmic_bytes_per_launch": total_bytes / n_trace,
                         "algorithmic_bytes_per_closest_ray": bytes_closest, "algorithmic_bytes_per_occlusion_ray": bytes_any,
                         "rays_per_launch": float(st.rays_closest + st.rays_any) / n_trace,
+                        # two pipeline groups run their launches concurrently on two streams: a launch's duration then spans
+                        # time it shares with the other group's kernels (sum of all kernel durations / wall time of the region)
+                        "kernel_time_over_wall_time": sum(v[0] for v in kt.values()) / (elapsed * 1e3),
                         "V": vt["V"], "T": vt["T"], "V_any": vt["V_any"], "T_any": vt["T_any"],
                         "vt_source": "cpu oracle, this run" if vt is cpu else "profiles/vt_spec.json"}
 

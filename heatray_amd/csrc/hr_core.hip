@@ -437,7 +437,10 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         // under the other group's trace) pay off while a pass fills the GPU reasonably: measured on MI355X +11..14 % on a
         // full 1080p frame and on a 1/2 shard, +5 % on 1/4, -5 % on 1/8 (each group has its own pipeline fill and drain).
         // With two resident trace kernels three workgroups per CU each are best, alone five.
-        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (c->injectBatch <= 4 ? 2 : 1);
+        // Larger frames lose: 2560x1440 948 vs 1491 Mrays/s, 3840x2160 1141 vs 1344 (one trace launch already fills the GPU for
+        // several ms; two of them only compete for L1/L2), so two groups are used from a quarter up to one 1080p frame of paths.
+        const bool midSized = c->injectBatch <= 4 && c->queueCapacity <= 2200000u;
+        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (midSized ? 2 : 1);
         c->nextGroup = 0;
         if (!c->tuneBlocksSet) c->tuneBlocks = c->nGroups > 1 ? 3 : 5;
         c->pendingInject.clear();
