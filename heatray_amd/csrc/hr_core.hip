@@ -929,18 +929,29 @@ static int resolveReady(hr_ctx *c)
     fr.fb = c->fb();
     const LaunchCfg cfg = c->cfg(c->stream);
     for (;;) {
-        hr_ctx::PassSlot *next = nullptr;
-        for (hr_ctx::PassSlot &ps : c->slots)
-            if ((ps.active || ps.finished) && ps.order == c->nextResolveOrder) next = &ps;
-        if (!next || !next->finished) return HR_OK;
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, next->evFinal, 0));
+        // collect the passes whose turn it is (up to kMaxBatch) and add them with one launch
+        PassBufList bufs{};
+        hr_ctx::PassSlot *ready[kMaxBatch];
+        while (bufs.n < kMaxBatch) {
+            hr_ctx::PassSlot *next = nullptr;
+            const unsigned long long want = c->nextResolveOrder + (unsigned long long)bufs.n;
+            for (hr_ctx::PassSlot &ps : c->slots)
+                if ((ps.active || ps.finished) && ps.order == want) next = &ps;
+            if (!next || !next->finished) break;
+            ready[bufs.n] = next;
+            bufs.buf[bufs.n++] = next->passbuf;
+        }
+        if (bufs.n == 0) return HR_OK;
+        for (int k = 0; k < bufs.n; ++k) HIP_TRY(c, hipStreamWaitEvent(c->stream, ready[k]->evFinal, 0));
         c->timeBegin(HR_KERNEL_RESOLVE, c->stream);
-        launchResolve(cfg, fr, next->passbuf);
+        launchResolve(cfg, fr, bufs);
         c->timeEnd(c->stream);
-        HIP_TRY(c, hipEventRecord(next->evResolved, c->stream));
-        next->finished = false, next->everResolved = true;
-        next->resolvedAt = c->nextResolveOrder;
-        c->nextResolveOrder++;
+        for (int k = 0; k < bufs.n; ++k) {
+            HIP_TRY(c, hipEventRecord(ready[k]->evResolved, c->stream));
+            ready[k]->finished = false, ready[k]->everResolved = true;
+            ready[k]->resolvedAt = c->nextResolveOrder;
+            c->nextResolveOrder++;
+        }
     }
 }
 
@@ -1041,9 +1052,11 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     HIP_TRY(c, hipEventRecord(G.tableCopied[ring], G.stream));
     G.tableUsed[ring] = true;
     if (c->pending.size() > 8192) c->drainTimes();
-    for (int j = 0; j < nInjectedSegs; ++j) {
+    for (int j0 = 0; j0 < nInjectedSegs; j0 += kMaxBatch) { // one launch for the passes injected this step
+        SegList segs{};
+        for (int j = j0; j < nInjectedSegs && segs.n < kMaxBatch; ++j) segs.seg[segs.n++] = injectedSegs[j];
         c->timeBegin(HR_KERNEL_RAYGEN, G.stream);
-        launchRaygen(cfg, c->dScene, dTbl, injectedSegs[j], fr, c->dStats);
+        launchRaygen(cfg, c->dScene, dTbl, segs, fr, c->dStats);
         c->timeEnd(G.stream);
     }
     c->timeBegin(HR_KERNEL_TRACE, G.stream);

@@ -57,8 +57,18 @@ struct StepTable {
 };
 
 // ---- hr_render.hip
-void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, int segIdx, const FrameDev &fr, Stats *stats);
-void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbuf);
+// Several passes per launch (a small shard injects / resolves a batch of passes per macro step: one launch instead of 8 + 8)
+static const int kMaxBatch = 16;
+struct SegList {
+    int32_t n;
+    int32_t seg[kMaxBatch]; // indices into StepTable::seg, one per blockIdx.y
+};
+struct PassBufList {
+    int32_t n;
+    const float *buf[kMaxBatch]; // pass samples, added to the frame in this order
+};
+void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, const SegList &segs, const FrameDev &fr, Stats *stats);
+void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &bufs);
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out);
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);

@@ -106,13 +106,13 @@ HRD bool ownedPixel(const FrameDev &fr, uint32_t gid, int &x, int &y)
 
 // ------------------------------------------------------------------------------------------ raygen
 static const int kRaygenBlock = 1024; // one queue-slot reservation (global atomic) per 1024 pixels
-__global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, int segIdx, FrameDev fr,
+__global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, SegList segs, FrameDev fr,
                                                          Stats *stats)
 {
     __shared__ uint32_t scratch[2 + kRaygenBlock / 64];
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
-    const SegDev &seg = tbl->seg[segIdx];
+    const SegDev &seg = tbl->seg[segs.seg[blockIdx.y]]; // blockIdx.y: which of the passes injected this step
     int x = 0, y = 0;
     const bool inFrame = ownedPixel(fr, blockIdx.x * kRaygenBlock + threadIdx.x, x, y);
     const uint32_t pixel = (uint32_t)(y * fr.W + x);
@@ -129,14 +129,17 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
 }
 
 // ------------------------------------------------------------------------------------------ resolve
-__global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, const float *__restrict__ passbuf)
+// The finished passes' samples are added one after the other, in pass order (float addition order is part of the contract)
+__global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, PassBufList bufs)
 {
     int x = 0, y = 0;
     if (!ownedPixel(fr, blockIdx.x * kBlock + threadIdx.x, x, y)) return;
     const uint32_t pixel = (uint32_t)(y * fr.W + x);
-    const float4 s = reinterpret_cast<const float4 *>(passbuf)[pixel];
     float4 a = reinterpret_cast<float4 *>(fr.fb)[pixel];
-    a.x = a.x + s.x, a.y = a.y + s.y, a.z = a.z + s.z, a.w = a.w + s.w;
+    for (int k = 0; k < bufs.n; ++k) {
+        const float4 s = reinterpret_cast<const float4 *>(bufs.buf[k])[pixel];
+        a.x = a.x + s.x, a.y = a.y + s.y, a.z = a.z + s.z, a.w = a.w + s.w;
+    }
     reinterpret_cast<float4 *>(fr.fb)[pixel] = a;
 }
 
@@ -589,18 +592,18 @@ __global__ __launch_bounds__(kBlock) void k_debug_trace(const SceneDev *__restri
 // ------------------------------------------------------------------------------------- launchers
 static int ownedThreads(const FrameDev &fr) { return fr.nOwnedTiles * fr.tile * fr.tile; }
 
-void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, int segIdx, const FrameDev &fr, Stats *stats)
+void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, const SegList &segs, const FrameDev &fr, Stats *stats)
 {
     const int threads = ownedThreads(fr);
-    if (threads <= 0) return;
-    hipLaunchKernelGGL(k_raygen, dim3((threads + kRaygenBlock - 1) / kRaygenBlock), dim3(kRaygenBlock), 0, cfg.stream, S, tbl, segIdx, fr, stats);
+    if (threads <= 0 || segs.n <= 0) return;
+    hipLaunchKernelGGL(k_raygen, dim3((threads + kRaygenBlock - 1) / kRaygenBlock, segs.n), dim3(kRaygenBlock), 0, cfg.stream, S, tbl, segs, fr, stats);
 }
 
-void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const float *passbuf)
+void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &bufs)
 {
     const int threads = ownedThreads(fr);
-    if (threads <= 0) return;
-    hipLaunchKernelGGL(k_resolve, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, fr, passbuf);
+    if (threads <= 0 || bufs.n <= 0) return;
+    hipLaunchKernelGGL(k_resolve, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, fr, bufs);
 }
 
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats)
