@@ -173,6 +173,7 @@ def main():
                     "reference render + 16 runs, about a minute on c3; N = 1 only")
     ap.add_argument("--converge-cap", type=int, default=4096, help="give up a convergence run after this many passes")
     ap.add_argument("--converge-runs", type=int, default=16, help="number of runs (Sobol sequence indices 0..n-1 of the offsets table)")
+    ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of: which rank's shard to render")
     ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
     args = ap.parse_args()
 
@@ -204,7 +205,8 @@ def main():
     passes_total = args.warmup + args.steps
     sc = build_scene(args.workload, args.width, args.height, max(32, passes_total))
     stream = torch.cuda.current_stream().cuda_stream
-    eng = core.create_engine(device_id=local_rank, rank=rank, world=eng_world, tile_size=32, stream=stream, time_kernels=True)
+    eng_rank = args.shard_rank if emulated else rank
+    eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, time_kernels=True)
     sc.apply(eng)  # tables and LUT are generated on the device
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
@@ -255,7 +257,7 @@ def main():
         # sanity of the timed result itself: every owned pixel got exactly `steps` samples
         a = full[..., 3]
         if emulated:
-            a = a[torch.from_numpy(tiles.owner_map(sc.width, sc.height, eng_world) == 0).to(dev)]
+            a = a[torch.from_numpy(tiles.owner_map(sc.width, sc.height, eng_world) == eng_rank).to(dev)]
         assert bool((a == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
         assert bool(torch.isfinite(full).all())
 
@@ -268,7 +270,7 @@ def main():
         # ---- the product's own traversal counters (4-wide quantised BVH), one extra counted pass outside the timed region
         gpu_counts = None
         if not args.no_stats_pass:
-            se = core.create_engine(device_id=local_rank, rank=rank, world=eng_world, tile_size=32, stream=stream, collect_stats=True)
+            se = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, collect_stats=True)
             sc.apply(se)
             se.render_pass(sc.options.pass_params(args.warmup))
             ss = se.stats()
@@ -362,7 +364,7 @@ def main():
         }
         if emulated:
             out["emulated_shard_of"] = eng_world
-            out["metric"] += f" [EMULATED rank 0 of {eng_world}, not a benchmark result]"
+            out["metric"] += f" [EMULATED rank {eng_rank} of {eng_world}, not a benchmark result]"
         print(json.dumps(out))
     if exchange:
         dist.barrier()
