@@ -110,6 +110,15 @@ struct hr_ctx {
     std::vector<hr_material> materials;
     hr_lights lights{};
     bool committed = false, sceneDirty = true, hasPassthrough = false;
+    // Entity-space vertex data of the live geometries stays resident between commits: a commit after transform-only edits
+    // (Scene::applyTransform while the user drags a slider) re-runs assemble + LBVH without staging or re-uploading it.
+    struct GeomOff {
+        size_t pos, nrm, uv, tan, bit, col, idx;
+    };
+    std::vector<GeomOff> geomOffs;
+    float *dGeomF = nullptr;
+    uint32_t *dGeomI = nullptr;
+    bool geomCacheValid = false;
     hr_scene_info info{};
 
     // scene (device)
@@ -318,6 +327,7 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->fbInternal);
     if (c->pinned) hipHostFree(c->pinned);
     hipFree(c->dDisplay);
+    hipFree(c->dGeomF), hipFree(c->dGeomI);
     if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
     hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero);
@@ -497,7 +507,7 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     std::memcpy(g.world, d->world_from_entity, sizeof(g.world));
     g.frontFaceCW = d->front_face_cw, g.isOccluder = d->is_occluder, g.material = d->material_id;
     c->geoms.push_back(std::move(g));
-    c->committed = false;
+    c->committed = false, c->geomCacheValid = false;
     if (out) *out = (hr_geom_id)c->geoms.size() - 1;
     return HR_OK;
 }
@@ -507,7 +517,7 @@ int hr_geom_remove(hr_ctx *c, hr_geom_id id)
     ENTER(c);
     if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive) FAIL(c, HR_ERR_INVALID, "bad geom id");
     c->geoms[id] = Geom();
-    c->committed = false;
+    c->committed = false, c->geomCacheValid = false;
     return HR_OK;
 }
 
@@ -524,7 +534,7 @@ int hr_scene_clear(hr_ctx *c)
 {
     ENTER(c);
     c->geoms.clear();
-    c->committed = false;
+    c->committed = false, c->geomCacheValid = false;
     return HR_OK;
 }
 
@@ -545,13 +555,12 @@ int hr_scene_commit(hr_ctx *c)
     HIP_TRY(c, hipEventCreate(&e1));
     HIP_TRY(c, hipEventRecord(e0, c->stream));
     freeSceneDevice(c);
-    // ---- stage every live geometry into one device buffer
+    // ---- stage every live geometry into one device buffer (skipped when only transforms changed since the last commit)
     std::vector<GeomDev> gd;
     std::vector<float> stageF;
     std::vector<uint32_t> stageI;
-    struct Off {
-        size_t pos, nrm, uv, tan, bit, col, idx;
-    };
+    typedef hr_ctx::GeomOff Off;
+    const bool reuse = c->geomCacheValid;
     std::vector<Off> offs;
     uint32_t nTris = 0;
     bool anyExt = false;
@@ -565,10 +574,13 @@ int hr_scene_commit(hr_ctx *c)
     for (const Geom &g : c->geoms) {
         if (!g.alive || g.nTris() == 0) continue;
         GeomDev d{};
-        Off o;
-        o.pos = push(g.pos), o.nrm = push(g.nrm), o.uv = push(g.uv), o.tan = push(g.tan), o.bit = push(g.bit), o.col = push(g.col);
-        o.idx = stageI.size();
-        stageI.insert(stageI.end(), g.idx.begin(), g.idx.end());
+        if (!reuse) {
+            Off o;
+            o.pos = push(g.pos), o.nrm = push(g.nrm), o.uv = push(g.uv), o.tan = push(g.tan), o.bit = push(g.bit), o.col = push(g.col);
+            o.idx = stageI.size();
+            stageI.insert(stageI.end(), g.idx.begin(), g.idx.end());
+            offs.push_back(o);
+        }
         d.triOffset = nTris, d.nTris = g.nTris(), d.strip = g.mode == HR_TRIANGLE_STRIP;
         d.flags = (g.frontFaceCW ? TF_FRONT_CW : 0u) | (g.isOccluder ? 0u : TF_NON_OCCLUDER) | (!g.uv.empty() ? TF_HAS_UV : 0u) |
                   ((!g.tan.empty() && !g.bit.empty()) ? TF_HAS_TANGENTS : 0u) | (!g.col.empty() ? TF_HAS_COLORS : 0u);
@@ -577,25 +589,35 @@ int hr_scene_commit(hr_ctx *c)
         if (d.flags & (TF_HAS_TANGENTS | TF_HAS_COLORS)) anyExt = true;
         nTris += d.nTris;
         gd.push_back(d);
-        offs.push_back(o);
+    }
+    if (!reuse) {
+        hipFree(c->dGeomF), hipFree(c->dGeomI);
+        c->dGeomF = nullptr, c->dGeomI = nullptr;
+        c->geomOffs = offs;
     }
     std::memset(&c->info, 0, sizeof(c->info));
     c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0;
     c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
     c->hScene.rayEps = 0.0f;
     if (nTris > 0) {
-        float *dF = nullptr;
-        uint32_t *dI = nullptr;
         GeomDev *dG = nullptr;
         Tri *trisPrim = nullptr;
-        HIP_TRY(c, hipMalloc(&dF, stageF.size() * sizeof(float)));
-        HIP_TRY(c, hipMalloc(&dI, stageI.size() * sizeof(uint32_t)));
+        if (!reuse) {
+            HIP_TRY(c, hipMalloc(&c->dGeomF, stageF.size() * sizeof(float)));
+            HIP_TRY(c, hipMalloc(&c->dGeomI, stageI.size() * sizeof(uint32_t)));
+            HIP_TRY(c, hipMemcpyAsync(c->dGeomF, stageF.data(), stageF.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->dGeomI, stageI.data(), stageI.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream)); // the staging vectors go out of scope with this call
+            c->geomCacheValid = true;
+        }
+        float *dF = c->dGeomF;
+        uint32_t *dI = c->dGeomI;
         HIP_TRY(c, hipMalloc(&dG, gd.size() * sizeof(GeomDev)));
         HIP_TRY(c, hipMalloc(&trisPrim, sizeof(Tri) * (size_t)nTris));
         HIP_TRY(c, hipMalloc(&c->attrs, sizeof(TriAttr) * (size_t)nTris));
         if (anyExt) HIP_TRY(c, hipMalloc(&c->attrsExt, sizeof(TriAttrExt) * (size_t)nTris));
         for (size_t i = 0; i < gd.size(); ++i) {
-            const Off &o = offs[i];
+            const Off &o = c->geomOffs[i];
             gd[i].pos = dF + o.pos, gd[i].nrm = dF + o.nrm;
             gd[i].uv = o.uv == none ? nullptr : dF + o.uv;
             gd[i].tan = o.tan == none ? nullptr : dF + o.tan;
@@ -603,8 +625,6 @@ int hr_scene_commit(hr_ctx *c)
             gd[i].col = o.col == none ? nullptr : dF + o.col;
             gd[i].idx = dI + o.idx;
         }
-        HIP_TRY(c, hipMemcpyAsync(dF, stageF.data(), stageF.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(dI, stageI.data(), stageI.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(dG, gd.data(), gd.size() * sizeof(GeomDev), hipMemcpyHostToDevice, c->stream));
         const uint32_t initB[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
         HIP_TRY(c, hipMemcpyAsync(c->dScratch, initB, sizeof(initB), hipMemcpyHostToDevice, c->stream));
@@ -620,7 +640,7 @@ int hr_scene_commit(hr_ctx *c)
         const float pad = 1e-5f * diag;
         BuildResult br{};
         const int rc = buildLBVH(c->stream, trisPrim, nTris, lo, hi, pad, &br);
-        hipFree(dF), hipFree(dI), hipFree(dG), hipFree(trisPrim);
+        hipFree(dG), hipFree(trisPrim);
         if (rc != 0) {
             hipFree(br.nodes), hipFree(br.tris);
             FAIL(c, HR_ERR_DEVICE, rc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");

@@ -545,3 +545,39 @@ def test_pentagon_bokeh_dof_config5_aperture(golden):
     sc2.options.fstop = 2.8
     g2, _, _, _ = render_both(sc2, 4, lut=golden["multiscatter_lut"], device_tables=True)
     assert g2.tobytes() != g.tobytes()                      # the aperture shape does change the image
+
+
+def test_scene_edit_sequences_keep_parity(golden):
+    # SURVEY §8f row 3 (dynamic updates): transform-only edits reuse the resident geometry (fast re-commit: assemble + LBVH
+    # only), adding / removing geometry re-stages it; every state must still render like the oracle's
+    sc = scenes.multi_material(64, 48, bounces=3)
+    g, o = core.create_engine(), oracle_lib.engine()
+    for eng in (g, o):
+        sc.apply(eng, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    tri_p = np.array([[-0.5, 0.2, 0.1], [0.5, 0.2, 0.1], [0.0, 0.9, 0.3]], np.float32)
+    tri_n = np.tile(np.array([0, 0, 1], np.float32), (3, 1))
+
+    def both(fn):
+        return fn(g), fn(o)
+
+    def check(what, passes=2):
+        for eng in (g, o):
+            eng.clear()
+            for s in range(passes):
+                eng.render_pass(sc.options.pass_params(s))
+        assert_parity(g.readback(), o.readback(), what)
+
+    check("initial")
+    both(lambda e: (e.set_transform(0, scenes._translate(0.2, 0.0, 0.1)), e.commit()))           # transform only -> reuse
+    check("after a transform")
+    both(lambda e: (e.set_transform(1, scenes._translate(-0.1, 0.05, 0.0)), e.set_transform(0, scenes._translate(0, 0, 0)), e.commit()))
+    check("after two more transforms")
+    ids = both(lambda e: e.add_mesh(tri_p, tri_n, [0, 1, 2], material_id=1))                     # new geometry -> re-staged
+    assert ids[0] == ids[1]
+    both(lambda e: e.commit())
+    check("after adding a triangle")
+    both(lambda e: (e.set_transform(ids[0], scenes._translate(0.0, -0.3, 0.2)), e.commit()))     # reuse again, new geom included
+    check("after moving the new triangle")
+    both(lambda e: (e.remove_mesh(ids[0]), e.commit()))
+    check("after removing it")
+    assert g.scene_info().n_triangles == o.scene_info().n_triangles
