@@ -180,6 +180,12 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # stdout carries exactly ONE JSON line: native libraries (RCCL prints a version banner on fd 1 when a communicator is
+    # created) are sent to stderr for the whole run, and the line is written to the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -211,7 +217,7 @@ def main():
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
     eng.bind_external_frame(fb.data_ptr())
-    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3) if exchange else None
+    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3, engine=eng) if exchange else None
 
     # On a small shard libhrcore injects (and therefore resolves) passes in batches of ceil(1080p / owned pixels) <= 16
     # (hr_frame_resize): the accumulation buffer changes once per batch, so that is the exchange cadence as well.
@@ -370,7 +376,7 @@ def main():
         if emulated:
             out["emulated_shard_of"] = eng_world
             out["metric"] += f" [EMULATED rank {eng_rank} of {eng_world}, not a benchmark result]"
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if exchange:
         dist.barrier()
         dist.destroy_process_group()

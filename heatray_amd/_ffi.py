@@ -148,7 +148,7 @@ ABI_SYMBOLS = [
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
-    "display", "display_readback",
+    "display", "display_readback", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
 ]
 
 
@@ -348,6 +348,19 @@ class Engine:
         n = w.value * h.value * ch
         buf = (C.c_uint8 * n).from_address(p.value) if dt is np.uint8 else (C.c_float * n).from_address(p.value)
         return np.frombuffer(buf, dtype=dt).reshape(h.value, w.value, ch).copy()
+
+    # -- tile-shard exchange (device pointers for the HIP core, host pointers for the oracle)
+    def packed_slots(self, rank, world):
+        n = C.c_uint64()
+        self._call("frame_packed_slots", C.c_int32(rank), C.c_int32(world), C.byref(n))
+        return int(n.value)
+
+    def pack_owned(self, out_ptr, stream=None):
+        self._call("frame_pack_owned", C.c_void_p(int(out_ptr)), C.c_void_p(stream or 0))
+
+    def unpack(self, src_rank, world, packed_ptr, full_ptr, stream=None):
+        self._call("frame_unpack", C.c_int32(src_rank), C.c_int32(world), C.c_void_p(int(packed_ptr)), C.c_void_p(int(full_ptr)),
+                   C.c_void_p(stream or 0))
 
     def display_device(self, device_ptr, params=None, fmt=HR_DISPLAY_RGBA8):
         """Asynchronous display resolve into device memory (e.g. a torch tensor or a GL-interop buffer)."""

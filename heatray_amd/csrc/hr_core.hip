@@ -295,7 +295,6 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
     bool groupsOk = true;
     for (int g = 0; g < kMaxGroups; ++g) {
         hr_ctx::Group &G = c->groups[g];
-        groupsOk = groupsOk && hipStreamCreateWithFlags(&G.stream, hipStreamNonBlocking) == hipSuccess;
         groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipEventCreateWithFlags(&G.evUser, hipEventDisableTiming) == hipSuccess;
@@ -350,6 +349,49 @@ int hr_ctx_set_stream(hr_ctx *c, void *stream)
     ENTER(c);
     QUIESCE(c);
     c->stream = (hipStream_t)stream;
+    return HR_OK;
+}
+
+// the frame geometry of `rank` of `world` (the ctx's own when they match its description)
+static FrameDev frameOf(const hr_ctx *c, int32_t rank, int32_t world)
+{
+    FrameDev f = c->frame;
+    f.rank = rank, f.world = world;
+    const int nTiles = f.tilesX * f.tilesY;
+    f.nOwnedTiles = nTiles > rank ? (nTiles - rank + world - 1) / world : 0;
+    return f;
+}
+
+int hr_frame_packed_slots(hr_ctx *c, int32_t rank, int32_t world, uint64_t *n_slots)
+{
+    ENTER(c);
+    if (!n_slots || world <= 0 || rank < 0 || rank >= world) FAIL(c, HR_ERR_INVALID, "bad rank / world");
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    *n_slots = (uint64_t)frameOf(c, rank, world).nOwnedTiles * (uint64_t)(c->tile * c->tile);
+    return HR_OK;
+}
+
+int hr_frame_pack_owned(hr_ctx *c, void *device_out, void *stream)
+{
+    ENTER(c);
+    if (!device_out) FAIL(c, HR_ERR_INVALID, "null output");
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    FrameDev fr = c->frame;
+    fr.fb = c->fb();
+    launchPackOwned(c->cfg(stream ? (hipStream_t)stream : c->stream), fr, c->fb(), (float *)device_out, 0, nullptr);
+    HIP_TRY(c, hipGetLastError());
+    return HR_OK;
+}
+
+int hr_frame_unpack(hr_ctx *c, int32_t src_rank, int32_t world, const void *device_packed, void *device_full_frame, void *stream)
+{
+    ENTER(c);
+    if (!device_packed || !device_full_frame) FAIL(c, HR_ERR_INVALID, "null argument");
+    if (world <= 0 || src_rank < 0 || src_rank >= world) FAIL(c, HR_ERR_INVALID, "bad rank / world");
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    launchPackOwned(c->cfg(stream ? (hipStream_t)stream : c->stream), frameOf(c, src_rank, world), nullptr, (float *)device_packed, 1,
+                    (float *)device_full_frame);
+    HIP_TRY(c, hipGetLastError());
     return HR_OK;
 }
 
@@ -980,6 +1022,15 @@ static int resolveReady(hr_ctx *c)
 static int macroStep(hr_ctx *c, int g, int nInject)
 {
     hr_ctx::Group &G = c->groups[g];
+    if (!G.stream) {
+        // Worker streams are created on first use, at the highest stream priority: HIP maps the streams of one priority
+        // to a small pool of hardware queues, and two groups that land on the same queue do not overlap at all — which is
+        // what happened as soon as the application had a few streams of its own (torch side stream, RCCL).  The high
+        // priority pool is practically empty, so the groups get a hardware queue each.
+        int least = 0, greatest = 0;
+        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_TRY(c, hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, greatest));
+    }
     const LaunchCfg cfg = c->cfg(G.stream);
     FrameDev fr = c->frame;
     fr.fb = c->fb();

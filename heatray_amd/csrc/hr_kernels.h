@@ -69,6 +69,7 @@ struct PassBufList {
 };
 void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, const SegList &segs, const FrameDev &fr, Stats *stats);
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &bufs);
+void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *frame, float *packed, int unpack, float *full);
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out);
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);

@@ -143,6 +143,31 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, PassBufList buf
     reinterpret_cast<float4 *>(fr.fb)[pixel] = a;
 }
 
+// ----------------------------------------------------------------------------------- shard exchange
+// dense copy of a rank's pixels, in ownedPixel order (coalesced 8x8 blocks); `unpack` is the inverse into a full frame
+__global__ __launch_bounds__(kBlock) void k_pack_owned(FrameDev fr, const float4 *__restrict__ frame, float4 *__restrict__ packed, int unpack,
+                                                       float4 *__restrict__ full)
+{
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= (uint32_t)(fr.nOwnedTiles * fr.tile * fr.tile)) return;
+    int x = 0, y = 0;
+    const bool in = ownedPixel(fr, gid, x, y);
+    const uint32_t pixel = (uint32_t)(y * fr.W + x);
+    if (unpack) {
+        if (in) full[pixel] = packed[gid];
+    } else {
+        packed[gid] = in ? frame[pixel] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
+void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *frame, float *packed, int unpack, float *full)
+{
+    const int threads = fr.nOwnedTiles * fr.tile * fr.tile;
+    if (threads <= 0) return;
+    hipLaunchKernelGGL(k_pack_owned, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, fr, reinterpret_cast<const float4 *>(frame),
+                       reinterpret_cast<float4 *>(packed), unpack, reinterpret_cast<float4 *>(full));
+}
+
 // ------------------------------------------------------------------------------------------ display
 // displayGL.frag on the accumulation buffer: one thread per pixel, row-major (coalesced 16-byte reads, 4- or 16-byte writes)
 __global__ __launch_bounds__(kBlock) void k_display(FrameDev fr, hr_display_params P, int format, void *__restrict__ out)

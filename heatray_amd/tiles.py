@@ -98,16 +98,25 @@ class FrameGatherer:
     `n_buffers` staging buffers, so it overlaps the next pass's kernels (xGMI is point-to-point: `dst` receives
     from each peer over its own link).  `finish()` returns the assembled frame of the last post on `dst`.
 
+    With `engine` (an `_ffi.Engine` on the same frame) packing and unpacking are the core's own kernels
+    (`hr_frame_pack_owned` / `hr_frame_unpack`: coalesced tile copies — torch's row gather with int64 indices costs
+    0.44 ms for a 1080p frame on MI355X, the kernel 0.02 ms); without it plain torch indexing is used (any device).
+
     Bit-exact by construction: pixels are copied, never summed."""
 
-    def __init__(self, width, height, rank, world, device, tile=32, dst=0, n_buffers=2, overlap=True):
+    def __init__(self, width, height, rank, world, device, tile=32, dst=0, n_buffers=2, overlap=True, engine=None):
         import torch
         self.torch = torch
         self.w, self.h, self.rank, self.world, self.dst = width, height, rank, world, dst
         self.device = torch.device(device)
-        self.idx = [torch.from_numpy(owned_pixel_index(width, height, r, world, tile)).to(self.device) if (r == rank or rank == dst) else None
-                    for r in range(world)]
-        self.n_max = max(len(owned_pixel_index(width, height, r, world, tile)) for r in range(world))
+        self.engine = engine
+        if engine is not None:
+            self.idx = None
+            self.n_max = max(engine.packed_slots(r, world) for r in range(world))
+        else:
+            self.idx = [torch.from_numpy(owned_pixel_index(width, height, r, world, tile)).to(self.device) if (r == rank or rank == dst) else None
+                        for r in range(world)]
+            self.n_max = max(len(owned_pixel_index(width, height, r, world, tile)) for r in range(world))
         self.send = [torch.zeros((self.n_max, 4), dtype=torch.float32, device=self.device) for _ in range(n_buffers)]
         self.recv = [[torch.empty((self.n_max, 4), dtype=torch.float32, device=self.device) for _ in range(world)] for _ in range(n_buffers)] \
             if rank == dst else None
@@ -118,37 +127,49 @@ class FrameGatherer:
         self.turn = 0
         self.posted = False
 
+    def _stream_handle(self, stream):
+        return stream.cuda_stream if (self.cuda and stream is not None) else None
+
     def post(self, frame):
         import torch.distributed as dist
         torch = self.torch
         b = self.turn % len(self.send)
         self.turn += 1
-        own = self.idx[self.rank]
+        cur = torch.cuda.current_stream(self.device) if self.cuda else None
         if self.side is not None and self.free_ev[b] is not None:
-            torch.cuda.current_stream(self.device).wait_event(self.free_ev[b])
-        if own.numel():
-            torch.index_select(frame.view(-1, 4), 0, own, out=self.send[b][: own.numel()])
+            cur.wait_event(self.free_ev[b])
+        if self.engine is not None:
+            # the engine reads its own accumulation buffer (`frame` is that buffer); ordered on the current stream
+            self.engine.pack_owned(self.send[b].data_ptr(), self._stream_handle(cur))
+        else:
+            own = self.idx[self.rank]
+            if own.numel():
+                torch.index_select(frame.view(-1, 4), 0, own, out=self.send[b][: own.numel()])
         if self.side is not None:
             ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
+            ready.record(cur)
             self.side.wait_event(ready)
             with torch.cuda.stream(self.side):
-                self._exchange(b, dist)
+                self._exchange(b, dist, self.side)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self.free_ev[b] = ev
         else:
-            self._exchange(b, dist)
+            self._exchange(b, dist, cur)
         self.posted = True
 
-    def _exchange(self, b, dist):
+    def _exchange(self, b, dist, stream):
         dist.gather(self.send[b], self.recv[b] if self.rank == self.dst else None, dst=self.dst)
         if self.rank == self.dst:
-            flat = self.full.view(-1, 4)
-            for r in range(self.world):
-                n = self.idx[r].numel()
-                if n:
-                    flat.index_copy_(0, self.idx[r], self.recv[b][r][:n])
+            if self.engine is not None:
+                for r in range(self.world):
+                    self.engine.unpack(r, self.world, self.recv[b][r].data_ptr(), self.full.data_ptr(), self._stream_handle(stream))
+            else:
+                flat = self.full.view(-1, 4)
+                for r in range(self.world):
+                    n = self.idx[r].numel()
+                    if n:
+                        flat.index_copy_(0, self.idx[r], self.recv[b][r][:n])
 
     def finish(self):
         """Join the side stream into the current one; returns the assembled frame on `dst`, None elsewhere."""

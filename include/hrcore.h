@@ -389,6 +389,21 @@ int hr_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, voi
 int hr_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t format, const void **pixels, int32_t *width,
                         int32_t *height);
 
+/* ------------------------------------------------------------------ tile-shard exchange
+ * The "RCCL reduce of the HDR accumulation buffer" of the north-star, done as a gather of the tiles each rank
+ * owns (world x fewer bytes than summing full frames, and exact: pixels are copied, never added).  These two
+ * calls are the device-side ends of it; the collective in between is the caller's (bench.py: RCCL gather).
+ * Pixel order = the order libhrcore enumerates a rank's pixels in (tile by tile, 8x8 blocks inside a tile);
+ * both ends use it, nobody else needs to know it.  Slots of pixels outside a cropped edge tile hold zeros. */
+/* number of float4 slots hr_frame_pack_owned writes for `rank` of `world` at the ctx's frame size and tile size */
+int hr_frame_packed_slots(hr_ctx *ctx, int32_t rank, int32_t world, uint64_t *n_slots);
+/* this context's owned pixels -> device_out (n_slots x RGBA32F); asynchronous on `stream` (a hipStream_t; NULL = the
+ * ctx stream, which orders it after the passes resolved so far — the pipeline is NOT drained: progressive display) */
+int hr_frame_pack_owned(hr_ctx *ctx, void *device_out, void *stream);
+/* rank `src_rank`'s packed pixels -> their place in a full-frame RGBA32F buffer (width*height*16 B); asynchronous on
+ * `stream` (NULL = the ctx stream), e.g. the side stream the collective ran on */
+int hr_frame_unpack(hr_ctx *ctx, int32_t src_rank, int32_t world, const void *device_packed, void *device_full_frame, void *stream);
+
 /* ------------------------------------------------------------------ debug */
 
 typedef struct hr_hit {

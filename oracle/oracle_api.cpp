@@ -24,6 +24,27 @@ struct hr_ctx {
         return (code);           \
     } while (0)
 
+// ---- tile-shard exchange helpers: same pixel enumeration as libhrcore (tile by tile, 8x8 blocks inside a tile)
+static uint64_t packedSlots(const Context &c, int rank, int world)
+{
+    const int tile = c.tile > 0 ? c.tile : 32;
+    const int tilesX = (c.W + tile - 1) / tile, tilesY = (c.H + tile - 1) / tile, nTiles = tilesX * tilesY;
+    const int owned = nTiles > rank ? (nTiles - rank + world - 1) / world : 0;
+    return (uint64_t)owned * (uint64_t)(tile * tile);
+}
+template <class F> static void forEachPackedSlot(const Context &c, int rank, int world, F f)
+{
+    const int tile = c.tile > 0 ? c.tile : 32, tilesX = (c.W + tile - 1) / tile, bpr = tile >> 3;
+    const uint64_t n = packedSlots(c, rank, world);
+    for (uint64_t gid = 0; gid < n; ++gid) {
+        const uint32_t perTile = (uint32_t)(tile * tile), slot = (uint32_t)(gid / perTile), within = (uint32_t)(gid % perTile);
+        const int tileId = rank + (int)slot * world, tx = tileId % tilesX, ty = tileId / tilesX;
+        const int blk = (int)(within >> 6), l = (int)(within & 63u);
+        const int x = tx * tile + (blk % bpr) * 8 + (l & 7), y = ty * tile + (blk / bpr) * 8 + (l >> 3);
+        f(gid, x < c.W && y < c.H, (size_t)y * c.W + x);
+    }
+}
+
 extern "C" {
 
 int ora_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
@@ -294,6 +315,38 @@ int ora_readback(hr_ctx *ctx, const float **rgba, int32_t *w, int32_t *h)
     if (h) *h = ctx->c.H;
     return HR_OK;
 }
+int ora_frame_packed_slots(hr_ctx *ctx, int32_t rank, int32_t world, uint64_t *n)
+{
+    if (!n || world <= 0 || rank < 0 || rank >= world) ORA_FAIL(ctx, HR_ERR_INVALID, "bad rank / world");
+    if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
+    *n = packedSlots(ctx->c, rank, world);
+    return HR_OK;
+}
+int ora_frame_pack_owned(hr_ctx *ctx, void *out, void *)
+{
+    if (!out) ORA_FAIL(ctx, HR_ERR_INVALID, "null output");
+    if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
+    float *o = (float *)out;
+    const float *fb = ctx->c.fb.data();
+    forEachPackedSlot(ctx->c, ctx->c.rank, ctx->c.world, [&](uint64_t gid, bool in, size_t pixel) {
+        for (int k = 0; k < 4; ++k) o[4 * gid + k] = in ? fb[4 * pixel + k] : 0.0f;
+    });
+    return HR_OK;
+}
+int ora_frame_unpack(hr_ctx *ctx, int32_t rank, int32_t world, const void *packed, void *full, void *)
+{
+    if (!packed || !full) ORA_FAIL(ctx, HR_ERR_INVALID, "null argument");
+    if (world <= 0 || rank < 0 || rank >= world) ORA_FAIL(ctx, HR_ERR_INVALID, "bad rank / world");
+    if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
+    const float *p = (const float *)packed;
+    float *f = (float *)full;
+    forEachPackedSlot(ctx->c, rank, world, [&](uint64_t gid, bool in, size_t pixel) {
+        if (in)
+            for (int k = 0; k < 4; ++k) f[4 * pixel + k] = p[4 * gid + k];
+    });
+    return HR_OK;
+}
+
 int ora_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *out)
 {
     if (!params || !out) ORA_FAIL(ctx, HR_ERR_INVALID, "null argument");

@@ -39,6 +39,13 @@ def _worker(rank, world, port, width, height, passes, q):
         for k in range(3):
             g.post(frame * float(k + 1))
         posted = g.finish()
+        # the same exchange through the engine's own pack / unpack entry points (here the oracle's, on host memory)
+        ge = tiles.FrameGatherer(width, height, rank, world, "cpu", n_buffers=2, engine=eng)
+        ge.post(frame)
+        ge.post(frame)
+        via_engine = ge.finish()
+        if rank == 0:
+            assert via_engine.numpy().tobytes() == gathered.numpy().tobytes()
         assert bool((frame[..., 3][~own] == 0).all())  # the local accumulator is untouched by the collectives
         if rank == 0:
             q.put((reduced.numpy(), gathered.numpy(), posted.numpy()))

@@ -5,9 +5,14 @@ import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_trace", "k_shade", "k_raygen", "k_resolve"))]
+if "--all" not in sys.argv:
+    rows = [r for r in rows if any(k in r["Kernel_Name"] for k in ("k_trace", "k_shade", "k_raygen", "k_resolve"))]
+sys.argv = [a for a in sys.argv if a != "--all"]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 first = int(sys.argv[2]) if len(sys.argv) > 2 else len(rows) // 2
+if first < 0:  # negative: start at the |first|-th k_trace launch
+    tr = [i for i, r in enumerate(rows) if "k_trace" in r["Kernel_Name"]]
+    first = tr[min(-first, len(tr) - 1)]
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 t0 = int(rows[first]["Start_Timestamp"])
 prev_end = t0
