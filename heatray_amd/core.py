@@ -20,7 +20,7 @@ def load_library():
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         _LIB = ctypes.CDLL(LIB_PATH)
         missing = [s for s in ABI_SYMBOLS if not hasattr(_LIB, "hr_" + s)]
-        if missing:
+        if missing and not (os.environ.get("HRCORE_LIB") and os.environ.get("HRCORE_ALLOW_OLD_ABI")):  # A/B against older builds only
             raise EngineError(f"libhrcore.so lacks C-ABI symbols: {missing}")
     return _LIB
 

@@ -35,7 +35,7 @@ struct Geom {
 
 } // namespace
 
-static const int kMaxGroups = 4;
+static const int kMaxGroups = 3;
 static const int kMaxSlots = 2 * kMaxSegs; // passes in flight over all groups
 
 struct hr_ctx {
@@ -93,6 +93,7 @@ struct hr_ctx {
     Group groups[kMaxGroups];
     int nGroups = 2;      // groups in use: chosen per frame size in hr_frame_resize unless HR_TUNE fixes it
     int tuneGroups = 0;   // HR_TUNE="groups=N" (0 = automatic)
+    int tunePrio = 1;     // HR_TUNE="prio=0": worker streams at normal priority
     int tuneBlocksSet = 0; // HR_TUNE="blocks=N" given
     int nextGroup = 0;
     unsigned long long nextResolveOrder = 0;
@@ -287,7 +288,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -295,6 +296,16 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
     bool groupsOk = true;
     for (int g = 0; g < kMaxGroups; ++g) {
         hr_ctx::Group &G = c->groups[g];
+        // Worker streams at the highest stream priority, created before anything else uses the device queues: HIP maps the
+        // streams of one priority to a small pool of hardware queues, and two groups that land on the same queue do not
+        // overlap at all — which happened as soon as the application had a few streams of its own (torch side stream, RCCL).
+        // The high-priority pool is practically empty, so the groups get a hardware queue each.  (Creating them lazily, at
+        // the first macro step, measurably loses overlap on half- and quarter-frame shards.)
+        {
+            int least = 0, greatest = 0;
+            groupsOk = groupsOk && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+            groupsOk = groupsOk && hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, c->tunePrio ? greatest : 0) == hipSuccess;
+        }
         groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipEventCreateWithFlags(&G.evUser, hipEventDisableTiming) == hipSuccess;
@@ -1022,15 +1033,6 @@ static int resolveReady(hr_ctx *c)
 static int macroStep(hr_ctx *c, int g, int nInject)
 {
     hr_ctx::Group &G = c->groups[g];
-    if (!G.stream) {
-        // Worker streams are created on first use, at the highest stream priority: HIP maps the streams of one priority
-        // to a small pool of hardware queues, and two groups that land on the same queue do not overlap at all — which is
-        // what happened as soon as the application had a few streams of its own (torch side stream, RCCL).  The high
-        // priority pool is practically empty, so the groups get a hardware queue each.
-        int least = 0, greatest = 0;
-        HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_TRY(c, hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, greatest));
-    }
     const LaunchCfg cfg = c->cfg(G.stream);
     FrameDev fr = c->frame;
     fr.fb = c->fb();
