@@ -359,6 +359,19 @@ def test_error_paths(gpu):
         e.add_mesh(np.zeros((3, 3)), np.zeros((3, 3)), [0, 1, 5])  # index out of range
     with pytest.raises(ffi.EngineError):
         core.create_engine(rank=2, world=2)
+    # shard-exchange entry points: argument checks before anything is launched
+    f = core.create_engine()
+    with pytest.raises(ffi.EngineError):
+        f.packed_slots(0, 1)                              # no frame yet
+    f.resize(40, 24)
+    assert f.packed_slots(0, 1) == 2 * 1 * 32 * 32        # 2 x 1 tiles of 32 x 32 slots (edge tiles padded)
+    assert f.packed_slots(1, 2) == 32 * 32 and f.packed_slots(2, 3) == 0
+    with pytest.raises(ffi.EngineError):
+        f.packed_slots(2, 2)
+    with pytest.raises(ffi.EngineError):
+        f.pack_owned(0)                                   # null output
+    with pytest.raises(ffi.EngineError):
+        f.unpack(0, 0, 1, 1)                              # world 0
 
 
 # ------------------------------------------------------------- full BASELINE sizes: properties
