@@ -574,8 +574,9 @@ HRD float haltonValue(uint32_t index, int base) // Random.h:192-204
 __constant__ int kHaltonBases[16][2] = {{2, 3},  {2, 5},  {2, 7},  {3, 7}, {4, 5},   {5, 7},  {5, 9},  {5, 11},
                                         {6, 11}, {5, 11}, {8, 11}, {3, 5}, {11, 15}, {2, 15}, {3, 19}, {7, 10}}; // Random.h:172-189
 
-// owenScrambleSequence (Random.h:85-108) with sobol / halton / hammersley generators; radial: Random.h:268-289
-__global__ __launch_bounds__(256) void k_qmc(int mode, uint32_t sequenceIndex, uint32_t count, int radial, float2 *__restrict__ out)
+// owenScrambleSequence (Random.h:85-108) with sobol / halton / hammersley generators (radialSobol's disk mapping,
+// Random.h:268-289, is applied on the host: hr_core.hip::radialOnHost)
+__global__ __launch_bounds__(256) void k_qmc(int mode, uint32_t sequenceIndex, uint32_t count, float2 *__restrict__ out)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
@@ -594,20 +595,13 @@ __global__ __launch_bounds__(256) void k_qmc(int mode, uint32_t sequenceIndex, u
     }
     float x = toNormalizedFloat(nestedUniformScramble(toUint32(sx), burleyHashCombine(seed, 0)));
     float y = toNormalizedFloat(nestedUniformScramble(toUint32(sy), burleyHashCombine(seed, 1)));
-    if (radial) {
-        const float sqrt_t = sqrt_(y);
-        float sn, cs;
-        sincos_(6.28318530717958647692f * x, &sn, &cs);
-        x = (sqrt_t * cs + 1.0f) * 0.5f;
-        y = (sqrt_t * sn + 1.0f) * 0.5f;
-    }
     out[i] = make_float2(x, y);
 }
 
-void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, int radial, float2 *out)
+void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, float2 *out)
 {
     if (count == 0) return;
-    hipLaunchKernelGGL(k_qmc, dim3((count + 255) / 256), dim3(256), 0, st, mode, sequenceIndex, count, radial, out);
+    hipLaunchKernelGGL(k_qmc, dim3((count + 255) / 256), dim3(256), 0, st, mode, sequenceIndex, count, out);
 }
 
 // ------------------------------------------------------------------------------ multiscatter LUT

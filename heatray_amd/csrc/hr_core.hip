@@ -821,6 +821,25 @@ int hr_seq_offsets_set(hr_ctx *c, const float *off, int32_t n)
     return HR_OK;
 }
 
+// radialSobol's disk mapping (Random.h:272-287).  The reference evaluates it with the C library's sqrtf / cosf / sinf, whose
+// last bit is libm-specific; it is therefore done on the host, with the same library the application itself would use, on the
+// device-generated Sobol points (which are bit-exact): the aperture tables then equal the reference's bit for bit.
+// (16 x maxRenderPasses points at initialisation time.)
+static void radialOnHost(float2 *p, size_t count)
+{
+    const float two_pi = 6.28318530717958647692f;
+    for (size_t i = 0; i < count; ++i) {
+        const float s = p[i].x, t = p[i].y;
+        const float sqrt_t = sqrtf(t);
+        const float two_pi_s = two_pi * s;
+        float x = sqrt_t * cosf(two_pi_s);
+        float y = sqrt_t * sinf(two_pi_s);
+        x = (x + 1.0f) * 0.5f;
+        y = (y + 1.0f) * 0.5f;
+        p[i] = make_float2(x, y);
+    }
+}
+
 int hr_qmc_generate(hr_ctx *c, int32_t mode, uint32_t seqIndex, uint32_t count, int32_t radial, float *out)
 {
     ENTER(c);
@@ -830,11 +849,12 @@ int hr_qmc_generate(hr_ctx *c, int32_t mode, uint32_t seqIndex, uint32_t count, 
     if (count == 0 || !out) FAIL(c, HR_ERR_INVALID, "bad count / output");
     float2 *d = nullptr;
     HIP_TRY(c, hipMalloc(&d, (size_t)count * sizeof(float2)));
-    launchQmc(c->stream, mode, seqIndex, count, radial, d);
+    launchQmc(c->stream, mode, seqIndex, count, d);
     hipError_t e = hipMemcpyAsync(out, d, (size_t)count * sizeof(float2), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d);
     HIP_TRY(c, e);
+    if (radial) radialOnHost(reinterpret_cast<float2 *>(out), count);
     return HR_OK;
 }
 
@@ -851,10 +871,18 @@ int hr_sequences_generate(hr_ctx *c, int32_t sampleMode, int32_t bokeh, int32_t 
     rc = setTable(c, &c->dAperture, nullptr, (size_t)nSeq * len);
     if (rc) return rc;
     for (int s = 0; s < nSeq; ++s) { // PassGenerator.cpp:614-662
-        launchQmc(c->stream, sampleMode, (uint32_t)s, (uint32_t)len, 0, c->dSeq + (size_t)s * len);
-        launchQmc(c->stream, HR_SAMPLE_SOBOL, (uint32_t)s, (uint32_t)len, 1, c->dAperture + (size_t)s * len);
+        launchQmc(c->stream, sampleMode, (uint32_t)s, (uint32_t)len, c->dSeq + (size_t)s * len);
+        launchQmc(c->stream, HR_SAMPLE_SOBOL, (uint32_t)s, (uint32_t)len, c->dAperture + (size_t)s * len);
     }
     HIP_TRY(c, hipGetLastError());
+    { // the aperture tables: Sobol points from the device, disk mapping on the host (see radialOnHost)
+        std::vector<float2> ap((size_t)nSeq * len);
+        HIP_TRY(c, hipMemcpyAsync(ap.data(), c->dAperture, ap.size() * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        radialOnHost(ap.data(), ap.size());
+        HIP_TRY(c, hipMemcpyAsync(c->dAperture, ap.data(), ap.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     c->nSeq = nSeq, c->seqLen = len;
     c->sceneDirty = true;
     return HR_OK;
@@ -867,7 +895,7 @@ int hr_seq_offsets_generate(hr_ctx *c)
     const size_t n = (size_t)c->W * c->H;
     int rc = setTable(c, &c->dSeqOffsets, nullptr, n);
     if (rc) return rc;
-    launchQmc(c->stream, HR_SAMPLE_SOBOL, 0, (uint32_t)n, 0, c->dSeqOffsets); // PassGenerator.cpp:150-159
+    launchQmc(c->stream, HR_SAMPLE_SOBOL, 0, (uint32_t)n, c->dSeqOffsets); // PassGenerator.cpp:150-159
     HIP_TRY(c, hipGetLastError());
     c->nSeqOffsets = (int)n;
     c->sceneDirty = true;
@@ -881,7 +909,7 @@ int hr_multiscatter_lut_generate(hr_ctx *c, float *out, hr_tex_id *outTex)
     float *lut = nullptr;
     HIP_TRY(c, hipMalloc(&seq, 4096 * sizeof(float2)));
     HIP_TRY(c, hipMalloc(&lut, 128 * 128 * sizeof(float)));
-    launchQmc(c->stream, HR_SAMPLE_SOBOL, 0, 4096, 0, seq); // MultiScatterUtil.cpp:102-104
+    launchQmc(c->stream, HR_SAMPLE_SOBOL, 0, 4096, seq); // MultiScatterUtil.cpp:102-104
     launchMultiscatterLUT(c->stream, seq, lut);
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess && out) e = hipMemcpy(out, lut, 128 * 128 * sizeof(float), hipMemcpyDeviceToHost);

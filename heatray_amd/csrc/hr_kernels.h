@@ -103,7 +103,7 @@ void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t n
 int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad,
               BuildResult *out);
 
-void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, int radial, float2 *out);
+void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, float2 *out);
 void launchMultiscatterLUT(hipStream_t st, const float2 *sobol4096, float *out128x128);
 
 } // namespace hr
