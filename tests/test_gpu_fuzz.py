@@ -145,3 +145,75 @@ def test_random_scene_parity(golden, seed):
     # and what the viewer would show of it
     P = ffi.display_params(tonemapping_enabled=bool(seed & 1), exposure=0.5 * (seed % 5 - 2), saturation=1.0 + 0.1 * (seed % 3))
     assert g.display(P, ffi.HR_DISPLAY_RGBA8).tobytes() == o.display(P, ffi.HR_DISPLAY_RGBA8).tobytes()
+
+
+def _clustered_soup(rng, n_tris):
+    """Triangles in tight clusters with log-uniform sizes over 5 decades: many identical Morton codes, deep and unbalanced
+    trees, large triangles spanning many cells next to tiny ones."""
+    n_cl = int(rng.integers(1, 12))
+    centres = rng.uniform(-1, 1, (n_cl, 3))
+    spread = 10.0 ** rng.uniform(-4, -0.5, n_cl)
+    which = rng.integers(0, n_cl, n_tris)
+    c = centres[which] + rng.normal(size=(n_tris, 3)) * spread[which, None]
+    size = 10.0 ** rng.uniform(-5, 0, n_tris)
+    e1 = rng.normal(size=(n_tris, 3)) * size[:, None]
+    e2 = rng.normal(size=(n_tris, 3)) * size[:, None] * 10.0 ** rng.uniform(-2, 0, (n_tris, 1))   # some needles
+    pos = np.stack([c, c + e1, c + e2], axis=1).astype(F)
+    return pos
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_traversal_vs_brute_force(seed):
+    rng = np.random.default_rng(500 + seed)
+    n_tris = int(rng.choice([7, 300, 2500, 9000, 20000]))
+    pos = _clustered_soup(rng, n_tris)
+    sc = scenes.Scene("clusters", width=16, height=16)
+    nrm = np.tile(np.array([0, 1, 0], F), (n_tris * 3, 1))
+    sc.materials[0] = host.bake_pbr()
+    sc.meshes.append(scenes.MeshData(pos.reshape(-1, 3), nrm, np.arange(n_tris * 3, dtype=np.uint32), material_id=0))
+    sc.use_multiscatter_lut = False
+    g, o = core.create_engine(), oracle_lib.engine()
+    for eng in (g, o):
+        sc.apply(eng)
+    oracle_lib.load().ora_set_brute_force(o._ctx, 1)
+    n = 12000
+    cent = pos.mean(axis=1)
+    org = (cent[rng.integers(0, n_tris, n)] + rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 0.5, (n, 1))).astype(F)
+    aim = cent[rng.integers(0, n_tris, n)] + rng.normal(size=(n, 3)) * 1e-4 - org
+    d = (aim / np.maximum(np.linalg.norm(aim, axis=1, keepdims=True), 1e-30)).astype(F)
+    hg, ho = g.debug_trace(org, d), o.debug_trace(org, d)
+    assert (ho["prim"] >= 0).sum() > n // 10
+    assert hg.tobytes() == ho.tobytes(), f"{(hg != ho).sum()} of {n} closest hits differ ({n_tris} triangles)"
+    tm = (10.0 ** rng.uniform(-3, 1, n)).astype(F)
+    ag = g.debug_trace(org, d, tmax=tm, skip_prim=ho["prim"], any_hit=True)
+    ao = o.debug_trace(org, d, tmax=tm, skip_prim=ho["prim"], any_hit=True)
+    assert ag.tobytes() == ao.tobytes()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_scene_modes_and_shards(golden, seed):
+    # the same random scenes under the per-pass modes (interactive 3x3 blocks, debug visualisers, NaN / Inf display) and as
+    # tile shards: every shard must render exactly its pixels of the full frame
+    rng = np.random.default_rng(7000 + seed)
+    sc = random_scene(2000 + seed)
+    sc.options.enable_interactive_mode = bool(rng.random() < 0.4)
+    sc.options.visualizer_mode = int(rng.choice([ffi.HR_VIS_NONE, ffi.HR_VIS_NONE] + [v for k, v in vars(ffi).items() if k.startswith("HR_VIS_") and k != "HR_VIS_NONE"]))
+    sc.options.show_nans, sc.options.show_inf = bool(rng.random() < 0.3), bool(rng.random() < 0.3)
+    world = int(rng.integers(1, 5))
+    tile = int(rng.choice([8, 16, 32, 64]))
+    full = None
+    acc = None
+    for rank in [-1] + list(range(world)):
+        kw = dict(tile_size=tile) if rank < 0 else dict(rank=rank, world=world, tile_size=tile)
+        g, o = core.create_engine(**kw), oracle_lib.engine(**kw)
+        for eng in (g, o):
+            sc.apply(eng, lut=golden["multiscatter_lut"])
+            for s in range(3):
+                eng.render_pass(sc.options.pass_params(s, current_block_pixel=(s % 3, (s // 3) % 3)))
+        a, b = g.readback(), o.readback()
+        assert a.tobytes() == b.tobytes(), f"seed {seed} rank {rank}/{world}: {int((a != b).any(axis=-1).sum())} pixels differ"
+        if rank < 0:
+            full = a
+        else:
+            acc = a.copy() if acc is None else acc + a
+    assert acc.tobytes() == full.tobytes()
