@@ -233,6 +233,11 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
 }
 
 
+#ifdef HR_TAILPROF
+// Experiment builds only: when does the work queue run dry, when does the launch end, how long is the longest ray?
+__device__ unsigned long long g_tailprof[8]; // [0] min start clock, [1] min exhaustion clock, [2] max end clock, [3] max steps of a ray, [4] sum steps, [5] rays
+#endif
+
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
                                                   StepTable *__restrict__ tbl, Stats *stats)
@@ -271,6 +276,12 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     uint32_t nvC = 0, ntC = 0, nvA = 0, ntA = 0, nacc = 0;
 
     int pend = 0; // postponed leaf (a negative leaf reference) or 0: the lane keeps descending while a leaf waits
+#ifdef HR_TAILPROF
+    const unsigned long long tStart = wall_clock64();
+    unsigned long long tExh = 0;
+    uint32_t mySteps = 0, maxSteps = 0;
+    unsigned long long sumSteps = 0, nRays = 0;
+#endif
     for (;;) {
         // ---------------- refill idle lanes (persistent threads with dynamic fetch)
         bool idle = (item == 0xFFFFFFFFu);
@@ -287,6 +298,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                     base = __shfl(base, 0);
                     if (base >= total) {
                         exhausted = true;
+#ifdef HR_TAILPROF
+                        tExh = wall_clock64();
+#endif
                         break;
                     }
                     lastBase = base;
@@ -349,6 +363,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                     else
                         ++nvC;
                 }
+#ifdef HR_TAILPROF
+                ++mySteps;
+#endif
                 const RayK rk{idx, idy, idz, oix, oiy, oiz};
                 nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny);
             }
@@ -423,9 +440,23 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
             } else {
                 sg.hits[local] = best;
             }
+#ifdef HR_TAILPROF
+            maxSteps = mySteps > maxSteps ? mySteps : maxSteps, sumSteps += mySteps, nRays += 1, mySteps = 0;
+#endif
             item = 0xFFFFFFFFu;
         }
     }
+#ifdef HR_TAILPROF
+    {
+        const unsigned long long tEnd = wall_clock64();
+        atomicMin(&g_tailprof[0], tStart);
+        if (tExh) atomicMin(&g_tailprof[1], tExh);
+        atomicMax(&g_tailprof[2], tEnd);
+        atomicMax(&g_tailprof[3], (unsigned long long)maxSteps);
+        atomicAdd(&g_tailprof[4], sumSteps);
+        atomicAdd(&g_tailprof[5], nRays);
+    }
+#endif
 
     nacc = waveSum(nacc);
     if (lane == 0 && nacc) atomicAdd(&stats->accumulates, (unsigned long long)nacc);
@@ -663,3 +694,16 @@ void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const floa
 size_t hitRecordSize() { return sizeof(HitRec); }
 
 } // namespace hr
+
+#ifdef HR_TAILPROF
+extern "C" int hr_debug_tailprof(unsigned long long *out8, int reset)
+{
+    hipDeviceSynchronize();
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hr::g_tailprof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {~0ull, ~0ull, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(hr::g_tailprof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
