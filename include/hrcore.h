@@ -342,11 +342,14 @@ typedef struct hr_kernel_times {
 /* replaces rlClear(RL_COLOR_BUFFER_BIT) (PassGenerator.cpp:439) */
 int hr_clear(hr_ctx *ctx);
 /* replaces rlRenderFrame() (PassGenerator.cpp:386): one sample per owned pixel.
- * Asynchronous on the ctx stream, and PIPELINED: up to max_ray_depth+2 passes are
- * kept in flight at different bounce stages; a pass's sample reaches the
- * accumulation buffer when its last stage has run, always in pass order.
- * hr_readback / hr_get_stats / hr_clear / hr_synchronize / hr_flush and every call
- * that changes scene state complete all enqueued passes first. */
+ * Asynchronous, and PIPELINED: passes are kept in flight at different bounce stages
+ * (max_ray_depth+2 stages per pass; on a small tile shard several passes are collected
+ * and injected together; the ray kernels run on internal streams ordered against the
+ * ctx stream by events).  A pass's sample reaches the accumulation buffer when its last
+ * stage has run — on the ctx stream, always in pass order — so the buffer only ever
+ * holds complete passes and its alpha channel says how many.
+ * hr_readback / hr_display / hr_get_stats / hr_clear / hr_synchronize / hr_flush and
+ * every call that changes scene state complete all enqueued passes first. */
 int hr_render_pass(hr_ctx *ctx, const hr_pass_params *params);
 /* enqueue the remaining stages of every pass in flight (asynchronous): after it, work
  * the caller puts on the ctx stream sees every requested sample in the buffer */
