@@ -161,7 +161,7 @@ def convergence_leg(core, sc, dev, stream, cap, n_runs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=128, help="timed passes (SURVEY 8d: at least 32); the pass pipeline is depth+2 stages deep, so short runs weigh its fill and drain")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=0)

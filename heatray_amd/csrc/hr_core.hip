@@ -497,13 +497,14 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         c->injectBatch = (int)(b < 1 ? 1 : (b > 16 ? 16 : b));
         if (c->tuneBatch > 0) c->injectBatch = c->tuneBatch;
         // Two pipeline groups (their steps alternate on two streams, so one group's trace tail and its shade / raygen run
-        // under the other group's trace) pay off while a pass fills the GPU reasonably: measured on MI355X +11..14 % on a
-        // full 1080p frame and on a 1/2 shard, +5 % on 1/4, -5 % on 1/8 (each group has its own pipeline fill and drain).
-        // With two resident trace kernels three workgroups per CU each are best, alone five.
+        // under the other group's trace) pay off up to one 1080p frame of paths per pass: measured on MI355X +11..14 % on a
+        // full 1080p frame and on a 1/2 shard, +5 % on 1/4; on a 1/8 shard +8 % at 64 passes and +16 % at 128, -5 % at 32 (each
+        // group has its own pipeline fill and drain: long runs — a viewer accumulates thousands of passes — are what counts).
         // Larger frames lose: 2560x1440 948 vs 1491 Mrays/s, 3840x2160 1141 vs 1344 (one trace launch already fills the GPU for
-        // several ms; two of them only compete for L1/L2), so two groups are used from a quarter up to one 1080p frame of paths.
-        const bool midSized = c->injectBatch <= 4 && c->queueCapacity <= 2200000u;
-        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (midSized ? 2 : 1);
+        // several ms; two of them only compete for L1/L2).  With two resident trace kernels three workgroups per CU each are
+        // best, alone five.
+        const bool upToOneFrame = c->queueCapacity <= 2200000u;
+        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (upToOneFrame ? 2 : 1);
         c->nextGroup = 0;
         if (!c->tuneBlocksSet) c->tuneBlocks = c->nGroups > 1 ? 3 : 5;
         c->pendingInject.clear();
