@@ -148,7 +148,7 @@ ABI_SYMBOLS = [
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
-    "display", "display_readback", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
+    "display", "display_readback", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
 ]
 
 
@@ -366,6 +366,13 @@ class Engine:
         """Asynchronous display resolve into device memory (e.g. a torch tensor or a GL-interop buffer)."""
         params = params if params is not None else display_params()
         self._call("display", C.byref(params), C.c_int32(fmt), C.c_void_p(int(device_ptr)))
+
+    def readback_progressive(self):
+        """(buffer copy, complete passes in it) without completing the passes still in the pipeline."""
+        p = f32p()
+        w, h, n = C.c_int32(), C.c_int32(), C.c_uint32()
+        self._call("readback_progressive", C.byref(p), C.byref(w), C.byref(h), C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy(), int(n.value)
 
     def debug_trace(self, origins, dirs, tmax=None, skip_prim=None, any_hit=False):
         o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)

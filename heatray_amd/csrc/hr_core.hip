@@ -97,6 +97,7 @@ struct hr_ctx {
     int tuneBlocksSet = 0; // HR_TUNE="blocks=N" given
     int nextGroup = 0;
     unsigned long long nextResolveOrder = 0;
+    unsigned long long resolvedAtClear = 0; // value of nextResolveOrder at the last hr_clear
     // Passes requested but not yet injected: when a shard is small (multi-GPU tiles, small frames) several passes are
     // injected per macro step so that every launch still carries about a full 1080p pass worth of rays.
     std::deque<hr_pass_params> pendingInject;
@@ -979,6 +980,7 @@ int hr_clear(hr_ctx *c)
     if (rc) return rc;
     HIP_TRY(c, hipMemsetAsync(c->fb(), 0, (size_t)c->W * c->H * 4 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats) * kStatSlots, c->stream));
+    c->resolvedAtClear = c->nextResolveOrder;
     c->drainTimes();
     for (int k = 0; k < HR_KERNEL_COUNT; ++k) c->kernelMs[k] = 0.0f, c->kernelLaunches[k] = 0;
     return HR_OK;
@@ -1331,6 +1333,21 @@ int hr_readback(hr_ctx *c, const float **rgba, int32_t *w, int32_t *h)
     *rgba = c->pinned;
     if (w) *w = c->W;
     if (h) *h = c->H;
+    return HR_OK;
+}
+
+int hr_readback_progressive(hr_ctx *c, const float **rgba, int32_t *w, int32_t *h, uint32_t *passes)
+{
+    ENTER(c);
+    if (c->W <= 0 || !rgba) FAIL(c, HR_ERR_INVALID, "no frame");
+    const size_t bytes = (size_t)c->W * c->H * 4 * sizeof(float);
+    // no drain: the resolves enqueued so far are ordered before this copy on the ctx stream
+    HIP_TRY(c, hipMemcpyAsync(c->pinned, c->fb(), bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *rgba = c->pinned;
+    if (w) *w = c->W;
+    if (h) *h = c->H;
+    if (passes) *passes = (uint32_t)(c->nextResolveOrder - c->resolvedAtClear);
     return HR_OK;
 }
 

@@ -272,7 +272,10 @@ void PassGenerator::runRenderFrameJob(const RenderOptions& newOptions)
         // the passes of one offline job overlap in libhrcore's pass pipeline.
         jobCompleted = !(m_renderOptions.enableOfflineMode && (m_currentSampleIndex < m_renderOptions.maxRenderPasses));
         if (jobCompleted) {
-            m_resultPixels->setPixelData();
+            // The last pass of a render (and every offline job) delivers the complete image; the passes in between are
+            // displayed progressively from what is complete already, so libhrcore's pass pipeline stays full.
+            const bool lastPass = m_currentSampleIndex >= m_renderOptions.maxRenderPasses;
+            m_resultPixels->setPixelData(lastPass || m_renderOptions.enableOfflineMode);
         }
 
         const float passTime = std::chrono::duration<float>(std::chrono::steady_clock::now() - start).count();

@@ -29,12 +29,22 @@ public:
         return std::shared_ptr<PixelPackBuffer>(new PixelPackBuffer(sizeInBytes));
     }
 
-    // Snapshot the accumulation buffer (device -> pinned host copy; completes every pass in flight first).
-    inline void setPixelData()
+    // Snapshot the accumulation buffer (device -> pinned host copy).
+    // complete = true: every pass requested so far is in the snapshot (libhrcore finishes the passes in its pipeline first).
+    // complete = false (progressive display while passes accumulate): the snapshot holds the passes that are complete
+    // already — alpha says how many — and the pipeline keeps running at full depth; if none is complete yet (right after a
+    // reset) it falls back to a complete snapshot, so the viewer never receives an empty buffer.
+    inline void setPixelData(bool complete = true)
     {
         assert(!m_isMapped);
         int32_t w = 0, h = 0;
-        if (HRFunc(hr_readback(currentContext(), &m_pixels, &w, &h))) {
+        bool ok = false;
+        if (!complete) {
+            uint32_t passes = 0;
+            ok = HRFunc(hr_readback_progressive(currentContext(), &m_pixels, &w, &h, &passes)) && passes > 0;
+        }
+        if (!ok) ok = HRFunc(hr_readback(currentContext(), &m_pixels, &w, &h));
+        if (ok) {
             m_width = w;
             m_height = h;
         }

@@ -362,6 +362,12 @@ int hr_get_kernel_times(hr_ctx *ctx, hr_kernel_times *out);
  * synchronous copy to a pinned host buffer owned by the ctx; the pointer stays
  * valid until the next hr_readback / hr_frame_resize / hr_ctx_destroy. */
 int hr_readback(hr_ctx *ctx, const float **rgba, int32_t *width, int32_t *height);
+/* Progressive variant for a viewer that refreshes while passes accumulate: does NOT complete the passes still in the
+ * pipeline (hr_readback does, which costs the pipeline's depth in latency for every displayed frame); copies the
+ * accumulation buffer as it stands — complete passes only, `passes_in_buffer` of them since the last hr_clear (the alpha
+ * channel holds the same number) — and synchronises the ctx stream.  Returns passes_in_buffer = 0 while the first passes
+ * after a clear are still in flight: call hr_readback then (PixelPackBuffer::setPixelData does). */
+int hr_readback_progressive(hr_ctx *ctx, const float **rgba, int32_t *width, int32_t *height, uint32_t *passes_in_buffer);
 int hr_synchronize(hr_ctx *ctx);
 
 /* ------------------------------------------------------------------ display resolve

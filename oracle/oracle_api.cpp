@@ -16,6 +16,7 @@ struct hr_ctx {
     Context c;
     int nThreads = 0;
     std::vector<float> display; // ora_display_readback's buffer (16 bytes per pixel)
+    uint32_t passesSinceClear = 0;
 };
 
 #define ORA_FAIL(ctx, code, msg) \
@@ -288,6 +289,7 @@ int ora_clear(hr_ctx *ctx)
 {
     std::fill(ctx->c.fb.begin(), ctx->c.fb.end(), 0.0f);
     ctx->c.stats = hr_pass_stats{};
+    ctx->passesSinceClear = 0;
     return HR_OK;
 }
 int ora_render_pass(hr_ctx *ctx, const hr_pass_params *pp)
@@ -299,6 +301,7 @@ int ora_render_pass(hr_ctx *ctx, const hr_pass_params *pp)
     if (c.nSeq <= 0 || c.seqOffsets.empty()) ORA_FAIL(ctx, HR_ERR_INVALID, "sample tables not set");
     auto t0 = std::chrono::steady_clock::now();
     renderPass(c, *pp, ctx->nThreads);
+    ctx->passesSinceClear++;
     c.stats.ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return HR_OK;
 }
@@ -366,6 +369,12 @@ int ora_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t f
     if (w) *w = ctx->c.W;
     if (h) *h = ctx->c.H;
     return HR_OK;
+}
+int ora_readback_progressive(hr_ctx *ctx, const float **rgba, int32_t *w, int32_t *h, uint32_t *passes)
+{
+    int rc = ora_readback(ctx, rgba, w, h); // the oracle has no pipeline: every requested pass is in the buffer
+    if (rc == HR_OK && passes) *passes = ctx->passesSinceClear;
+    return rc;
 }
 int ora_synchronize(hr_ctx *) { return HR_OK; }
 int ora_flush(hr_ctx *) { return HR_OK; }

@@ -308,6 +308,7 @@ int main(int argc, char** argv)
         float red = 1.1f, green = 0.9f, blue = 1.0f, vignetteIntensity = 0.5f, vignetteFalloff = 0.4f;
     } post;
     size_t lastIndex = 0;
+    float lastSamples = 0.0f;
     for (int p = 0; p < passes; ++p) {
         options.resetInternalState = (p == 0);
         renderer.renderPass(options, [&](bool frameDataAvailable, std::shared_ptr<openrl::PixelPackBuffer> results, float passTime, size_t passIndex) {
@@ -315,6 +316,12 @@ int main(int argc, char** argv)
             CHECK(results->width() == width && results->height() == height);
             const float* mapped = results->mapPixelData(); // left mapped, like the viewer does between frames
             pixels.assign(mapped, mapped + (size_t)width * height * 4);
+            // progressive display: complete passes only, at least one, never more than requested; the last one is complete
+            const float samples = pixels[3];
+            CHECK(samples >= 1.0f && samples <= float(passIndex));
+            CHECK(samples >= lastSamples);
+            if (passIndex == (size_t)passes) CHECK(samples == float(passes));
+            lastSamples = samples;
             // display-ready pixels from the device (the extension of SURVEY §8f row 1)
             const uint32_t* shown = (const uint32_t*)results->resolveForDisplay(openrl::PixelPackBuffer::displayParams(post), HR_DISPLAY_RGBA8);
             CHECK(shown != nullptr);

@@ -20,7 +20,7 @@ EXE = os.path.join(ROOT, "tests", "host", "host_layer_test")
 
 def test_host_layer_render_matches_oracle(tmp_path, golden):
     assert os.path.exists(EXE), "tests/host/host_layer_test not built (python -c 'import __graft_entry__ as g; g.build()')"
-    W, H, depth, passes = 96, 54, 6, 3
+    W, H, depth, passes = 96, 54, 6, 16   # = maxRenderPasses of the layer test: the last pass delivers the complete image
     sp, sn, suv, si = scenes.uv_sphere(16, 16, 1.0)
     pp, pn, puv, pi = scenes.plane_strip(15, 15)
     meshes = [  # (strip, material, transform, pos, nrm, uv, idx)

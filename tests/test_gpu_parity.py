@@ -594,3 +594,40 @@ def test_scene_edit_sequences_keep_parity(golden):
     both(lambda e: (e.remove_mesh(ids[0]), e.commit()))
     check("after removing it")
     assert g.scene_info().n_triangles == o.scene_info().n_triangles
+
+
+@pytest.mark.parametrize("tune,passes", [("batch=1", 24), ("", 288)])
+def test_progressive_readback_never_drains_and_holds_complete_passes(golden, monkeypatch, tune, passes):
+    # hr_readback_progressive: whatever is in the buffer is a prefix of the passes, complete, bit-identical to the oracle's
+    # image of that many passes; the pipeline is not completed by it
+    # (a frame this small injects 16 passes at a time into two groups unless HR_TUNE says otherwise)
+    monkeypatch.setenv("HR_TUNE", tune)
+    sc = scenes.multi_material(64, 48, bounces=4, passes=320)
+    g, o = core.create_engine(), oracle_lib.engine()
+    oracle_lib.load().ora_set_threads(o._ctx, 16)
+    for eng in (g, o):
+        sc.apply(eng, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    oracle_frames = {}
+    for s in range(passes):
+        o.render_pass(sc.options.pass_params(s))
+        oracle_frames[s + 1] = o.readback()
+    seen = []
+    for s in range(passes):
+        g.render_pass(sc.options.pass_params(s))
+        buf, n = g.readback_progressive()
+        assert 0 <= n <= s + 1
+        if n:
+            assert (buf[..., 3] == n).all()
+            assert buf.tobytes() == oracle_frames[n].tobytes()
+        else:
+            assert (buf == 0).all()
+        seen.append(n)
+    assert seen == sorted(seen) and seen[-1] < passes      # lags behind: the pipeline was never completed
+    assert max(seen) > 0
+    full = g.readback()                                        # this one completes everything
+    assert full.tobytes() == oracle_frames[passes].tobytes()
+    _, n = g.readback_progressive()
+    assert n == passes
+    g.clear()
+    _, n = g.readback_progressive()
+    assert n == 0
