@@ -133,6 +133,7 @@ def display_params(tonemapping_enabled=False, exposure=0.0, brightness=0.0, cont
 
 
 HR_DISPLAY_RGBA8, HR_DISPLAY_RGBA32F, HR_DISPLAY_HDR_RGBA32F = 0, 1, 2
+HR_DISPLAY_PROGRESSIVE = 0x100
 
 
 class Hit(C.Structure):
@@ -332,16 +333,17 @@ class Engine:
     def synchronize(self):
         self._call("synchronize")
 
-    def readback(self):
+    def readback(self, copy=True):
         p = f32p()
         w, h = C.c_int32(), C.c_int32()
         self._call("readback", C.byref(p), C.byref(w), C.byref(h))
-        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy()
+        a = np.ctypeslib.as_array(p, shape=(h.value, w.value, 4))
+        return a.copy() if copy else a
 
     def display(self, params=None, fmt=HR_DISPLAY_RGBA8):
         """Display resolve of the accumulation buffer -> numpy: uint8 [H, W, 4] (RGBA8) or float32 [H, W, 4]."""
         params = params if params is not None else display_params()
-        dt, ch = (np.uint8, 4) if fmt == HR_DISPLAY_RGBA8 else (np.float32, 4)
+        dt, ch = (np.uint8, 4) if (fmt & 0xFF) == HR_DISPLAY_RGBA8 else (np.float32, 4)
         p = C.c_void_p()
         w, h = C.c_int32(), C.c_int32()
         self._call("display_readback", C.byref(params), C.c_int32(fmt), C.byref(p), C.byref(w), C.byref(h))
@@ -367,12 +369,14 @@ class Engine:
         params = params if params is not None else display_params()
         self._call("display", C.byref(params), C.c_int32(fmt), C.c_void_p(int(device_ptr)))
 
-    def readback_progressive(self):
-        """(buffer copy, complete passes in it) without completing the passes still in the pipeline."""
+    def readback_progressive(self, copy=True):
+        """(buffer, complete passes in it) without completing the passes still in the pipeline.  copy=False returns a view
+        of the context's pinned buffer (valid until the next readback)."""
         p = f32p()
         w, h, n = C.c_int32(), C.c_int32(), C.c_uint32()
         self._call("readback_progressive", C.byref(p), C.byref(w), C.byref(h), C.byref(n))
-        return np.ctypeslib.as_array(p, shape=(h.value, w.value, 4)).copy(), int(n.value)
+        a = np.ctypeslib.as_array(p, shape=(h.value, w.value, 4))
+        return (a.copy() if copy else a), int(n.value)
 
     def debug_trace(self, origins, dirs, tmax=None, skip_prim=None, any_hit=False):
         o, d = _f32(origins).reshape(-1, 3), _f32(dirs).reshape(-1, 3)

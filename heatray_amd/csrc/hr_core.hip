@@ -52,6 +52,22 @@ struct hr_ctx {
     float *pinned = nullptr;
     size_t pinnedBytes = 0;
     void *dDisplay = nullptr, *pinnedDisplay = nullptr; // display resolve: device staging + pinned host copy
+    // Progressive snapshots are handed out one call late from rotating buffers: the host then waits for a copy enqueued a
+    // whole call ago instead of for everything it has just enqueued, so the GPU always has the next step queued
+    // (waiting for the latest copy cost 0.8 ms of idle GPU per pass).
+    struct Lagged {
+        void *pinned[3] = {nullptr, nullptr, nullptr};
+        void *dev[3] = {nullptr, nullptr, nullptr}; // device staging (display snapshots only)
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        uint32_t passes[3] = {0, 0, 0};
+        unsigned long long epoch[3] = {0, 0, 0};
+        int32_t format[3] = {-1, -1, -1};
+        bool pending[3] = {false, false, false};
+        size_t bytes = 0;
+        int turn = 0;
+    };
+    Lagged progFrame, progDisplay;
+    unsigned long long snapshotEpoch = 1; // bumped by clear / resize / bind: older snapshots are not handed out any more
     size_t displayBytes = 0;
     FrameDev frame{};
     uint32_t queueCapacity = 0;
@@ -229,6 +245,48 @@ static int quiesce(hr_ctx *c)
         int rc_ = quiesce(ctx);   \
         if (rc_) return rc_;      \
     } while (0)
+
+static int occupiedSlots(const hr_ctx *c, int group = -1);
+static void freeLagged(hr_ctx::Lagged &L)
+{
+    for (int k = 0; k < 3; ++k) {
+        if (L.pinned[k]) hipHostFree(L.pinned[k]);
+        hipFree(L.dev[k]);
+        if (L.ev[k]) hipEventDestroy(L.ev[k]);
+        L.pinned[k] = nullptr, L.dev[k] = nullptr, L.ev[k] = nullptr, L.pending[k] = false;
+    }
+    L.bytes = 0;
+}
+
+static int ensureLagged(hr_ctx *c, hr_ctx::Lagged &L, size_t bytes, bool withDevice)
+{
+    if (L.bytes >= bytes && (!withDevice || L.dev[0])) return HR_OK;
+    freeLagged(L);
+    for (int k = 0; k < 3; ++k) {
+        HIP_TRY(c, hipHostMalloc(&L.pinned[k], bytes, hipHostMallocDefault));
+        if (withDevice) HIP_TRY(c, hipMalloc(&L.dev[k], bytes));
+        HIP_TRY(c, hipEventCreateWithFlags(&L.ev[k], hipEventDisableTiming));
+    }
+    L.bytes = bytes;
+    return HR_OK;
+}
+
+// slot to fill now; afterwards `finishLagged` picks what to hand out
+static int beginLagged(hr_ctx::Lagged &L) { return L.turn++ % 3; }
+static int finishLagged(hr_ctx *c, hr_ctx::Lagged &L, int k, int32_t format, const void **out, uint32_t *passes)
+{
+    HIP_TRY(c, hipEventRecord(L.ev[k], c->stream));
+    L.pending[k] = true, L.epoch[k] = c->snapshotEpoch, L.format[k] = format;
+    L.passes[k] = (uint32_t)(c->nextResolveOrder - c->resolvedAtClear);
+    const int prev = (k + 2) % 3;
+    // nothing in flight (e.g. right after a complete readback): the current snapshot is final, hand it out itself
+    const bool idle = c->pendingInject.empty() && occupiedSlots(c) == 0;
+    const int use = (!idle && L.pending[prev] && L.epoch[prev] == c->snapshotEpoch && L.format[prev] == format && L.passes[prev] > 0) ? prev : k;
+    HIP_TRY(c, hipEventSynchronize(L.ev[use]));
+    *out = L.pinned[use];
+    if (passes) *passes = L.passes[use];
+    return HR_OK;
+}
 
 static void freeQueues(hr_ctx *c)
 {
@@ -414,9 +472,13 @@ int hr_display(hr_ctx *c, const hr_display_params *params, int32_t format, void 
     ENTER(c);
     if (!params || !device_out) FAIL(c, HR_ERR_INVALID, "null argument");
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    const bool progressive = (format & HR_DISPLAY_PROGRESSIVE) != 0;
+    format &= ~HR_DISPLAY_PROGRESSIVE;
     if (format < HR_DISPLAY_RGBA8 || format > HR_DISPLAY_HDR_RGBA32F) FAIL(c, HR_ERR_INVALID, "unknown display format");
-    int rc = drainPipeline(c);
-    if (rc) return rc;
+    if (!progressive) {
+        int rc = drainPipeline(c);
+        if (rc) return rc;
+    }
     FrameDev fr = c->frame;
     fr.fb = c->fb();
     launchDisplay(c->cfg(c->stream), fr, *params, format, device_out);
@@ -438,9 +500,26 @@ int hr_display_readback(hr_ctx *c, const hr_display_params *params, int32_t form
         HIP_TRY(c, hipHostMalloc(&c->pinnedDisplay, need, hipHostMallocDefault));
         c->displayBytes = need;
     }
+    if (format & HR_DISPLAY_PROGRESSIVE) { // lagged, like hr_readback_progressive
+        int rc = ensureLagged(c, c->progDisplay, need, true);
+        if (rc) return rc;
+        const int k = beginLagged(c->progDisplay);
+        rc = hr_display(c, params, format, c->progDisplay.dev[k]);
+        if (rc) return rc;
+        const size_t nb = (size_t)c->W * c->H * displayPixelBytes(format & ~HR_DISPLAY_PROGRESSIVE);
+        HIP_TRY(c, hipMemcpyAsync(c->progDisplay.pinned[k], c->progDisplay.dev[k], nb, hipMemcpyDeviceToHost, c->stream));
+        // the parameters are part of the snapshot's identity: a change of settings must not hand out an old image
+        int32_t key = format;
+        for (size_t i = 0; i < sizeof(*params) / 4; ++i) key = key * 31 + ((const int32_t *)params)[i];
+        rc = finishLagged(c, c->progDisplay, k, key, pixels, nullptr);
+        if (rc) return rc;
+        if (width) *width = c->W;
+        if (height) *height = c->H;
+        return HR_OK;
+    }
     int rc = hr_display(c, params, format, c->dDisplay);
     if (rc) return rc;
-    const size_t bytes = (size_t)c->W * c->H * displayPixelBytes(format);
+    const size_t bytes = (size_t)c->W * c->H * displayPixelBytes(format & ~HR_DISPLAY_PROGRESSIVE);
     HIP_TRY(c, hipMemcpyAsync(c->pinnedDisplay, c->dDisplay, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     *pixels = c->pinnedDisplay;
@@ -463,6 +542,8 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
     if (w <= 0 || h <= 0 || (long long)w * h > (1ll << 28)) FAIL(c, HR_ERR_INVALID, "bad frame size");
     QUIESCE(c);
     c->W = w, c->H = h;
+    c->snapshotEpoch++;
+    freeLagged(c->progFrame), freeLagged(c->progDisplay);
     hipFree(c->fbInternal);
     c->fbInternal = nullptr;
     c->fbExternal = nullptr;
@@ -519,6 +600,7 @@ int hr_frame_bind_external(hr_ctx *c, void *deviceRgba)
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
     QUIESCE(c);
     c->fbExternal = (float *)deviceRgba;
+    c->snapshotEpoch++;
     return HR_OK;
 }
 
@@ -981,6 +1063,7 @@ int hr_clear(hr_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->fb(), 0, (size_t)c->W * c->H * 4 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats) * kStatSlots, c->stream));
     c->resolvedAtClear = c->nextResolveOrder;
+    c->snapshotEpoch++;
     c->drainTimes();
     for (int k = 0; k < HR_KERNEL_COUNT; ++k) c->kernelMs[k] = 0.0f, c->kernelLaunches[k] = 0;
     return HR_OK;
@@ -1010,7 +1093,7 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
 }
 
 // passes that hold a slot: in flight, or finished and waiting for their turn to resolve
-static int occupiedSlots(const hr_ctx *c, int group = -1)
+static int occupiedSlots(const hr_ctx *c, int group)
 {
     int n = 0;
     for (const hr_ctx::PassSlot &ps : c->slots) n += ((ps.active || ps.finished) && (group < 0 || ps.group == group)) ? 1 : 0;
@@ -1342,12 +1425,16 @@ int hr_readback_progressive(hr_ctx *c, const float **rgba, int32_t *w, int32_t *
     if (c->W <= 0 || !rgba) FAIL(c, HR_ERR_INVALID, "no frame");
     const size_t bytes = (size_t)c->W * c->H * 4 * sizeof(float);
     // no drain: the resolves enqueued so far are ordered before this copy on the ctx stream
-    HIP_TRY(c, hipMemcpyAsync(c->pinned, c->fb(), bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    *rgba = c->pinned;
+    int rc = ensureLagged(c, c->progFrame, bytes, false);
+    if (rc) return rc;
+    const int k = beginLagged(c->progFrame);
+    HIP_TRY(c, hipMemcpyAsync(c->progFrame.pinned[k], c->fb(), bytes, hipMemcpyDeviceToHost, c->stream));
+    const void *out = nullptr;
+    rc = finishLagged(c, c->progFrame, k, 0, &out, passes);
+    if (rc) return rc;
+    *rgba = (const float *)out;
     if (w) *w = c->W;
     if (h) *h = c->H;
-    if (passes) *passes = (uint32_t)(c->nextResolveOrder - c->resolvedAtClear);
     return HR_OK;
 }
 

@@ -69,8 +69,10 @@ public:
     // setPixelData()/mapPixelData() are called (PassGenerator's worker thread, inside the completion callback).
     // format: HR_DISPLAY_RGBA8 (4 x fewer bytes over PCIe), HR_DISPLAY_RGBA32F or HR_DISPLAY_HDR_RGBA32F (saveScreenshot).
     // The pointer stays valid until the next resolveForDisplay(), resize or context destruction.
-    inline const void* resolveForDisplay(const hr_display_params& params, int32_t format = HR_DISPLAY_RGBA8)
+    // complete = false: progressive, like setPixelData(false) (pixels without a complete pass yet come out black).
+    inline const void* resolveForDisplay(const hr_display_params& params, int32_t format = HR_DISPLAY_RGBA8, bool complete = true)
     {
+        if (!complete) format |= HR_DISPLAY_PROGRESSIVE;
         const void* pixels = nullptr;
         int32_t w = 0, h = 0;
         if (HRFunc(hr_display_readback(currentContext(), &params, format, &pixels, &w, &h))) {

@@ -365,8 +365,10 @@ int hr_readback(hr_ctx *ctx, const float **rgba, int32_t *width, int32_t *height
 /* Progressive variant for a viewer that refreshes while passes accumulate: does NOT complete the passes still in the
  * pipeline (hr_readback does, which costs the pipeline's depth in latency for every displayed frame); copies the
  * accumulation buffer as it stands — complete passes only, `passes_in_buffer` of them since the last hr_clear (the alpha
- * channel holds the same number) — and synchronises the ctx stream.  Returns passes_in_buffer = 0 while the first passes
- * after a clear are still in flight: call hr_readback then (PixelPackBuffer::setPixelData does). */
+ * channel holds the same number).  Snapshots rotate through three pinned buffers and, while passes are in flight, the one
+ * handed out is the previous call's (so the host never waits for work it has only just enqueued); a pointer stays valid for
+ * two further calls.  Returns passes_in_buffer = 0 while the first passes after a clear are still in flight: call
+ * hr_readback then (PixelPackBuffer::setPixelData does). */
 int hr_readback_progressive(hr_ctx *ctx, const float **rgba, int32_t *width, int32_t *height, uint32_t *passes_in_buffer);
 int hr_synchronize(hr_ctx *ctx);
 
@@ -388,8 +390,10 @@ typedef struct hr_display_params {            /* HeatrayRenderer.h:104-117 PostP
 #define HR_DISPLAY_RGBA8 0       /* uint8 x 4, sRGB-encoded, alpha 255: what the GL framebuffer would hold        */
 #define HR_DISPLAY_RGBA32F 1     /* float x 4, the shader's fragColor before framebuffer conversion               */
 #define HR_DISPLAY_HDR_RGBA32F 2 /* float x 4, rgb * (1 / a), a unchanged: saveScreenshot's HDR path (.cpp:1624-1645) */
+#define HR_DISPLAY_PROGRESSIVE 0x100 /* OR into `format`: show the passes that are complete already instead of completing
+                                      * the ones still in the pipeline (see hr_readback_progressive) */
 
-/* Completes all enqueued passes, then writes width*height pixels (row 0 = bottom, like the accumulation
+/* Completes all enqueued passes (unless HR_DISPLAY_PROGRESSIVE), then writes width*height pixels (row 0 = bottom, like the accumulation
  * buffer) to device memory `device_out` (asynchronous on the ctx stream). Pixels without samples (a == 0) give
  * colour 0.  Pixels owned by other ranks of a tile-sharded frame are written as 0. */
 int hr_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *device_out);

@@ -354,6 +354,7 @@ int ora_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, vo
 {
     if (!params || !out) ORA_FAIL(ctx, HR_ERR_INVALID, "null argument");
     if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
+    format &= ~HR_DISPLAY_PROGRESSIVE; // the oracle has no pipeline
     if (format < HR_DISPLAY_RGBA8 || format > HR_DISPLAY_HDR_RGBA32F) ORA_FAIL(ctx, HR_ERR_INVALID, "unknown display format");
     displayResolve(ctx->c, *params, format, out);
     return HR_OK;

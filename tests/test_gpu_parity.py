@@ -622,6 +622,15 @@ def test_progressive_readback_never_drains_and_holds_complete_passes(golden, mon
         else:
             assert (buf == 0).all()
         seen.append(n)
+    # the progressive display snapshot shows exactly those passes
+    shown = g.display(ffi.display_params(tonemapping_enabled=True), ffi.HR_DISPLAY_RGBA32F | ffi.HR_DISPLAY_PROGRESSIVE)
+    _, n_now = g.readback_progressive()
+    if n_now:
+        o2 = oracle_lib.engine()
+        sc.apply(o2, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        for s in range(n_now):
+            o2.render_pass(sc.options.pass_params(s))
+        assert shown.tobytes() == o2.display(ffi.display_params(tonemapping_enabled=True), ffi.HR_DISPLAY_RGBA32F).tobytes()
     assert seen == sorted(seen) and seen[-1] < passes      # lags behind: the pipeline was never completed
     assert max(seen) > 0
     full = g.readback()                                        # this one completes everything
