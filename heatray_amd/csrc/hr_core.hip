@@ -579,14 +579,13 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         c->injectBatch = (int)(b < 1 ? 1 : (b > 16 ? 16 : b));
         if (c->tuneBatch > 0) c->injectBatch = c->tuneBatch;
         // Two pipeline groups (their steps alternate on two streams, so one group's trace tail and its shade / raygen run
-        // under the other group's trace) pay off up to one 1080p frame of paths per pass: measured on MI355X +11..14 % on a
-        // full 1080p frame and on a 1/2 shard, +5 % on 1/4; on a 1/8 shard +8 % at 64 passes and +16 % at 128, -5 % at 32 (each
-        // group has its own pipeline fill and drain: long runs — a viewer accumulates thousands of passes — are what counts).
-        // Larger frames lose: 2560x1440 948 vs 1491 Mrays/s, 3840x2160 1141 vs 1344 (one trace launch already fills the GPU for
-        // several ms; two of them only compete for L1/L2).  With two resident trace kernels three workgroups per CU each are
-        // best, alone five.
-        const bool upToOneFrame = c->queueCapacity <= 2200000u;
-        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (upToOneFrame ? 2 : 1);
+        // under the other group's trace) pay off while one trace launch does not fill the GPU for long: measured on MI355X
+        // +11..14 % on a full 1080p frame and on a 1/2 shard, +5 % on 1/4, +5 % at 2560x1440; on a 1/8 shard +8 % at 64 passes
+        // and +16 % at 128 (-5 % at 32: each group has its own pipeline fill and drain; long runs — a viewer accumulates
+        // thousands of passes — are what counts); at 3840x2160 -1..2 %.  With two resident trace kernels three workgroups per
+        // CU each are best, alone five.
+        const bool notHuge = c->queueCapacity <= 4200000u;
+        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (notHuge ? 2 : 1);
         c->nextGroup = 0;
         if (!c->tuneBlocksSet) c->tuneBlocks = c->nGroups > 1 ? 3 : 5;
         c->pendingInject.clear();
@@ -1349,6 +1348,19 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
         if (rc) return rc;
     }
     c->lastDepth = pp->max_ray_depth;
+    {
+        // All pass slots this depth needs are allocated up front, on the first pass (hipMalloc synchronises the device and
+        // takes ~0.1 ms per buffer: allocating slot by slot as the pipeline filled stalled the first 20-odd passes of a render)
+        const int stagesNow = stagesOf(*pp);
+        const int batchNow = batchFor(c, stagesNow);
+        int want = c->nGroups * batchNow * stagesNow + 2 * c->nGroups * batchNow;
+        if (want > slotLimit(c)) want = slotLimit(c);
+        for (int i = 0; i < kMaxSlots && c->nSlotsAllocated < want; ++i)
+            if (!c->slots[i].allocated) {
+                rc = allocSlot(c, c->slots[i]);
+                if (rc) return rc;
+            }
+    }
     c->pendingInject.push_back(*pp);
     if (c->hasPassthrough) return drainPipeline(c); // such passes may need extra stages: run them alone
     // a macro step is launched once enough passes are waiting to fill it; each group holds batch x stages passes
