@@ -174,6 +174,8 @@ def main():
     ap.add_argument("--converge-cap", type=int, default=4096, help="give up a convergence run after this many passes")
     ap.add_argument("--converge-runs", type=int, default=16, help="number of runs (Sobol sequence indices 0..n-1 of the offsets table)")
     ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of: which rank's shard to render")
+    ap.add_argument("--no-wakeup", action="store_true", help="skip the untimed device wake-up (profiling runs: every k_trace "
+                    "launch rocprofv3 sees then belongs to the timed region)")
     ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
     args = ap.parse_args()
 
@@ -238,7 +240,7 @@ def main():
     # first touch of ~10 GB of pass slots), which the 2-step warm-up of the contract does not absorb.
     t_wake = time.perf_counter()
     n_wake = 0
-    while n_wake < 64 or (time.perf_counter() - t_wake < 1.0 and n_wake < 1024):
+    while not args.no_wakeup and (n_wake < 64 or (time.perf_counter() - t_wake < 1.0 and n_wake < 1024)):
         eng.render_pass(sc.options.pass_params(n_wake % passes_total))
         n_wake += 1
         if n_wake % 32 == 0:
