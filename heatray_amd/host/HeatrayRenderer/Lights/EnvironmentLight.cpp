@@ -35,40 +35,26 @@ void EnvironmentLight::setTexture(std::shared_ptr<openrl::Texture> texture, cons
     m_textureSourcePath = std::string(sourceName);
 }
 
-// EnvironmentLight.cpp:48-72 of the reference: a 1x1 RGB texture.
+// A solid colour is a 1x1 RGB float texture with clamped, linear sampling (EnvironmentLight.cpp:48-72 of the reference).
 void EnvironmentLight::enableSolidColor(const glm::vec3& color)
 {
-    if ((m_textureSourcePath != SOLID_COLOR) || (m_solidColor != color)) {
-        openrl::Texture::Descriptor desc;
-        desc.dataType = RL_FLOAT;
-        desc.format = RL_RGB;
-        desc.internalFormat = RL_RGB;
-        desc.width = 1;
-        desc.height = 1;
-
-        openrl::Texture::Sampler sampler;
-        sampler.magFilter = RL_LINEAR;
-        sampler.minFilter = RL_LINEAR;
-        sampler.wrapS = RL_CLAMP_TO_EDGE;
-        sampler.wrapT = RL_CLAMP_TO_EDGE;
-
-        const float texel[3] = { color.x, color.y, color.z };
-        m_texture = openrl::Texture::create(texel, desc, sampler, false);
-
-        m_textureSourcePath = std::string(SOLID_COLOR);
-        m_solidColor = color;
-    }
+    const bool unchanged = (m_textureSourcePath == SOLID_COLOR) && (m_solidColor == color);
+    if (unchanged) return;
+    openrl::Texture::Descriptor onePixel;
+    onePixel.width = onePixel.height = 1;
+    onePixel.format = onePixel.internalFormat = RL_RGB;
+    onePixel.dataType = RL_FLOAT;
+    openrl::Texture::Sampler clamped;
+    clamped.minFilter = clamped.magFilter = RL_LINEAR;
+    clamped.wrapS = clamped.wrapT = RL_CLAMP_TO_EDGE;
+    const float texel[3] = { color.x, color.y, color.z };
+    m_texture = openrl::Texture::create(texel, onePixel, clamped, false);
+    m_solidColor = color;
+    m_textureSourcePath = std::string(SOLID_COLOR);
 }
 
-void EnvironmentLight::rotate(const float theta_radians)
-{
-    m_thetaRotation = theta_radians;
-}
-
-void EnvironmentLight::setExposure(const float exposureCompensation)
-{
-    m_exposureCompensation = exposureCompensation;
-}
+void EnvironmentLight::setExposure(const float exposureCompensation) { m_exposureCompensation = exposureCompensation; }
+void EnvironmentLight::rotate(const float theta_radians) { m_thetaRotation = theta_radians; }
 
 // EnvironmentLight.cpp:84-98 of the reference: exposure compensation is applied as 2^stops.
 void EnvironmentLight::copyToLightBuffer(hr_lights* block)

@@ -1,10 +1,4 @@
-//
-//  SpotLight.h
-//  heatray_amd host layer
-//
-//  API of /root/reference/Source/HeatrayRenderer/Lights/SpotLight.h:24-70.
-//
-
+// SpotLight.h (heatray_amd host layer); Params as in /root/reference/Source/HeatrayRenderer/Lights/SpotLight.h
 #pragma once
 
 #include "Light.h"
@@ -14,32 +8,25 @@
 class SpotLight final : public Light
 {
 public:
-    explicit SpotLight(const std::string_view name, size_t lightIndex);
-    ~SpotLight() = default;
-
     struct Params {
-        glm::vec3 color = glm::vec3(1.0f);
-        glm::vec3 position = glm::vec3(0.0f);
-        float luminousIntensity = 1.0f;
-        float innerAngle = 0.0f;
-        float outerAngle = 0.0f;
-
+        glm::vec3 color = glm::vec3(1.0f), position = glm::vec3(0.0f);
+        float luminousIntensity = 1.0f, innerAngle = 0.0f, outerAngle = 0.0f;
         struct Orientation {
-            float phi = 0.0f;   // radians [0 - 2π]
-            float theta = 0.0f; // radians [-π/2 - π/2]
+            float phi = 0.0f, theta = 0.0f; // radians: [0, 2 pi] and [-pi/2, pi/2]
         } orientation;
     };
 
-    void copyToLightBuffer(hr_lights* block);
+    explicit SpotLight(const std::string_view name, size_t lightIndex);
+    ~SpotLight() = default;
 
     Params params() const { return m_params; }
     void setParams(const Params &params);
-
     void updateLightIndex(const size_t newLightIndex) { m_lightIndex = newLightIndex; }
+    void copyToLightBuffer(hr_lights* block);
 
 private:
     glm::vec3 calculateDirection();
 
-    Params m_params;
     size_t m_lightIndex = 0;
+    Params m_params;
 };

@@ -1,12 +1,6 @@
-//
-//  PhysicallyBasedMaterial.h
-//  heatray_amd host layer
-//
-//  Opaque microfacet material: diffuse + GGX specular + clear coat + multiscatter compensation.
-//  Parameters struct and defaults as in
-//  /root/reference/Source/HeatrayRenderer/Materials/PhysicallyBasedMaterial.h:22-41.
-//
-
+// PhysicallyBasedMaterial.h (heatray_amd host layer)
+// Opaque microfacet material: diffuse + GGX specular + clear coat + multiscatter compensation.  Parameter names and defaults
+// are those of /root/reference/Source/HeatrayRenderer/Materials/PhysicallyBasedMaterial.h:22-41.
 #pragma once
 
 #include "Material.h"
@@ -19,41 +13,29 @@
 class PhysicallyBasedMaterial final : public Material
 {
 public:
+    struct Parameters {
+        TexturePtr baseColorTexture, emissiveTexture, normalmap, metallicRoughnessTexture;
+        TexturePtr clearCoatTexture, clearCoatRoughnessTexture, clearCoatNormalmap;
+        glm::vec3 baseColor = glm::vec3(1.0f), emissiveColor = glm::vec3(0.0f); // linear; albedo (dielectric) or specular colour (conductor)
+        float roughness = 1.0f, metallic = 0.0f;              // [0-1]
+        float specularF0 = 0.5f, clearCoat = 0.0f;            // [0-1], scaled to [0-0.08] and [0-0.2]
+        float clearCoatRoughness = 0.0f;                      // [0-1]
+        bool doubleSided = true, alphaMask = false;           // shade back faces with the flipped normal; cut out alpha < 1 texels
+        bool forceEnableAllTextures = false;                  // enable every texture slot even when no texture is bound
+    };
+
     explicit PhysicallyBasedMaterial(const std::string_view name) : Material(name, Material::Type::PBR) {}
     virtual ~PhysicallyBasedMaterial() = default;
-
-    struct Parameters {
-        std::shared_ptr<openrl::Texture> baseColorTexture = nullptr;
-        std::shared_ptr<openrl::Texture> emissiveTexture = nullptr;
-        std::shared_ptr<openrl::Texture> normalmap = nullptr;
-        std::shared_ptr<openrl::Texture> metallicRoughnessTexture = nullptr;
-        std::shared_ptr<openrl::Texture> clearCoatTexture = nullptr;
-        std::shared_ptr<openrl::Texture> clearCoatRoughnessTexture = nullptr;
-        std::shared_ptr<openrl::Texture> clearCoatNormalmap = nullptr;
-        glm::vec3 baseColor = glm::vec3(1.0f);      // linear; albedo of a dielectric, specular colour of a conductor
-        glm::vec3 emissiveColor = glm::vec3(0.0f);  // linear
-        float roughness = 1.0f;                     // [0-1]
-        float metallic  = 0.0f;                     // [0-1]
-        float specularF0 = 0.5f;                    // [0-1], scaled to [0-0.08]
-        float clearCoat = 0.0f;                     // [0-1], scaled to [0-0.2]
-        float clearCoatRoughness = 0.0f;            // [0-1]
-        bool doubleSided = true;                    // shade back faces with the flipped normal
-        bool alphaMask = false;                     // cut out texels whose base-colour alpha is < 1
-
-        bool forceEnableAllTextures = false;        // enable every texture slot even when no texture is bound
-    };
 
     void build() override;
     void rebuild() override;
     void modify() override;
-
     Parameters& parameters() { return m_params; }
 
-    // The host-side baking of a table row (no device access): exposed for the tests.
+    // host-side baking of the table row (no device access): exposed for the tests
     static void bake(const Parameters& params, bool vertexColors, hr_tex_id multiscatterLut, hr_material* row);
 
 private:
-    std::shared_ptr<openrl::Texture> m_multiscatterLUT = nullptr;
-
     Parameters m_params;
+    TexturePtr m_multiscatterLUT;
 };

@@ -1,12 +1,7 @@
-//
-//  Mesh.h
-//  heatray_amd host layer
-//
-//  One loaded model: the geometry handles and materials of its submeshes.  Public surface of
-//  /root/reference/Source/HeatrayRenderer/Scene/Mesh.h:29-71; each submesh is one libhrcore geometry
-//  (hr_geom_add) instead of an RL primitive with vertex / index buffers.
-//
-
+// Mesh.h (heatray_amd host layer)
+// One loaded model: the geometry handles and materials of its submeshes.  Public surface of
+// /root/reference/Source/HeatrayRenderer/Scene/Mesh.h:29-71; a submesh is one libhrcore geometry (hr_geom_add) instead of an
+// RL primitive with vertex / index buffers.
 #pragma once
 
 #include <RLWrapper/RLTypes.h>
@@ -17,39 +12,34 @@
 #include <memory>
 #include <vector>
 
-class MeshProvider;
 class Material;
+class MeshProvider;
 
 class Mesh
 {
 public:
-    Mesh() = delete;
+    struct Submesh {
+        std::shared_ptr<Material> material;
+        glm::mat4 transform = glm::mat4(1.0f);
+        size_t elementCount = 0, offset = 0;
+        RLenum mode = 0;
+        int geometry = -1; // hr_geom_id
+    };
 
-    // Pull every buffer out of the provider and submit one geometry per submesh.  The scene is NOT
-    // committed here: Scene::addMesh / PassGenerator commit once per batch of changes.
+    // Pulls every buffer out of the provider and submits one geometry per submesh.  The scene is NOT committed here:
+    // Scene::addMesh / PassGenerator commit once per batch of changes.
     Mesh(MeshProvider *meshProvider, std::vector<std::shared_ptr<Material>> &materials, const glm::mat4 &transform);
-    ~Mesh() = default;
+    Mesh() = delete;
     Mesh(Mesh&&) = default;
     Mesh& operator=(Mesh&&) = default;
+    ~Mesh() = default;
 
-    // Remove the submitted geometry from libhrcore.
-    void destroy();
-
+    void destroy(); // removes the submitted geometry from libhrcore
     bool valid() const { return !m_submeshes.empty(); }
-
-    const std::vector<std::shared_ptr<Material>>& materials() const { return m_materials;  }
-
-    struct Submesh {
-        int geometry = -1;             // hr_geom_id
-        size_t elementCount = 0;
-        size_t offset = 0;
-        RLenum mode = 0;
-        std::shared_ptr<Material> material = nullptr;
-        glm::mat4 transform = glm::mat4(1.0f);
-    };
     const std::vector<Submesh> &submeshes() const { return m_submeshes; }
+    const std::vector<std::shared_ptr<Material>>& materials() const { return m_materials; }
 
 private:
-    std::vector<Submesh> m_submeshes;
     std::vector<std::shared_ptr<Material>> m_materials;
+    std::vector<Submesh> m_submeshes;
 };
