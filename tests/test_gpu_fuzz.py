@@ -3,6 +3,7 @@ slot, vertex colours / tangents, single-sided and alpha-masked surfaces, glass, 
 sample modes, strips and indexed meshes, non-uniform and mirrored transforms, odd frame sizes) — the HIP core must match the
 oracle bit for bit on every one of them.  Small frames keep the oracle fast; the seeds are fixed, so failures reproduce."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -124,7 +125,7 @@ def _rot(rng):
                      [2 * (b * d - a * c), 2 * (c * d + a * b), a * a - b * b - c * c + d * d]])
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("HR_FUZZ_SEEDS", "40"))))   # HR_FUZZ_SEEDS=500 for a longer campaign
 def test_random_scene_parity(golden, seed):
     sc = random_scene(1000 + seed)
     g, o = core.create_engine(), oracle_lib.engine()
