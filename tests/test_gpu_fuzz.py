@@ -163,7 +163,7 @@ def _clustered_soup(rng, n_tris):
     return pos
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(max(6, int(os.environ.get("HR_FUZZ_SEEDS", "40")) // 10)))
 def test_random_traversal_vs_brute_force(seed):
     rng = np.random.default_rng(500 + seed)
     n_tris = int(rng.choice([7, 300, 2500, 9000, 20000]))
@@ -191,7 +191,7 @@ def test_random_traversal_vs_brute_force(seed):
     assert ag.tobytes() == ao.tobytes()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(max(8, int(os.environ.get("HR_FUZZ_SEEDS", "40")) // 5)))
 def test_random_scene_modes_and_shards(golden, seed):
     # the same random scenes under the per-pass modes (interactive 3x3 blocks, debug visualisers, NaN / Inf display) and as
     # tile shards: every shard must render exactly its pixels of the full frame
