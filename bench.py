@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--converge-cap", type=int, default=4096, help="give up a convergence run after this many passes")
     ap.add_argument("--converge-runs", type=int, default=16, help="number of runs (Sobol sequence indices 0..n-1 of the offsets table)")
     ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of: which rank's shard to render")
+    ap.add_argument("--depth", type=int, default=-1, help="override the workload's max ray depth (analysis runs; not the BASELINE config)")
     ap.add_argument("--no-wakeup", action="store_true", help="skip the untimed device wake-up (profiling runs: every k_trace "
                     "launch rocprofv3 sees then belongs to the timed region)")
     ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
@@ -218,6 +219,8 @@ def main():
     eng_world = args.shard_of if emulated else world
     passes_total = args.warmup + args.steps
     sc = build_scene(args.workload, args.width, args.height, max(32, passes_total))
+    if args.depth >= 0:
+        sc.options.max_ray_depth = args.depth
     stream = torch.cuda.current_stream().cuda_stream
     eng_rank = args.shard_rank if emulated else rank
     eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, time_kernels=True)
