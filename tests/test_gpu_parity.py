@@ -640,3 +640,21 @@ def test_progressive_readback_never_drains_and_holds_complete_passes(golden, mon
     g.clear()
     _, n = g.readback_progressive()
     assert n == 0
+
+
+def test_large_scene_3m_triangles(golden):
+    # maximum-size end of the range (tools/big_scene_check.py goes to 30 M): device LBVH + collapse of 3 M triangles, hits against
+    # the oracle's own tree and a render, bit for bit
+    sc = scenes.triangle_soup(3_000_000, width=48, height=48, bounces=3, passes=4, env=True)
+    g, o = core.create_engine(), oracle_lib.engine()
+    for eng in (g, o):
+        sc.apply(eng, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    assert g.scene_info().n_triangles == 3_000_000
+    rng = np.random.default_rng(8)
+    org = rng.uniform(-1.1, 1.1, (8000, 3)).astype(np.float32)
+    d = rng.normal(size=(8000, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    assert g.debug_trace(org, d).tobytes() == o.debug_trace(org, d).tobytes()
+    for s in range(2):
+        g.render_pass(sc.options.pass_params(s)), o.render_pass(sc.options.pass_params(s))
+    assert_parity(g.readback(), o.readback(), "3 M triangles")
