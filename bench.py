@@ -63,13 +63,11 @@ def cpu_baseline(sc, budget_s, lut):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     n_tiles = ((sc.width + 31) // 32) * ((sc.height + 31) // 32)
-    cores = os.cpu_count() or 1
+    cores = oracle_lib.usable_cpus()  # affinity mask capped by the cgroup CPU quota (a one-GPU box: 16 of the host's 256)
     max_passes = sc.options.max_render_passes
 
     def run(world, budget, threads=0):
-        eng = oracle_lib.engine(rank=0, world=world, tile_size=32)
-        if threads:
-            oracle_lib.load().ora_set_threads(eng._ctx, threads)
+        eng = oracle_lib.engine(threads=threads or cores, rank=0, world=world, tile_size=32)
         t0 = time.perf_counter()
         sc.apply(eng, lut=lut)
         build_s = time.perf_counter() - t0

@@ -20,6 +20,21 @@ def load():
     return _LIB
 
 
-def engine(**kw):
+def usable_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows 256 CPUs but
+    grants 16: 256 OpenMP threads then share the quota and spend their time being throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def engine(threads=None, **kw):
     from heatray_amd._ffi import Engine
-    return Engine(load(), "ora_", **kw)
+    eng = Engine(load(), "ora_", **kw)
+    load().ora_set_threads(eng._ctx, int(threads) if threads else usable_cpus())
+    return eng
