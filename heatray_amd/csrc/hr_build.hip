@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
         const int ref = ord[c];
         if (ref < 0) {
             cb[c] = leafBox[~ref];
-            finalTris[leafBase + (uint32_t)(c - nInner)] = sorted[~ref];
+            finalTris[leafBase + (uint32_t)(nValid - 1 - c)] = sorted[~ref]; // descending with the child slot (see leafKey)
         } else {
             cb[c] = nodeBox[ref];
             binOf[innerBase + (uint32_t)c] = ref;
@@ -416,8 +416,9 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
             qhi[k] |= hi8 << (8 * c);
         }
     }
-    // child j >= nInner is triangle leafBase + (j - nInner): reference ~(leafBase - nInner + j) = ~(leafBase - nInner) - j
-    const int leafKey = ~((int)leafBase - nInner);
+    // child j >= nInner is triangle top - j with top = leafBase + nValid - 1: its reference ~(top - j) = ~top + j, so that a
+    // child reference is `base + slot` for both kinds (base = innerBase or leafKey)
+    const int leafKey = ~((int)leafBase + nValid - 1);
     Node4 nd;
     nd.a = make_float4(nb.lo[0], nb.lo[1], nb.lo[2],
                        __uint_as_float(e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)nInner << 24) | ((uint32_t)nValid << 27)));

@@ -98,7 +98,7 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int sl = (int)(key[j] & 3u);
-        ref[j] = ((uint32_t)sl < nInner) ? innerBase + sl : leafKey - sl; // (a miss computes a value nobody uses)
+        ref[j] = (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl; // (a miss computes a value nobody uses)
     }
     if (sp <= kStackLDS - 3) {
         // common case, branch-free: store the three farther children farthest first and advance the stack pointer only

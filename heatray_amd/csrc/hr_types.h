@@ -17,7 +17,7 @@ namespace hr {
 // child box = origin + q * scale, with qlo rounded down and qhi rounded up (conservative).
 // Children 0 .. nInner-1 are the inner nodes innerBase + j: the children of one node are allocated together, so
 // siblings — which a ray tends to visit together — share 128-byte cache lines.  Children nInner .. nValid-1 are single
-// triangles, also stored together: the reference of child j is ~(triangle index) = leafKey - j.
+// triangles, also stored together, in descending order of the slot: the reference of child j is ~(triangle index) = leafKey + j.
 // A reference >= 0 is a node index; < 0 is a leaf ~(first | (count-1) << 28) (count > 1 only for a root leaf).
 struct alignas(64) Node4 {
     float4 a;
