@@ -46,6 +46,10 @@ template <class F> static void forEachPackedSlot(const Context &c, int rank, int
     }
 }
 
+namespace ora {
+Context &contextOf(hr_ctx *ctx) { return ctx->c; } // for the probes in oracle_shade.cpp
+}
+
 extern "C" {
 
 int ora_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)

@@ -512,6 +512,28 @@ struct Shader {
         return s;
     }
 
+    // ---- physicallyBased.rlsl:206-228: layer colours and the lobe-selection probabilities ----
+    struct Lobes {
+        vec3 Cdiff, Cspec;
+        float clearCoatScale, diffuseProbability, specularProbability, clearCoatProbability;
+    };
+    static Lobes computeLobes(vec3 baseColor, float metallic, float specularF0, float clearCoat, float clearCoatNdotV)
+    {
+        Lobes lb;
+        float clearCoatF = F_Schlick(0.04f, clearCoatNdotV); // :210
+        lb.clearCoatScale = clearCoatF * clearCoat;
+        float clearCoatBottomLayerScale = 1.0f - lb.clearCoatScale;
+        lb.Cdiff = (baseColor * (1.0f - metallic)) * clearCoatBottomLayerScale;                         // :214
+        lb.Cspec = mix(vec3(specularF0), baseColor, vec3(metallic)) * clearCoatBottomLayerScale;        // :220
+        float diffuseLuminance = luminosity(lb.Cdiff);
+        float specularLuminance = luminosity(lb.Cspec);
+        float probabilityNormalization = 1.0f / greaterThanZero(diffuseLuminance + specularLuminance + lb.clearCoatScale);
+        lb.diffuseProbability = diffuseLuminance * probabilityNormalization;
+        lb.specularProbability = specularLuminance * probabilityNormalization;
+        lb.clearCoatProbability = lb.clearCoatScale * probabilityNormalization;
+        return lb;
+    }
+
     // ---- physicallyBased.rlsl:55-331 ----
     void physicallyBased(const Ray &inRay, const Hit &h, const hr_material &M, Ray &nee, Ray &next)
     {
@@ -610,17 +632,11 @@ struct Shader {
         }
         performAccumulate(in.weight * emissive); // :205
         float clearCoatNdotV = saturate(dot(clearCoatN, V));
-        float clearCoatF = F_Schlick(0.04f, clearCoatNdotV); // :210
-        float clearCoatScale = clearCoatF * clearCoat;
-        float clearCoatBottomLayerScale = 1.0f - clearCoatScale;
-        vec3 Cdiff = (baseColor * (1.0f - metallic)) * clearCoatBottomLayerScale;                            // :214
-        vec3 Cspec = mix(vec3(M.specular_f0), baseColor, vec3(metallic)) * clearCoatBottomLayerScale;        // :220
-        float diffuseLuminance = luminosity(Cdiff);
-        float specularLuminance = luminosity(Cspec);
-        float probabilityNormalization = 1.0f / greaterThanZero(diffuseLuminance + specularLuminance + clearCoatScale);
-        float diffuseProbability = diffuseLuminance * probabilityNormalization;
-        float specularProbability = specularLuminance * probabilityNormalization;
-        float clearCoatProbability = clearCoatScale * probabilityNormalization;
+        const Lobes lb = computeLobes(baseColor, metallic, M.specular_f0, clearCoat, clearCoatNdotV);
+        const vec3 Cdiff = lb.Cdiff, Cspec = lb.Cspec;
+        const float clearCoatScale = lb.clearCoatScale;
+        const float diffuseProbability = lb.diffuseProbability, specularProbability = lb.specularProbability,
+                    clearCoatProbability = lb.clearCoatProbability;
         // clearCoatFrame (:230-233) is computed but never used by the shader.
 
         const int si = pp.sample_index + in.sequenceIndexOffset;
@@ -962,3 +978,87 @@ void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
 }
 
 } // namespace ora
+
+// ---- function-level probes for the known-answer tests (tests/test_oracle_kat.py): each evaluates ONE restated RLSL
+// function on caller-supplied inputs, so that a transcription error shows against an independently written formula.
+struct hr_ctx;
+namespace ora {
+Context &contextOf(hr_ctx *ctx); // oracle_api.cpp
+}
+extern "C" {
+using namespace ora;
+
+// which: 0 F_Fresnel(eta, cosI)  1 F_Schlick(f0, cos)  2 D_GGX(NdotH, alpha)  3 G1_Smith_GGX(NdotI, alpha)
+//        4 G2_Smith_GGX(NdotO, NdotI, alpha)  5 luminosity(rgb)  6 smoothstep(e0, e1, x)
+float ora_kat_scalar(int which, float a, float b, float c)
+{
+    switch (which) {
+    case 0: return Shader::F_Fresnel(a, b);
+    case 1: return Shader::F_Schlick(a, b);
+    case 2: return Shader::D_GGX(a, b);
+    case 3: return Shader::G1_Smith_GGX(a, b);
+    case 4: return Shader::G2_Smith_GGX(a, b, c);
+    case 5: return Shader::luminosity(vec3(a, b, c));
+    case 6: return smoothstep(a, b, c);
+    default: return NAN;
+    }
+}
+// utility.rlsl:109-139 (y-up local space in, y-up microfacet normal out)
+void ora_kat_sample_visible_ggx(const float v[3], float u1, float u2, float alpha, float out[3])
+{
+    vec3 h = Shader::sampleVisibleGGX(vec3(v[0], v[1], v[2]), u1, u2, alpha);
+    out[0] = h.x, out[1] = h.y, out[2] = h.z;
+}
+void ora_kat_cosine_sample(float u1, float u2, float out[3]) // utility.rlsl:64-75
+{
+    vec3 d = Shader::cosineWeightedSample(u1, u2);
+    out[0] = d.x, out[1] = d.y, out[2] = d.z;
+}
+void ora_kat_frame(const float n[3], float out[9]) // utility.rlsl:43-60, columns c0 c1 c2
+{
+    mat3 m = Shader::orthonormalFrame(vec3(n[0], n[1], n[2]));
+    const vec3 c[3] = {m.c0, m.c1, m.c2};
+    for (int k = 0; k < 3; ++k) out[3 * k] = c[k].x, out[3 * k + 1] = c[k].y, out[3 * k + 2] = c[k].z;
+}
+void ora_kat_refract(const float i[3], const float n[3], float eta, float out[3]) // GLSL refract as glass.rlsl:235 uses it
+{
+    vec3 r = refract(vec3(i[0], i[1], i[2]), vec3(n[0], n[1], n[2]), eta);
+    out[0] = r.x, out[1] = r.y, out[2] = r.z;
+}
+// physicallyBased.rlsl:206-228 — out: Cdiff[3] Cspec[3] clearCoatScale pDiffuse pSpecular pClearCoat
+void ora_kat_pbr_lobes(const float baseColor[3], float metallic, float specularF0, float clearCoat, float clearCoatNdotV, float out[10])
+{
+    Shader::Lobes lb = Shader::computeLobes(vec3(baseColor[0], baseColor[1], baseColor[2]), metallic, specularF0, clearCoat, clearCoatNdotV);
+    out[0] = lb.Cdiff.x, out[1] = lb.Cdiff.y, out[2] = lb.Cdiff.z, out[3] = lb.Cspec.x, out[4] = lb.Cspec.y, out[5] = lb.Cspec.z;
+    out[6] = lb.clearCoatScale, out[7] = lb.diffuseProbability, out[8] = lb.specularProbability, out[9] = lb.clearCoatProbability;
+}
+// lightSampling.rlsl:11-161 with the ctx's light block — out: type, missKind, index | probability, maxDistance, dir[3]
+void ora_kat_light_sample(hr_ctx *ctx, const float N[3], const float P[3], float xi, int outI[3], float outF[5])
+{
+    Context &c = contextOf(ctx);
+    hr_pass_params pp{};
+    hr_pass_stats st{};
+    float px[4] = {0, 0, 0, 0};
+    Shader sh(c, pp, px, st);
+    Shader::LightSample ls = sh.computeLightSample(vec3(N[0], N[1], N[2]), xi, vec3(P[0], P[1], P[2]));
+    outI[0] = ls.type, outI[1] = ls.missKind, outI[2] = ls.missIdx;
+    outF[0] = ls.probability, outF[1] = ls.maxDistance, outF[2] = ls.dir.x, outF[3] = ls.dir.y, outF[4] = ls.dir.z;
+}
+// the light / miss shaders (environmentLight / directionalLight / pointLight / spotLight.rlsl) for a ray that reached its light:
+// missKind 1 env 2 directional 3 point 4 spot; out = the value performAccumulate added (clamped by maxChannelValue)
+void ora_kat_light_shader(hr_ctx *ctx, int missKind, int index, const float dir[3], const float weight[3], float t, float extraT,
+                          float maxChannelValue, float out[3])
+{
+    Context &c = contextOf(ctx);
+    hr_pass_params pp{};
+    pp.max_channel_value = maxChannelValue;
+    hr_pass_stats st{};
+    float px[4] = {0, 0, 0, 0};
+    Shader sh(c, pp, px, st);
+    Ray r;
+    r.d = vec3(dir[0], dir[1], dir[2]), r.weight = vec3(weight[0], weight[1], weight[2]);
+    r.missKind = missKind, r.missIdx = index, r.extraT = extraT;
+    sh.lightShader(r, t);
+    out[0] = sh.px[0], out[1] = sh.px[1], out[2] = sh.px[2];
+}
+} // extern "C"
