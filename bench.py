@@ -10,15 +10,25 @@ sharded by 32x32-pixel tile across the ranks (strong scaling: the frame is fixed
 owned tiles are gathered on rank 0 over RCCL on a side stream, and the assembled final image is checked
 inside the timed region.  A small shard batches several passes into each kernel launch.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (closest-hit traversal), timed
-with HIP events inside libhrcore over the timed region; `cpu_baseline` is the CPU oracle (oracle/, the
-checker — used here only as the reported baseline leg) timed on a bounded tile sample of the same workload.
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel (k_trace: closest-hit + occlusion traversal).
+Its fraction is COUNTER-BASED and cannot exceed 1: before the parent process touches the GPU, the same command
+is run under `rocprofv3 --pmc` in child processes (FETCH_SIZE, WRITE_SIZE and SQ_INSTS_VALU in separate passes, as
+MI355X_MICROARCH.md prescribes), which yields HBM-side bytes and VALU instructions per ray of THIS configuration and
+step count; multiplied by the rays of the timed region and divided by its wall time they give the achieved bandwidth
+and issue rate against the 8 TB/s and 256 CU x 4 SIMD x f / 2 ceilings.  The algorithmic (spec-BVH) figure of SURVEY
+§8d is kept under `spec_model`.  `cpu_baseline` is the CPU oracle (oracle/, the checker — used here only as the
+reported baseline leg, built -O3 -march=native) timed on a bounded tile sample of the same workload.
 """
 import argparse
+import csv
+import glob
 import json
 import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -30,6 +40,10 @@ from heatray_amd import _ffi as ffi  # noqa: E402
 from heatray_amd import core, scenes, tiles  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# VALU issue ceiling: a wave64 VALU instruction occupies a SIMD-32 for 2 cycles once more than one wave is resident
+# (MI355X_MICROARCH.md 'Wave scheduling'; tools/calib_valu.hip measures it: profiles/r2_calib_valu.json), 4 SIMDs per CU
+VALU_CLOCK_GHZ = 2.4
+VALU_CYCLES_PER_WAVE_OP = 2.0
 
 WORKLOADS = {
     # BASELINE.json configs; c3 is the configuration the north-star target (>= 1 Gray/s) is quoted on
@@ -67,7 +81,7 @@ def cpu_baseline(sc, budget_s, lut):
     max_passes = sc.options.max_render_passes
 
     def run(world, budget, threads=0):
-        eng = oracle_lib.engine(threads=threads or cores, rank=0, world=world, tile_size=32)
+        eng = oracle_lib.engine(threads=threads or cores, native=True, rank=0, world=world, tile_size=32)
         t0 = time.perf_counter()
         sc.apply(eng, lut=lut)
         build_s = time.perf_counter() - t0
@@ -96,6 +110,7 @@ def cpu_baseline(sc, budget_s, lut):
     return {
         "single_thread_value": (st1.rays_closest + st1.rays_any) / el1 / 1e6,
         "value": rays / el / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "build": "oracle/Makefile native: g++ -O3 -march=native -fopenmp (timing build; the parity build keeps -O2 -ffp-contract=off)",
         "sample": f"1/{world} of the frame's 32x32 tiles (interleaved), {passes} passes, {rays} rays in {el:.1f} s "
                   f"(+{build_s:.1f} s scene/BVH build), OpenMP over tiles on {cores} threads",
         "per_core": rays / el / 1e6 / cores,
@@ -103,6 +118,66 @@ def cpu_baseline(sc, budget_s, lut):
         "T": (st.tri_tests - st.tri_tests_any) / max(st.rays_closest, 1),
         "V_any": st.node_visits_any / max(st.rays_any, 1), "T_any": st.tri_tests_any / max(st.rays_any, 1),
     }
+
+
+def _short_kernel(name):
+    n = name.split("(")[0].replace("void ", "").replace("hr::", "")
+    return n.split("<")[0]
+
+
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]))
+
+
+def pmc_legs(args, keep_dir=None):
+    """Counter passes of THIS command (same workload, size, depth and step count), each in a child process under
+    `rocprofv3 --kernel-trace --pmc <counters>` — run before the parent initialises the GPU.  FETCH_SIZE and WRITE_SIZE do
+    not fit one pass (MI355X_MICROARCH.md 'rocprofv3 PMC slots'), so they are separate passes; the SQ counters are a third.
+    Returns per-kernel counter sums over every dispatch of the child's run plus the child's ray count, or None when rocprofv3
+    is not usable here (then the roofline falls back to the committed per-ray figures and says so)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out_root = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="hr_pmc_", dir="/tmp")
+    os.makedirs(out_root, exist_ok=True)
+    child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.join(ROOT, "bench.py"),
+             "--pmc-child", "--workload", args.workload, "--steps", str(args.steps), "--warmup", "0", "--cpu-seconds", "0", "--no-stats-pass",
+             "--no-wakeup", "--no-pmc", "--no-converge", "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    res = {"kernels": {}, "passes": {}, "dir": out_root if keep_dir else None}
+    t0 = time.perf_counter()
+    for name, ctrs in PMC_PASSES:
+        d = os.path.join(out_root, name)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "-d", d, "-o", name, "--output-format", "csv", "--", *child]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        except (OSError, subprocess.TimeoutExpired) as e:
+            res["passes"][name] = {"error": str(e)[:200]}
+            continue
+        line = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            res["passes"][name] = {"error": f"rc {r.returncode}: " + r.stderr.decode(errors="replace")[-300:]}
+            continue
+        cj = json.loads(line[-1])
+        res["passes"][name] = {"rays": cj["extra"]["rays"], "steps": cj["steps"], "counters": ctrs}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    k = _short_kernel(row["Kernel_Name"])
+                    kk = res["kernels"].setdefault(k, {})
+                    kk[row["Counter_Name"]] = kk.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    disp = kk.setdefault("_dispatches_" + row["Counter_Name"], set())
+                    disp.add(row["Dispatch_Id"])
+        if not keep_dir:
+            shutil.rmtree(d, ignore_errors=True)
+    for k in res["kernels"].values():
+        for key in [x for x in k if x.startswith("_dispatches_")]:
+            k["launches_" + key[len("_dispatches_"):]] = len(k.pop(key))
+    res["seconds"] = time.perf_counter() - t0
+    if not keep_dir:
+        shutil.rmtree(out_root, ignore_errors=True)
+    ok = all("rays" in res["passes"].get(n, {}) for n, _ in PMC_PASSES[:2])
+    return res if ok else {"failed": True, **res}
 
 
 def convergence_leg(core, sc, dev, stream, cap, n_runs):
@@ -173,8 +248,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--shard-of", type=int, default=0, help="tuning aid, single process: render only rank 0's tiles of a W-way "
                     "sharded frame (no collective); the JSON line is marked emulated and is not a benchmark result")
-    ap.add_argument("--converge", action="store_true", help="also measure passes-to-converge p50 (BASELINE metric 2): an 8192-pass "
-                    "reference render + 16 runs, about a minute on c3; N = 1 only")
+    ap.add_argument("--converge", action="store_true", help="passes-to-converge p50 (BASELINE metric 2) over all 16 runs (default: 3 of them): an "
+                    "8192-pass reference render + the runs; N = 1 only")
+    ap.add_argument("--no-converge", action="store_true", help="skip the live passes-to-converge leg (the committed measurement is quoted, marked as such)")
     ap.add_argument("--converge-cap", type=int, default=4096, help="give up a convergence run after this many passes")
     ap.add_argument("--converge-runs", type=int, default=16, help="number of runs (Sobol sequence indices 0..n-1 of the offsets table)")
     ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of: which rank's shard to render")
@@ -182,7 +258,20 @@ def main():
     ap.add_argument("--no-wakeup", action="store_true", help="skip the untimed device wake-up (profiling runs: every k_trace "
                     "launch rocprofv3 sees then belongs to the timed region)")
     ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (the roofline then quotes the committed per-ray "
+                    "figures of profiles/traffic.json, scaled by this run's rays, and says so)")
+    ap.add_argument("--quick", action="store_true", help="tuning runs: only the timed region (= --cpu-seconds 0 --no-stats-pass --no-pmc --no-converge)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-keep", default="", help="keep the rocprofv3 output of the counter passes in this directory")
     args = ap.parse_args()
+    if args.quick:
+        args.cpu_seconds, args.no_stats_pass, args.no_pmc, args.no_converge = 0.0, True, True, True
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    pmc = None
+    if world_env == 1 and not args.no_pmc and not args.pmc_child and args.shard_of <= 1:
+        # child processes under rocprofv3, before this process initialises the GPU (a process that holds the GPU never execs)
+        pmc = pmc_legs(args, keep_dir=args.pmc_keep or None)
 
     import torch
     import torch.distributed as dist
@@ -253,6 +342,7 @@ def main():
         if n_wake % 32 == 0:
             eng.flush()
             torch.cuda.synchronize()
+    wake_s = time.perf_counter() - t_wake
     eng.clear()
     for i in range(args.warmup):
         step(i)
@@ -315,38 +405,97 @@ def main():
             se.close()
 
         # ---- roofline of the dominant kernel: k_trace (closest-hit + occlusion traversal in one launch).
-        # ALGORITHMIC bytes per ray (SURVEY §8d / DESIGN.md §Roofline), defined on the spec BVH (binary LBVH, two-box
-        # 64-byte nodes, <= 4 triangles per leaf) so the figure does not depend on this implementation's tree:
-        #   48 B ray read + 16 B result + 64 B x V (nodes visited) + 48 B x T (triangles tested),
-        # with V and T measured by the CPU oracle on the same scene (cpu_baseline leg); the committed figures of
-        # profiles/vt_spec.json are used when that leg is skipped.
+        # (1) `frac`: COUNTER-BASED.  HBM-side bytes per ray of this configuration (rocprofv3 FETCH_SIZE + WRITE_SIZE of the counter
+        #     passes run above on the same command, corrected as MI355X_MICROARCH.md's HBM section prescribes and as calibrated on this
+        #     kernel's access pattern, profiles/*_calib_fetch.json: scattered 64-B gathers are counted exactly, the coalesced 48-B/ray
+        #     queue stream at half its bytes) x the rays of the timed region / the WALL time of the timed region / 8 TB/s.  The counter
+        #     sits on the L2's memory side, so Infinity-Cache hits are included: an upper bound of what reaches HBM, and <= 1 by physics.
+        # (2) `valu`: second ceiling, wave-level VALU instructions (SQ_INSTS_VALU) / wall time against 256 CUs x 4 SIMDs x f / 2.
+        # (3) `spec_model`: SURVEY §8d's ALGORITHMIC bytes (48 B ray + 16 B result + 64 B x V + 48 B x T with V, T measured by the CPU
+        #     oracle on the spec structure: binary LBVH, 64-B two-box nodes, <= 4 triangles per leaf) / the average k_trace launch
+        #     duration.  NOT a ceiling for this implementation: the product walks a compressed 4-wide tree whose upper levels stay in
+        #     cache, so it moves far fewer bytes than the spec structure would and this ratio can exceed 1.
         ms_trace, n_trace = kt["trace"]
         roofline = None
-        vt = cpu
-        if vt is None:
-            vpath = os.path.join(ROOT, "profiles", "vt_spec.json")
-            if os.path.exists(vpath):
-                vt = json.load(open(vpath)).get(args.workload)
-        if vt is not None and n_trace:
-            bytes_closest = 48.0 + 16.0 + 64.0 * vt["V"] + 48.0 * vt["T"]
-            bytes_any = 48.0 + 16.0 + 64.0 * vt["V_any"] + 48.0 * vt["T_any"]
-            total_bytes = bytes_closest * float(st.rays_closest) + bytes_any * float(st.rays_any)
+        wall_s = elapsed
+        run_rays = float(st.rays_closest + st.rays_any)
+        if n_trace:
             avg_ms = ms_trace / n_trace
-            achieved = total_bytes / n_trace / (avg_ms * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("k_trace_hbm_bytes_per_launch")
-            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "kernel": "k_trace", "avg_launch_ms": avg_ms, "launches": n_trace,
-                        "algorithmic_bytes_per_launch": total_bytes / n_trace,
-                        "algorithmic_bytes_per_closest_ray": bytes_closest, "algorithmic_bytes_per_occlusion_ray": bytes_any,
-                        "rays_per_launch": float(st.rays_closest + st.rays_any) / n_trace,
-                        # two pipeline groups run their launches concurrently on two streams: a launch's duration then spans
-                        # time it shares with the other group's kernels (sum of all kernel durations / wall time of the region)
-                        "kernel_time_over_wall_time": sum(v[0] for v in kt.values()) / (elapsed * 1e3),
-                        "V": vt["V"], "T": vt["T"], "V_any": vt["V_any"], "T_any": vt["T_any"],
-                        "vt_source": "cpu oracle, this run" if vt is cpu else "profiles/vt_spec.json"}
+            src = None
+            per_ray = per_ray_all = valu_per_ray = None
+            if pmc and not pmc.get("failed"):
+                kt_c = pmc["kernels"].get("k_trace", {})
+                rays_f, rays_w = pmc["passes"]["fetch"]["rays"], pmc["passes"]["write"]["rays"]
+                if "FETCH_SIZE" in kt_c and "WRITE_SIZE" in kt_c:
+                    # FETCH_SIZE / WRITE_SIZE are in KiB; + half of the streamed queue reads (48 B per ray) that FETCH_SIZE under-counts
+                    per_ray = kt_c["FETCH_SIZE"] * 1024.0 / rays_f + kt_c["WRITE_SIZE"] * 1024.0 / rays_w + 0.5 * 48.0
+                    per_ray_all = (sum(k.get("FETCH_SIZE", 0.0) for k in pmc["kernels"].values()) * 1024.0 / rays_f +
+                                   sum(k.get("WRITE_SIZE", 0.0) for k in pmc["kernels"].values()) * 1024.0 / rays_w)
+                    src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, three child passes of this command ({args.steps} steps, "
+                           f"warm-up 0) run before the timed region, {pmc['seconds']:.0f} s")
+                sq = pmc["passes"].get("sq", {})
+                if "rays" in sq and "SQ_INSTS_VALU" in kt_c:
+                    valu_per_ray = {"k_trace": kt_c["SQ_INSTS_VALU"] / sq["rays"],
+                                    "all_kernels": sum(k.get("SQ_INSTS_VALU", 0.0) for k in pmc["kernels"].values()) / sq["rays"]}
+            if per_ray is None:  # counter passes unavailable: the committed measurement of the same workload, scaled by this run's rays
+                tpath = os.path.join(ROOT, "profiles", "traffic.json")
+                if os.path.exists(tpath):
+                    tj = json.load(open(tpath)).get(args.workload)
+                    if tj and not tj.get("k_trace_hbm_bytes_per_ray") and tj.get("streamed_queue_read_bytes_per_launch"):
+                        tj["k_trace_hbm_bytes_per_ray"] = tj["k_trace_hbm_bytes_per_launch"] / (tj["streamed_queue_read_bytes_per_launch"] / 48.0)
+                    if tj and tj.get("k_trace_hbm_bytes_per_ray"):
+                        per_ray = tj["k_trace_hbm_bytes_per_ray"]
+                        valu_per_ray = tj.get("valu_wave_instructions_per_ray")
+                        src = "profiles/traffic.json (committed counter passes of the same workload), scaled by this run's rays — NOT measured in this run"
+            if per_ray is not None:
+                traffic_run = per_ray * run_rays
+                achieved = traffic_run / wall_s / 1e9
+                roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": traffic_run / n_trace, "kernel": "k_trace",
+                            "definition": "counter-based: (FETCH_SIZE + WRITE_SIZE + half the streamed 48 B/ray queue reads) per ray x rays of the timed "
+                                          "region / wall time of the timed region; includes Infinity-Cache hits (upper bound of HBM bytes)",
+                            "traffic_source": src, "hbm_side_bytes_per_ray": per_ray, "wall_ms": wall_s * 1e3,
+                            "avg_launch_ms": avg_ms, "launches": n_trace, "rays_per_launch": run_rays / n_trace,
+                            "kernel_time_over_wall_time": sum(v[0] for v in kt.values()) / (wall_s * 1e3)}
+                if per_ray_all:
+                    roofline["all_kernels_frac"] = per_ray_all * run_rays / wall_s / 1e9 / HBM_PEAK_GBS
+                if valu_per_ray:
+                    cal = os.path.join(ROOT, "profiles", "r2_calib_valu.json")
+                    per_simd = VALU_CLOCK_GHZ / VALU_CYCLES_PER_WAVE_OP  # G wave-instructions / s / SIMD
+                    peak_src = f"{VALU_CLOCK_GHZ} GHz / {VALU_CYCLES_PER_WAVE_OP:g} cycles per wave64 op (MI355X_MICROARCH.md)"
+                    if os.path.exists(cal):
+                        runs = json.load(open(cal)).get("runs", [])
+                        if runs:
+                            per_simd = max(r["per_simd_ginstr_per_s"] for r in runs)
+                            peak_src = "tools/calib_valu.hip, measured (profiles/r2_calib_valu.json)"
+                    n_cus = int(getattr(torch.cuda.get_device_properties(dev), "multi_processor_count", 256))
+                    peak = n_cus * 4 * per_simd  # G wave-instructions / s
+                    ach = valu_per_ray["all_kernels"] * run_rays / wall_s / 1e9
+                    roofline["valu"] = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+                                        "peak_source": peak_src, "wave_instructions_per_ray": valu_per_ray}
+            vt = cpu
+            if vt is None:
+                vpath = os.path.join(ROOT, "profiles", "vt_spec.json")
+                if os.path.exists(vpath):
+                    vt = json.load(open(vpath)).get(args.workload)
+            if vt is not None and roofline is not None:
+                bytes_closest = 48.0 + 16.0 + 64.0 * vt["V"] + 48.0 * vt["T"]
+                bytes_any = 48.0 + 16.0 + 64.0 * vt["V_any"] + 48.0 * vt["T_any"]
+                total_bytes = bytes_closest * float(st.rays_closest) + bytes_any * float(st.rays_any)
+                roofline["spec_model"] = {
+                    "note": "SURVEY 8d algorithmic bytes on the SPEC structure (binary LBVH); not a ceiling for a compressed 4-wide tree — may exceed 1",
+                    "algorithmic_bytes_per_launch": total_bytes / n_trace, "achieved_gbs_per_launch_duration": total_bytes / n_trace / (avg_ms * 1e-3) / 1e9,
+                    "ratio_to_hbm_peak": total_bytes / n_trace / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "algorithmic_bytes_per_closest_ray": bytes_closest, "algorithmic_bytes_per_occlusion_ray": bytes_any,
+                    "V": vt["V"], "T": vt["T"], "V_any": vt["V_any"], "T_any": vt["T_any"],
+                    "vt_source": "cpu oracle, this run" if vt is cpu else "profiles/vt_spec.json"}
+            if gpu_counts is not None and roofline is not None:
+                # the same accounting on the tree the product really walks: 64-B 4-wide nodes, 48-B triangles (every visit charged)
+                b = (48.0 + 16.0) * run_rays + 64.0 * (gpu_counts["node4_visits_per_closest_ray"] * st.rays_closest + gpu_counts["node4_visits_per_occlusion_ray"] * st.rays_any) \
+                    + 48.0 * (gpu_counts["tri_tests_per_closest_ray"] * st.rays_closest + gpu_counts["tri_tests_per_occlusion_ray"] * st.rays_any)
+                roofline["product_tree_model"] = {"note": "algorithmic bytes of the tree the kernel walks (every node visit = 64 B, every triangle test = 48 B, "
+                                                          "no cache credit) / wall time", "bytes_per_ray": b / run_rays, "gbs": b / wall_s / 1e9,
+                                                  "ratio_to_hbm_peak": b / wall_s / 1e9 / HBM_PEAK_GBS}
 
         # the display resolve, outside the timed region: device-side displayGL.frag -> RGBA8
         disp_ms = None
@@ -364,11 +513,15 @@ def main():
             if world == 1:
                 assert int(shown.view(torch.uint8).reshape(sc.height, sc.width, 4)[..., 3].min().item()) == 255
 
+        # BASELINE metric 2, measured live: the full leg (--converge: 16 runs) takes ~2.5 min on c3, the default run does 3 of the 16
+        # runs (the runs differ by a few passes in 2900: profiles/r1h_converge_c3.json) so that the line's number is this run's own
         conv = None
-        if args.converge and world == 1 and not emulated:
-            conv = convergence_leg(core, sc, dev, stream, args.converge_cap, args.converge_runs)
+        if world == 1 and not emulated and not args.no_converge and not args.pmc_child:
+            n_runs = args.converge_runs if args.converge else min(3, args.converge_runs)
+            conv = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
             conv["measured_live"] = True
-        else:  # the leg takes minutes on c3: the committed measurement of the same workload is quoted instead
+            conv["runs_of_16"] = n_runs
+        else:
             cpath = os.path.join(ROOT, "profiles", "converge.json")
             if os.path.exists(cpath):
                 conv = json.load(open(cpath)).get(args.workload)
@@ -379,6 +532,8 @@ def main():
         out = {
             "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3") else f"Mrays/s ({args.workload})",
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # untimed device wake-up BEFORE the W warm-up steps (clock ramp / first touch of the pass slots on a freshly started box)
+            "wakeup_passes": n_wake, "wakeup_s": wake_s,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "width": sc.width, "height": sc.height,
@@ -386,6 +541,8 @@ def main():
                        "sharding": f"32x32 pixel tiles round-robin over {world} GPU(s)" + (f"; RCCL gather of the owned RGBA32F tiles to rank 0 every {post_every} step(s) (= every resolved batch of passes), overlapped on a side stream" if exchange else ""),
                        "seed": hex(scenes.SEED)},
             "roofline": roofline,
+            "pmc_passes": None if pmc is None else {"seconds": pmc.get("seconds"), "failed": bool(pmc.get("failed")), "passes": pmc.get("passes"),
+                                                    "k_trace": pmc.get("kernels", {}).get("k_trace")},
             "cpu_baseline": cpu,
             "passes_to_converge": conv,
             "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,

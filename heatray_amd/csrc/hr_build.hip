@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
 
 int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, BuildResult *out)
 {
-    out->nodes = nullptr, out->tris = nullptr, out->nNodes = 0, out->rootLeafCount = 0;
+    out->nodes = nullptr, out->tris = nullptr, out->nNodes = 0, out->rootLeafCount = 0, out->levels = 0;
     if (n == 0) return 0;
     if (n >= (1u << 28)) return 2;
     const uint32_t nBlocks = (n + kSortTile - 1) / kSortTile;
@@ -508,8 +508,10 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
             }
             levelStart = levelEnd;
             levelEnd = newEnd;
+            out->levels = level + 1;
         }
         hipFree(binOf);
+        if (levelEnd > levelStart && rc == 0) rc = 6; // deeper than the key length allows: cannot happen with n < 2^28
         out->nNodes = (int)levelEnd;
         uint32_t placed = 0;
         HR_CHECK(hipMemcpyAsync(&placed, total + 1, 4, hipMemcpyDeviceToHost, st));

@@ -4,6 +4,7 @@
 // a pass.  There is no CPU rendering path in this library: without a usable HIP device every entry point
 // that needs one fails with HR_ERR_DEVICE.
 #include "hr_kernels.h"
+#include "hr_trace.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -51,6 +52,7 @@ struct hr_ctx {
     float *fbInternal = nullptr, *fbExternal = nullptr;
     float *pinned = nullptr;
     size_t pinnedBytes = 0;
+    hipEvent_t evPack = nullptr; // orders hr_frame_pack_owned on a foreign stream against the resolves on the ctx stream
     void *dDisplay = nullptr, *pinnedDisplay = nullptr; // display resolve: device staging + pinned host copy
     // Progressive snapshots are handed out one call late from rotating buffers: the host then waits for a copy enqueued a
     // whole call ago instead of for everything it has just enqueued, so the GPU always has the next step queued
@@ -390,6 +392,7 @@ int hr_ctx_destroy(hr_ctx *c)
     hipStreamSynchronize(c->stream);
     c->drainTimes();
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
+    if (c->evPack) hipEventDestroy(c->evPack);
     freeQueues(c);
     freeSceneDevice(c);
     for (Texture &t : c->textures) hipFree(t.dpx);
@@ -448,8 +451,18 @@ int hr_frame_pack_owned(hr_ctx *c, void *device_out, void *stream)
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
     FrameDev fr = c->frame;
     fr.fb = c->fb();
-    launchPackOwned(c->cfg(stream ? (hipStream_t)stream : c->stream), fr, c->fb(), (float *)device_out, 0, nullptr);
+    hipStream_t st = stream ? (hipStream_t)stream : c->stream;
+    if (st != c->stream) { // the resolves enqueued so far run on the ctx stream: order the copy behind them
+        if (!c->evPack) HIP_TRY(c, hipEventCreateWithFlags(&c->evPack, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->evPack, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(st, c->evPack, 0));
+    }
+    launchPackOwned(c->cfg(st), fr, c->fb(), (float *)device_out, 0, nullptr);
     HIP_TRY(c, hipGetLastError());
+    if (st != c->stream) { // ... and the next resolve (which rewrites the frame) behind the copy
+        HIP_TRY(c, hipEventRecord(c->evPack, st));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evPack, 0));
+    }
     return HR_OK;
 }
 
@@ -682,15 +695,37 @@ static inline float floatFromOrdered(uint32_t u)
     return f;
 }
 
+// Device temporaries and timing events of one commit: released on every exit path.
+namespace {
+struct CommitScratch {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    GeomDev *dG = nullptr;
+    Tri *trisPrim = nullptr;
+    BuildResult br{};
+    bool keepBuild = false;
+    ~CommitScratch()
+    {
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        hipFree(dG), hipFree(trisPrim);
+        if (!keepBuild) hipFree(br.nodes), hipFree(br.tris);
+    }
+};
+} // namespace
+
 int hr_scene_commit(hr_ctx *c)
 {
     ENTER(c);
     QUIESCE(c);
-    hipEvent_t e0, e1;
-    HIP_TRY(c, hipEventCreate(&e0));
-    HIP_TRY(c, hipEventCreate(&e1));
-    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    // until this call succeeds there is no scene to render: a failed re-commit must not leave `committed` set over freed arrays
+    c->committed = false, c->sceneDirty = true;
+    CommitScratch cs;
+    HIP_TRY(c, hipEventCreate(&cs.e0));
+    HIP_TRY(c, hipEventCreate(&cs.e1));
+    HIP_TRY(c, hipEventRecord(cs.e0, c->stream));
     freeSceneDevice(c);
+    c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
+    c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0;
     // ---- stage every live geometry into one device buffer (skipped when only transforms changed since the last commit)
     std::vector<GeomDev> gd;
     std::vector<float> stageF;
@@ -729,15 +764,12 @@ int hr_scene_commit(hr_ctx *c)
     if (!reuse) {
         hipFree(c->dGeomF), hipFree(c->dGeomI);
         c->dGeomF = nullptr, c->dGeomI = nullptr;
+        c->geomCacheValid = false;
         c->geomOffs = offs;
     }
     std::memset(&c->info, 0, sizeof(c->info));
-    c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0;
-    c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
     c->hScene.rayEps = 0.0f;
     if (nTris > 0) {
-        GeomDev *dG = nullptr;
-        Tri *trisPrim = nullptr;
         if (!reuse) {
             HIP_TRY(c, hipMalloc(&c->dGeomF, stageF.size() * sizeof(float)));
             HIP_TRY(c, hipMalloc(&c->dGeomI, stageI.size() * sizeof(uint32_t)));
@@ -748,8 +780,8 @@ int hr_scene_commit(hr_ctx *c)
         }
         float *dF = c->dGeomF;
         uint32_t *dI = c->dGeomI;
-        HIP_TRY(c, hipMalloc(&dG, gd.size() * sizeof(GeomDev)));
-        HIP_TRY(c, hipMalloc(&trisPrim, sizeof(Tri) * (size_t)nTris));
+        HIP_TRY(c, hipMalloc(&cs.dG, gd.size() * sizeof(GeomDev)));
+        HIP_TRY(c, hipMalloc(&cs.trisPrim, sizeof(Tri) * (size_t)nTris));
         HIP_TRY(c, hipMalloc(&c->attrs, sizeof(TriAttr) * (size_t)nTris));
         if (anyExt) HIP_TRY(c, hipMalloc(&c->attrsExt, sizeof(TriAttrExt) * (size_t)nTris));
         for (size_t i = 0; i < gd.size(); ++i) {
@@ -761,10 +793,10 @@ int hr_scene_commit(hr_ctx *c)
             gd[i].col = o.col == none ? nullptr : dF + o.col;
             gd[i].idx = dI + o.idx;
         }
-        HIP_TRY(c, hipMemcpyAsync(dG, gd.data(), gd.size() * sizeof(GeomDev), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(cs.dG, gd.data(), gd.size() * sizeof(GeomDev), hipMemcpyHostToDevice, c->stream));
         const uint32_t initB[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
         HIP_TRY(c, hipMemcpyAsync(c->dScratch, initB, sizeof(initB), hipMemcpyHostToDevice, c->stream));
-        launchAssemble(c->stream, dG, (int)gd.size(), nTris, trisPrim, c->attrs, c->attrsExt, c->dScratch);
+        launchAssemble(c->stream, cs.dG, (int)gd.size(), nTris, cs.trisPrim, c->attrs, c->attrsExt, c->dScratch);
         uint32_t ob[6];
         HIP_TRY(c, hipMemcpyAsync(ob, c->dScratch, sizeof(ob), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -774,24 +806,22 @@ int hr_scene_commit(hr_ctx *c)
         const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
         const float diag = sqrtf(ex * ex + ey * ey + ez * ez);
         const float pad = 1e-5f * diag;
-        BuildResult br{};
-        const int rc = buildLBVH(c->stream, trisPrim, nTris, lo, hi, pad, &br);
-        hipFree(dG), hipFree(trisPrim);
-        if (rc != 0) {
-            hipFree(br.nodes), hipFree(br.tris);
-            FAIL(c, HR_ERR_DEVICE, rc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
-        }
-        c->nodes = br.nodes, c->tris = br.tris;
+        const int rc = buildLBVH(c->stream, cs.trisPrim, nTris, lo, hi, pad, &cs.br);
+        if (rc != 0) FAIL(c, HR_ERR_DEVICE, rc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
+        // the traversal stack holds at most 3 entries per level of inner nodes (hr_trace.h)
+        if (3 * cs.br.levels > kStackLDS + kStackOvf) FAIL(c, HR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+        cs.keepBuild = true;
+        c->nodes = cs.br.nodes, c->tris = cs.br.tris;
         c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = c->attrsExt;
-        c->hScene.nTris = (int)nTris, c->hScene.nNodes = br.nNodes, c->hScene.rootLeafCount = br.rootLeafCount;
+        c->hScene.nTris = (int)nTris, c->hScene.nNodes = cs.br.nNodes, c->hScene.rootLeafCount = cs.br.rootLeafCount;
         c->hScene.rayEps = 1e-4f * diag;
         for (int k = 0; k < 3; ++k) c->info.aabb_min[k] = lo[k], c->info.aabb_max[k] = hi[k];
-        c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)br.nNodes, c->info.ray_epsilon = c->hScene.rayEps;
+        c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)cs.br.nNodes, c->info.ray_epsilon = c->hScene.rayEps;
+        c->info.bvh_levels = (uint32_t)cs.br.levels;
     }
-    HIP_TRY(c, hipEventRecord(e1, c->stream));
-    HIP_TRY(c, hipEventSynchronize(e1));
-    hipEventElapsedTime(&c->info.build_ms, e0, e1);
-    hipEventDestroy(e0), hipEventDestroy(e1);
+    HIP_TRY(c, hipEventRecord(cs.e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(cs.e1));
+    hipEventElapsedTime(&c->info.build_ms, cs.e0, cs.e1);
     c->committed = true;
     c->sceneDirty = true;
     return HR_OK;

@@ -94,6 +94,7 @@ struct BuildResult {
     Node4 *nodes;
     Tri *tris;
     int32_t nNodes, rootLeafCount;
+    int32_t levels; // levels of 4-wide inner nodes (the traversal stack holds at most 3 entries per level)
 };
 
 // scene bounds as float-ordered uints: lo.xyz, hi.xyz

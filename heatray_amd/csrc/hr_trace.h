@@ -7,7 +7,8 @@
 // to be conservative (boxes are padded at build time).  While-while traversal: all lanes descend
 // inner nodes until each holds a leaf, then all test triangles.  The deferred-child stack lives in
 // LDS, one column per lane ([entry][lane] => bank = lane, conflict-free), with a private overflow
-// region so that no tree depth can corrupt it.
+// region sized for the deepest tree the builder can produce (kStackLDS + kStackOvf >= 3 x kMaxTreeLevels;
+// hr_scene_commit additionally checks the built tree's level count against it).
 #pragma once
 
 #include "hr_texture.h"
@@ -19,7 +20,12 @@ namespace hr {
 #define HR_STACK_LDS 16
 #endif
 static const int kStackLDS = HR_STACK_LDS; // entries per lane kept in LDS
-static const int kStackOvf = 80;   // private overflow: a 4-wide node pushes up to 3 entries per level, binary depth <= 58 -> <= 29 levels
+// A 4-wide node pushes up to 3 entries and the ray descends one level, so a path through L inner levels holds at most 3 L
+// entries.  The collapse opens the child with the largest area, so an unopened sibling sits only ONE binary level deeper:
+// along such a path the 4-wide depth equals the binary depth, and that is bounded by the key length of the radix tree:
+// 30 Morton bits + 28 index bits (n < 2^28) = 58 levels.
+static const int kMaxTreeLevels = 58;
+static const int kStackOvf = 3 * kMaxTreeLevels + 2 - HR_STACK_LDS; // private overflow area (scratch; touched by 0.1 % of node steps on c3)
 static const int kSentinel = 0x7FFFFFFF;
 static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
 static const int kTriPhaseLanes = 20; // run the triangle phase once this many lanes are blocked on a postponed leaf

@@ -131,6 +131,8 @@ typedef struct hr_scene_info {
     float aabb_max[3];
     float ray_epsilon; /* self-intersection t_min, 1e-4 * |aabb diagonal| */
     float build_ms;
+    uint32_t bvh_levels; /* levels of inner nodes of the acceleration structure (0 for the oracle's brute force / a leaf root) */
+    uint32_t reserved;
 } hr_scene_info;
 int hr_scene_get_info(hr_ctx *ctx, hr_scene_info *out);
 
@@ -411,7 +413,8 @@ int hr_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t fo
 /* number of float4 slots hr_frame_pack_owned writes for `rank` of `world` at the ctx's frame size and tile size */
 int hr_frame_packed_slots(hr_ctx *ctx, int32_t rank, int32_t world, uint64_t *n_slots);
 /* this context's owned pixels -> device_out (n_slots x RGBA32F); asynchronous on `stream` (a hipStream_t; NULL = the
- * ctx stream, which orders it after the passes resolved so far — the pipeline is NOT drained: progressive display) */
+ * ctx stream).  Either way the copy is ordered after the passes resolved so far and before the next resolve (on a
+ * foreign stream through events) — the pipeline is NOT drained: progressive display */
 int hr_frame_pack_owned(hr_ctx *ctx, void *device_out, void *stream);
 /* rank `src_rank`'s packed pixels -> their place in a full-frame RGBA32F buffer (width*height*16 B); asynchronous on
  * `stream` (NULL = the ctx stream), e.g. the side stream the collective ran on */

@@ -206,6 +206,51 @@ def test_hostile_geometry_hits_bit_exact(golden):
     assert_parity(g.readback(), o.readback(), "hostile geometry render")
 
 
+def test_deep_tree_stresses_the_traversal_stack():
+    # A deliberately deep tree: 8192 coincident triangles inside one Morton cell of a scene 2000 units wide (the radix tree splits
+    # them on index bits, and every ray through them hits all four children at every level), a chain of 28 nested, mutually
+    # overlapping sheets whose centroids sit in ever smaller Morton cells, and some filler.  The traversal stack (16 LDS entries
+    # + private overflow, sized for 3 entries per level of the deepest tree the builder can make) must neither overflow nor drop
+    # a hit; equal distances are resolved towards the smallest triangle id.
+    rng = np.random.default_rng(123)
+    one = np.array([[-0.01, -0.01, 0.5], [0.02, -0.01, 0.5], [-0.01, 0.02, 0.5]], np.float32)
+    coincident = np.tile(one[None], (8192, 1, 1))
+    sheets = []
+    for j in range(28):
+        c, s = 700.0 * 2.0 ** -j, 2.5 * 700.0 * 2.0 ** -j
+        sheets.append([[c - s, c - s, 1.0 + 0.01 * j], [c + 2 * s, c - s, 1.0 + 0.01 * j], [c - s, c + 2 * s, 1.0 + 0.01 * j]])
+    sheets = np.array(sheets, np.float32)
+    filler = rng.uniform(-1000, 1000, (300, 1, 3)).astype(np.float32) + rng.uniform(-30, 30, (300, 3, 3)).astype(np.float32)
+    pos = np.concatenate([coincident, sheets, filler]).astype(np.float32)
+    sc = scenes.Scene("deep", width=16, height=16)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (pos.shape[0] * 3, 1))
+    sc.materials = scenes._material_palette(scenes.SplitMix64(2), 1)
+    sc.meshes.append(scenes.MeshData(pos.reshape(-1, 3), nrm, np.arange(pos.shape[0] * 3, dtype=np.uint32), material_id=0))
+    g, ob = core.create_engine(), oracle_lib.engine()
+    sc.apply(g), sc.apply(ob)
+    oracle_lib.load().ora_set_brute_force(ob._ctx, 1)
+    info = g.scene_info()
+    assert info.bvh_levels >= 8, info.bvh_levels                    # a shallow tree would not test anything
+    assert 3 * info.bvh_levels <= 16 + 160                          # kStackLDS + kStackOvf (hr_trace.h)
+    n = 4000
+    org = np.zeros((n, 3), np.float32)
+    org[:, :2] = rng.uniform(-0.02, 0.03, (n, 2))
+    org[:, 2] = rng.choice([-5.0, 8.0], n)
+    d = np.zeros((n, 3), np.float32)
+    d[:, 2] = -np.sign(org[:, 2])
+    d[:, :2] = rng.normal(scale=2e-3, size=(n, 2))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    hg, hb = g.debug_trace(org, d), ob.debug_trace(org, d)
+    assert (hb["prim"] >= 0).mean() > 0.5
+    assert hg.tobytes() == hb.tobytes(), f"{(hg != hb).sum()} of {n} closest hits differ"
+    first = hb["prim"][(hb["prim"] >= 0) & (hb["prim"] < 8192)]
+    assert first.size > 100 and (first == 0).all()                  # 8192 equal distances: triangle 0 wins
+    tm = rng.uniform(0.5, 12.0, n).astype(np.float32)
+    ag = g.debug_trace(org, d, tmax=tm, skip_prim=hb["prim"], any_hit=True)
+    ab = ob.debug_trace(org, d, tmax=tm, skip_prim=hb["prim"], any_hit=True)
+    assert ag.tobytes() == ab.tobytes()
+
+
 def test_tiny_scenes_and_frames(golden):
     # 1, 2 and 5 triangles (root leaf / a root with leaf children only), frames of 1x1, 33x17 and 1x64 pixels
     for n_tris, (w, h) in [(1, (1, 1)), (2, (33, 17)), (5, (1, 64)), (1, (40, 24))]:
@@ -465,6 +510,51 @@ def test_full_size_config3_properties(golden):
         own = ob[..., 3] > 0
         assert own.sum() in (32 * 32, 32 * 24)                 # 1080 = 33 * 32 + 24: the top tile row is cropped
         assert a[own].tobytes() == ob[own].tobytes()
+
+
+def test_full_size_config5_properties(golden):
+    # BASELINE config 5 at full size on one GPU: 3840x2160, 16 bounces, 1M triangles, 25 % glass + 25 % clearcoat materials,
+    # f/2.8 depth of field with the PENTAGON aperture (deterministic host-side tables, host.polygon_aperture)
+    W, H, depth = 3840, 2160, 16
+    sc = scenes.triangle_soup(1_000_000, width=W, height=H, bounces=depth, passes=32, env=True, glass_fraction=0.25, clearcoat_fraction=0.25)
+    sc.options.fstop = 2.8
+    sc.options.bokeh_shape = ffi.HR_BOKEH_PENTAGON
+    assert sum(1 for m in sc.materials.values() if m.type == ffi.HR_MAT_GLASS) == 4
+    assert sum(1 for m in sc.materials.values() if m.type == ffi.HR_MAT_PBR and m.clear_coat > 0) == 4
+    e = core.create_engine()
+    sc.apply(e, lut=golden["multiscatter_lut"])     # polygonal bokeh: scenes.Scene.apply builds the tables through the engine
+    assert e.scene_info().n_triangles == 1_000_000
+    passes = 2
+    for s in range(passes):
+        e.render_pass(sc.options.pass_params(s))
+    a = e.readback()
+    st = e.stats()
+    assert a.shape == (H, W, 4)
+    assert (a[..., 3] == passes).all()
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all()
+    assert st.paths == W * H * passes
+    assert st.rays_closest + st.rays_any <= W * H * passes * 2 * (depth + 1)       # SURVEY §8a ray budget
+    assert st.rays_closest > st.paths and st.rays_any > 0                          # paths bounce and sample lights
+    assert a[..., :3].max() <= sc.options.max_channel_value * passes * (2 * (depth + 1) + 1)
+    e.clear()                                                                      # idempotence
+    for s in range(passes):
+        e.render_pass(sc.options.pass_params(s))
+    assert e.readback().tobytes() == a.tobytes()
+    # tiles of the full-size frame against the oracle, bit for bit: the centre, and the ragged top row (2160 = 67 * 32 + 16)
+    n_tiles = 120 * 68
+    for tile_id in (34 * 120 + 60, n_tiles - 50):
+        o = oracle_lib.engine(rank=tile_id, world=n_tiles, tile_size=32)
+        sc.apply(o, lut=golden["multiscatter_lut"])
+        for s in range(passes):
+            o.render_pass(sc.options.pass_params(s))
+        ob = o.readback()
+        own = ob[..., 3] > 0
+        assert own.sum() in (32 * 32, 32 * 16)
+        assert a[own].tobytes() == ob[own].tobytes()
+        ost = o.stats()
+        if tile_id == 34 * 120 + 60:                               # the centre tile looks into the soup (the top row sees sky only)
+            assert ost.shaded_hits > 0 and ost.rays_any > 0
+    e.close()
 
 
 # ------------------------------------------------------------- display resolve

@@ -6,7 +6,7 @@ for t in "$@"; do
   lib=""
   if [[ "$t" == @* ]]; then n="${t%%:*}"; lib="$PWD/build_variants/libhrcore_${n#@}.so"; fi
   tune="${t#@*:}"; [[ "$t" == @* && "$t" != *:* ]] && tune=""
-  HRCORE_LIB="$lib" HR_TUNE="$tune" python bench.py --cpu-seconds 0 --no-stats-pass $args > gpurun_out/ab.json 2> gpurun_out/ab.err || { echo "FAILED $t"; tail -3 gpurun_out/ab.err; exit 1; }
+  HRCORE_LIB="$lib" HR_TUNE="$tune" python bench.py --quick $args > gpurun_out/ab.json 2> gpurun_out/ab.err || { echo "FAILED $t"; tail -3 gpurun_out/ab.err; exit 1; }
   python - "$t" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab.json"))

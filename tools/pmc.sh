@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 i=0
 for ctrs in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $ctrs -d "$OUT/p$i" -o p --output-format csv -- python3 bench.py --cpu-seconds 0 --no-stats-pass --warmup 0 --no-wakeup --steps ${STEPS:-16} ${EXTRA} > "$OUT/p$i.json" 2> "$OUT/p$i.err" || { echo "pass $i ($ctrs) failed"; tail -3 "$OUT/p$i.err"; }
+  rocprofv3 --kernel-trace --pmc $ctrs -d "$OUT/p$i" -o p --output-format csv -- python3 bench.py --quick --warmup 0 --no-wakeup --steps ${STEPS:-16} ${EXTRA} > "$OUT/p$i.json" 2> "$OUT/p$i.err" || { echo "pass $i ($ctrs) failed"; tail -3 "$OUT/p$i.err"; }
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys

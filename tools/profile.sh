@@ -4,7 +4,7 @@
 # Afterwards, in the repo:  python tools/summarize_profile.py <tag>   -> profiles/<tag>_*
 set -e
 tag="$1"; shift
-ARGS="--cpu-seconds 0 --no-stats-pass --warmup 0 --no-wakeup $*"
+ARGS="--quick --warmup 0 --no-wakeup $*"
 ROOT="$PWD"
 OUT="$ROOT/gpurun_out/prof_$tag"
 rm -rf "$OUT"; mkdir -p "$OUT"

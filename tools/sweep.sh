@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/sweep.sh "leaf=4,tri=20" "leaf=2,tri=20" ...   (runs bench per HR_TUNE setting, prints one line each)
 for t in "$@"; do
-  HR_TUNE="$t" python bench.py --cpu-seconds 0 --steps ${STEPS:-16} ${EXTRA} 2>/dev/null | python -c "
+  HR_TUNE="$t" python bench.py --cpu-seconds 0 --no-pmc --no-converge --steps ${STEPS:-16} ${EXTRA} 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline'] or {}
 g=d['extra'].get('gpu_traversal_counters') or {}
