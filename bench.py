@@ -49,6 +49,7 @@ WORKLOADS = {
     # BASELINE.json configs; c3 is the configuration the north-star target (>= 1 Gray/s) is quoted on
     "c1": dict(desc="Cornell box (32 tris), 256x256, 4 bounces"),
     "c2": dict(desc="synthetic soup 50k tris, 16 PBR materials, 1 directional light, 1920x1080, 8 bounces"),
+    "c2p": dict(desc="c2 with 30% single-sided / alpha-masked (pass-through) materials, as glTF assets have them"),
     "c3": dict(desc="synthetic soup 1M tris + 2048x1024 HDRI + NEE, 1920x1080, 8 bounces"),
     "c5": dict(desc="soup 1M tris, 25% glass, 25% clearcoat, f/2.8 pentagon-bokeh DoF, 3840x2160, 16 bounces"),
 }
@@ -59,6 +60,8 @@ def build_scene(name, width, height, passes):
         return scenes.cornell_box(width or 256, height or 256, bounces=4, passes=passes)
     if name == "c2":
         return scenes.triangle_soup(50_000, width or 1920, height or 1080, bounces=8, passes=passes, env=False)
+    if name == "c2p":
+        return scenes.triangle_soup(50_000, width or 1920, height or 1080, bounces=8, passes=passes, env=False, passthrough_fraction=0.3)
     if name == "c3":
         return scenes.triangle_soup(1_000_000, width or 1920, height or 1080, bounces=8, passes=passes, env=True)
     if name == "c5":
@@ -317,10 +320,10 @@ def main():
     eng.bind_external_frame(fb.data_ptr())
     gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3, engine=eng) if exchange else None
 
-    # On a small shard libhrcore injects (and therefore resolves) passes in batches of ceil(1080p / owned pixels) <= 16
-    # (hr_frame_resize): the accumulation buffer changes once per batch, so that is the exchange cadence as well.
+    # libhrcore injects (and therefore resolves) passes in batches (hr_frame_pass_batch): the accumulation buffer changes once per
+    # batch, so that is the exchange cadence as well.
     owned_px = len(tiles.owned_tiles(sc.width, sc.height, eng_rank, eng_world)) * 32 * 32
-    post_every = max(1, min(16, -(-1920 * 1080 // max(owned_px, 1))))
+    post_every = max(1, eng.pass_batch(sc.options.max_ray_depth))
 
     def step(i):
         eng.render_pass(sc.options.pass_params(i))

@@ -151,6 +151,7 @@ ABI_SYMBOLS = [
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
     "display", "display_readback", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
+    "frame_pass_batch",
 ]
 
 
@@ -316,6 +317,11 @@ class Engine:
 
     def render_pass(self, params):
         self._call("render_pass", C.byref(params))
+
+    def pass_batch(self, max_ray_depth):
+        b = C.c_int32(0)
+        self._call("frame_pass_batch", C.c_int32(max_ray_depth), C.byref(b))
+        return int(b.value)
 
     def flush(self):
         self._call("flush")

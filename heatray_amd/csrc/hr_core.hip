@@ -107,6 +107,14 @@ struct hr_ctx {
         unsigned long long stepCounter = 0;
         hipEvent_t evUser = nullptr;    // caller-stream state this group has to wait for
         bool needUserSync = true;
+        // Pass-through scenes (single-sided / alpha-masked materials): a pass has no fixed number of stages, so after every
+        // macro step the closest-queue lengths of all pass slots are copied to a pinned ring; the host reads the copy of TWO
+        // steps ago (a step that has long finished while newer ones are still queued: it never waits for work it has just
+        // enqueued) and retires the passes whose queue ran empty.
+        uint32_t *hQCount = nullptr;    // [kStatusRing][kMaxSlots][kMaxBounceSlots], pinned
+        hipEvent_t statusEv[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool statusUsed[4] = {false, false, false, false};
+        unsigned long long statusOrder[4][2 * HR_MAX_SEGS]; // pass (order + 1) a slot held when the snapshot was taken, 0 = none
     };
     Group groups[kMaxGroups];
     int nGroups = 2;      // groups in use: chosen per frame size in hr_frame_resize unless HR_TUNE fixes it
@@ -123,6 +131,7 @@ struct hr_ctx {
     int lastDepth = -1;
     unsigned long long injected = 0;
     uint32_t *dZero = nullptr;    // a zero word (occlusion count of a pass's first step)
+    Counters *dCounters = nullptr; // one per pass slot, contiguous (copied to the host in one piece in pass-through scenes)
 
     // scene (host mirror)
     std::vector<Geom> geoms;
@@ -295,7 +304,7 @@ static void freeQueues(hr_ctx *c)
     for (hr_ctx::PassSlot &ps : c->slots) {
         for (int i = 0; i < 2; ++i) hipFree(ps.q[i].A), hipFree(ps.q[i].B), hipFree(ps.q[i].C), hipFree(ps.q[i].D);
         hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C);
-        hipFree(ps.hits), hipFree(ps.passbuf), hipFree(ps.ctr);
+        hipFree(ps.hits), hipFree(ps.passbuf);
         if (ps.evFinal) hipEventDestroy(ps.evFinal);
         if (ps.evResolved) hipEventDestroy(ps.evResolved);
         ps = hr_ctx::PassSlot();
@@ -371,10 +380,13 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipEventCreateWithFlags(&G.evUser, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.statusEv[k], hipEventDisableTiming) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hQCount, sizeof(uint32_t) * kTableRing * kMaxSlots * kMaxBounceSlots, hipHostMallocDefault) == hipSuccess;
+        std::memset(G.statusOrder, 0, sizeof(G.statusOrder));
     }
     if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
         hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess ||
-        hipMalloc(&c->dZero, 64) != hipSuccess) {
+        hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters) * kMaxSlots) != hipSuccess) {
         delete c;
         return HR_ERR_DEVICE;
     }
@@ -402,8 +414,11 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->dGeomF), hipFree(c->dGeomI);
     if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
-    hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero);
+    hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dCounters);
     for (hr_ctx::Group &G : c->groups) {
+        if (G.hQCount) hipHostFree(G.hQCount);
+        for (hipEvent_t e : G.statusEv)
+            if (e) hipEventDestroy(e);
         if (G.stream) hipStreamDestroy(G.stream);
         hipFree(G.dTables);
         if (G.hTables) hipHostFree(G.hTables);
@@ -582,23 +597,25 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
     c->maxSlots = kMaxSlots;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 + hitRecordSize()) + fbBytes + sizeof(Counters);
-        const size_t fit = (freeB / 2) / perSlot;
+        const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
         c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
     }
     {
-        const long long target = 1920ll * 1080ll; // paths per macro step worth launching for
+        // Paths per macro step worth launching for.  A trace launch ends in a tail of a few long rays (0.5-0.7 ms whatever it
+        // carries) and every pass costs depth + 2 dependent launches, so passes requested back to back are collected and injected
+        // together: 9 passes of a 1080p frame per step measured 1715 against 1607 Mrays/s (128 passes) and 1488 against 1400
+        // (20 passes) for one at a time on two pipeline groups (profiles/r2b_batch_sweep*.txt).  A caller that asks for pixels
+        // after every pass (hr_readback) completes what is pending, so batching never delays a displayed frame.
+        const long long target = 9ll * 1920ll * 1080ll;
         const long long own = c->queueCapacity ? c->queueCapacity : 1;
         long long b = (target + own - 1) / own;
         c->injectBatch = (int)(b < 1 ? 1 : (b > 16 ? 16 : b));
         if (c->tuneBatch > 0) c->injectBatch = c->tuneBatch;
         // Two pipeline groups (their steps alternate on two streams, so one group's trace tail and its shade / raygen run
-        // under the other group's trace) pay off while one trace launch does not fill the GPU for long: measured on MI355X
-        // +11..14 % on a full 1080p frame and on a 1/2 shard, +5 % on 1/4, +5 % at 2560x1440; on a 1/8 shard +8 % at 64 passes
-        // and +16 % at 128 (-5 % at 32: each group has its own pipeline fill and drain; long runs — a viewer accumulates
-        // thousands of passes — are what counts); at 3840x2160 -1..2 %.  With two resident trace kernels three workgroups per
-        // CU each are best, alone five.
-        const bool notHuge = c->queueCapacity <= 4200000u;
-        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (notHuge ? 2 : 1);
+        // under the other group's trace) pay off only while a launch carries little work: +11..14 % on a 1080p frame at one pass
+        // per step; with several passes per step one group (five trace workgroups per CU) is as fast or faster (1697 vs 1696
+        // Mrays/s at 8 passes per step) and needs half the pass slots.
+        c->nGroups = c->tuneGroups > 0 ? c->tuneGroups : (c->injectBatch >= 4 || c->queueCapacity > 4200000u ? 1 : 2);
         c->nextGroup = 0;
         if (!c->tuneBlocksSet) c->tuneBlocks = c->nGroups > 1 ? 3 : 5;
         c->pendingInject.clear();
@@ -1113,7 +1130,7 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
     HIP_TRY(c, hipMalloc(&ps.sq.C, n16));
     HIP_TRY(c, hipMalloc(&ps.hits, cap * hitRecordSize()));
     HIP_TRY(c, hipMalloc(&ps.passbuf, (size_t)c->W * c->H * 4 * sizeof(float)));
-    HIP_TRY(c, hipMalloc(&ps.ctr, sizeof(Counters)));
+    ps.ctr = c->dCounters + (&ps - c->slots);
     HIP_TRY(c, hipEventCreateWithFlags(&ps.evFinal, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&ps.evResolved, hipEventDisableTiming));
     ps.allocated = true;
@@ -1218,15 +1235,26 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         HIP_TRY(c, hipMemsetAsync(ps.ctr, 0, sizeof(Counters), G.stream));
         injectedSlots[nInjected++] = slot;
     }
-    // Pass-through rays (back faces of single-sided materials, alpha masks) are not bounded by maxRayDepth:
-    // before a pass's last step, see whether closest-hit rays are still queued and extend the pass if so.
+    // Pass-through rays (back faces of single-sided materials, alpha masks: physicallyBased.rlsl:70-108) are not bounded by
+    // maxRayDepth, so in such scenes a pass runs until its closest-hit queue is empty.  The queue lengths come from the snapshot
+    // taken two macro steps ago (see Group::hQCount): a slot about to run stage `st` then knows the lengths of stages <= st - 1;
+    // if stage st - 1 had no rays, it emitted nothing and the pass was complete with the steps already enqueued.
     if (c->hasPassthrough) {
-        for (hr_ctx::PassSlot &ps : c->slots) {
-            if (!ps.active || ps.group != g || ps.step != ps.nIter || ps.nIter >= kMaxBounceSlots - 2) continue;
-            uint32_t remaining = 0;
-            HIP_TRY(c, hipMemcpyAsync(&remaining, &ps.ctr->qCount[ps.nIter], 4, hipMemcpyDeviceToHost, G.stream));
-            HIP_TRY(c, hipStreamSynchronize(G.stream));
-            if (remaining > 0) ps.nIter = ps.nIter + 4 < kMaxBounceSlots - 2 ? ps.nIter + 4 : kMaxBounceSlots - 2;
+        const unsigned long long N = G.stepCounter;
+        if (N >= 2 && G.statusUsed[(N - 2) % kTableRing]) {
+            const int ring = (int)((N - 2) % kTableRing);
+            HIP_TRY(c, hipEventSynchronize(G.statusEv[ring]));
+            const uint32_t *snap = G.hQCount + (size_t)ring * kMaxSlots * kMaxBounceSlots;
+            for (int i = 0; i < kMaxSlots; ++i) {
+                hr_ctx::PassSlot &ps = c->slots[i];
+                if (!ps.active || ps.group != g || G.statusOrder[ring][i] != ps.order + 1ull) continue;
+                const int st = ps.step;
+                const bool empty = st >= 2 && snap[(size_t)i * kMaxBounceSlots + (st - 1)] == 0u;
+                if (empty || st >= kMaxBounceSlots - 2) {
+                    ps.active = false, ps.finished = true;
+                    HIP_TRY(c, hipEventRecord(ps.evFinal, G.stream));
+                }
+            }
         }
     }
     // table of the group's in-flight passes, oldest first
@@ -1235,7 +1263,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         if (c->slots[i].active && c->slots[i].group == g) order[n++] = i;
     for (int a = 1; a < n; ++a)
         for (int b = a; b > 0 && c->slots[order[b]].order < c->slots[order[b - 1]].order; --b) std::swap(order[b], order[b - 1]);
-    if (n == 0) return HR_OK;
+    if (n == 0) return resolveReady(c);
     if (n > kMaxSegs) FAIL(c, HR_ERR_INVALID, "internal: too many passes in one group");
     const int ring = (int)(G.stepCounter++ % kTableRing);
     if (G.tableUsed[ring]) HIP_TRY(c, hipEventSynchronize(G.tableCopied[ring])); // staging entry free again (4 steps old)
@@ -1258,7 +1286,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         sg.qCountOut = &ps.ctr->qCount[st + 1];
         sg.sCountOut = &ps.ctr->sCount[st];
         sg.pp = ps.pp;
-        sg.closestEnabled = st < ps.nIter ? 1 : 0;
+        sg.closestEnabled = (c->hasPassthrough || st < ps.nIter) ? 1 : 0;
         for (int j = 0; j < nInjected; ++j)
             if (order[k] == injectedSlots[j]) injectedSegs[nInjectedSegs++] = k;
     }
@@ -1283,19 +1311,29 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     c->timeEnd(G.stream);
     for (int k = 0; k < n; ++k) {
         hr_ctx::PassSlot &ps = c->slots[order[k]];
-        if (ps.step >= ps.nIter) {
+        if (!c->hasPassthrough && ps.step >= ps.nIter) {
             ps.active = false, ps.finished = true;
             HIP_TRY(c, hipEventRecord(ps.evFinal, G.stream));
         } else {
             ps.step++;
         }
     }
+    if (c->hasPassthrough) { // snapshot of the queue lengths after this step, read two steps from now
+        uint32_t *dst = G.hQCount + (size_t)ring * kMaxSlots * kMaxBounceSlots;
+        HIP_TRY(c, hipMemcpy2DAsync(dst, sizeof(uint32_t) * kMaxBounceSlots, &c->dCounters[0].qCount[0], sizeof(Counters),
+                                    sizeof(uint32_t) * kMaxBounceSlots, kMaxSlots, hipMemcpyDeviceToHost, G.stream));
+        HIP_TRY(c, hipEventRecord(G.statusEv[ring], G.stream));
+        G.statusUsed[ring] = true;
+        for (int i = 0; i < kMaxSlots; ++i)
+            G.statusOrder[ring][i] = (c->slots[i].active && c->slots[i].group == g) ? c->slots[i].order + 1ull : 0ull;
+    }
     HIP_TRY(c, hipGetLastError());
     return resolveReady(c);
 }
 
-// Stages a pass occupies in the pipeline (depth+1 shaded stages + the last occlusion stage).
-static int stagesOf(const hr_pass_params &pp) { return pp.max_ray_depth + 2; }
+// Stages a pass occupies in the pipeline (depth+1 shaded stages + the last occlusion stage; in pass-through scenes two more
+// until the host has seen that its queue ran empty — longer only for rays that really pass through surfaces).
+static int stagesOf(const hr_ctx *c, const hr_pass_params &pp) { return pp.max_ray_depth + 2 + (c->hasPassthrough ? 2 : 0); }
 
 // Advance the group that holds the oldest in-flight pass by one macro step (keeps passes finishing in order).
 static int stepOldest(hr_ctx *c)
@@ -1339,7 +1377,7 @@ static int batchFor(const hr_ctx *c, int stages)
 static int drainPipeline(hr_ctx *c)
 {
     while (!c->pendingInject.empty()) {
-        const int stages = stagesOf(c->pendingInject.front());
+        const int stages = stagesOf(c, c->pendingInject.front());
         const int batch = batchFor(c, stages);
         const int n = (int)c->pendingInject.size() < batch ? (int)c->pendingInject.size() : batch;
         int perGroup = batch * stages;
@@ -1381,7 +1419,7 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     {
         // All pass slots this depth needs are allocated up front, on the first pass (hipMalloc synchronises the device and
         // takes ~0.1 ms per buffer: allocating slot by slot as the pipeline filled stalled the first 20-odd passes of a render)
-        const int stagesNow = stagesOf(*pp);
+        const int stagesNow = stagesOf(c, *pp);
         const int batchNow = batchFor(c, stagesNow);
         int want = c->nGroups * batchNow * stagesNow + 2 * c->nGroups * batchNow;
         if (want > slotLimit(c)) want = slotLimit(c);
@@ -1392,12 +1430,22 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
             }
     }
     c->pendingInject.push_back(*pp);
-    if (c->hasPassthrough) return drainPipeline(c); // such passes may need extra stages: run them alone
     // a macro step is launched once enough passes are waiting to fill it; each group holds batch x stages passes
-    const int stages = stagesOf(*pp);
+    const int stages = stagesOf(c, *pp);
     const int batch = batchFor(c, stages);
     if ((int)c->pendingInject.size() < batch) return HR_OK;
     return injectBatch(c, batch, batch * stages);
+}
+
+int hr_frame_pass_batch(hr_ctx *c, int32_t max_ray_depth, int32_t *batch)
+{
+    ENTER(c);
+    if (!batch || max_ray_depth < 0) FAIL(c, HR_ERR_INVALID, "bad arguments");
+    if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    hr_pass_params pp{};
+    pp.max_ray_depth = max_ray_depth;
+    *batch = batchFor(c, stagesOf(c, pp));
+    return HR_OK;
 }
 
 int hr_flush(hr_ctx *c)

@@ -184,7 +184,7 @@ def cornell_box(width=256, height=256, bounces=4, passes=32):
     return sc
 
 
-def _material_palette(rng, n=16, glass_fraction=0.0, clearcoat_fraction=0.0):
+def _material_palette(rng, n=16, glass_fraction=0.0, clearcoat_fraction=0.0, passthrough_fraction=0.0):
     """16 PBR rows: baseColor ~U(0.2,0.9)^3, roughness ~U(0.05,1), metallic in {0,1} p=0.25 (SURVEY §8d);
     C5 swaps in 25 % glass (ior 1.5, density 0.5, roughness 0.05) and 25 % clearcoat 1 / roughness 0.1."""
     mats = {}
@@ -198,6 +198,12 @@ def _material_palette(rng, n=16, glass_fraction=0.0, clearcoat_fraction=0.0):
         elif i < n_glass + n_cc:
             mats[i] = host.bake_pbr(base_color=base[i], roughness=float(rough[i]), metallic=float(metal[i]),
                                     clear_coat=1.0, clear_coat_roughness=0.1)
+        elif i >= n - int(round(n * passthrough_fraction)):
+            # glTF-style assets: single-sided surfaces (AI_MATKEY_TWOSIDED defaults to false) and alpha-masked cut-outs, whose
+            # back faces / holes let rays pass through (physicallyBased.rlsl:70-108); texture 0 is the scene's alpha mask
+            masked = (i % 2) == 0
+            mats[i] = host.bake_pbr(base_color=base[i], roughness=float(rough[i]), metallic=float(metal[i]), double_sided=False,
+                                    alpha_mask=masked, base_color_texture=0 if masked else -1)
         else:
             mats[i] = host.bake_pbr(base_color=base[i], roughness=float(rough[i]), metallic=float(metal[i]))
     return mats
@@ -235,7 +241,7 @@ def _camera_for(sc, lo, hi, phi=0.6, theta=0.3):
 
 
 def triangle_soup(n_tris, width=1920, height=1080, bounces=8, passes=32, env=False, seed=SEED, glass_fraction=0.0,
-                  clearcoat_fraction=0.0, n_materials=16):
+                  clearcoat_fraction=0.0, n_materials=16, passthrough_fraction=0.0):
     """S-50k / S-1M: N random triangles, centroid ~U([-1,1]^3), two edge vectors ~U([-l,l]^3) with
     l = 0.5 N^(-1/3), de-indexed with flat normals, 16 materials, one directional light
     (theta 60 deg, phi 30 deg, illuminance 683 pi) and optionally the synthetic HDRI."""
@@ -250,14 +256,21 @@ def triangle_soup(n_tris, width=1920, height=1080, bounces=8, passes=32, env=Fal
     pos = np.stack([v0, v0 + e1, v0 + e2], axis=1).astype(F)  # [n,3,3]
     nrm = np.cross(e1.astype(np.float64), e2.astype(np.float64))
     nrm = (nrm / np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-30)).astype(F)
-    sc.materials = _material_palette(rng, n_materials, glass_fraction, clearcoat_fraction)
+    sc.materials = _material_palette(rng, n_materials, glass_fraction, clearcoat_fraction, passthrough_fraction)
+    if passthrough_fraction > 0.0:  # the alpha mask: 32x32 RGBA, a quarter of the texels are holes (alpha 0)
+        chk = ((np.add.outer(np.arange(32), np.arange(32)) // 4) % 4 == 0).astype(F)
+        sc.textures.append((np.stack([np.ones_like(chk)] * 3 + [F(1.0) - chk], axis=-1).astype(F), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_NEAREST))
     for m in range(n_materials):  # triangle i -> material i % 16, one submesh per material
         sel = np.arange(m, n_tris, n_materials)
         if sel.size == 0:
             continue
         p = pos[sel].reshape(-1, 3)
         n = np.repeat(nrm[sel], 3, axis=0)
-        sc.meshes.append(MeshData(p, n, np.arange(p.shape[0], dtype=np.uint32), material_id=m))
+        mat = sc.materials[m]
+        masked = mat.type == ffi.HR_MAT_PBR and bool(mat.flags & ffi.HR_MF_ALPHA_MASK)
+        uv = np.tile(np.array([[0, 0], [1, 0], [0, 1]], dtype=F), (sel.size, 1)) if masked else None
+        # alpha-masked primitives are not occluders: shadow rays run their shader (Mesh.cpp:95-100)
+        sc.meshes.append(MeshData(p, n, np.arange(p.shape[0], dtype=np.uint32), uvs=uv, material_id=m, is_occluder=not masked))
     sc.lights.add_directional(color=(1, 1, 1), illuminance=683.0 * math.pi, phi=math.radians(30.0), theta=math.radians(60.0))
     if env:
         sc.env_pixels = synthetic_hdri()

@@ -353,6 +353,10 @@ int hr_clear(hr_ctx *ctx);
  * hr_readback / hr_display / hr_get_stats / hr_clear / hr_synchronize / hr_flush and
  * every call that changes scene state complete all enqueued passes first. */
 int hr_render_pass(hr_ctx *ctx, const hr_pass_params *params);
+/* How many passes hr_render_pass collects before it launches them together at this frame size and depth (1 = every call
+ * launches).  The accumulation buffer changes once per batch, so this is also the cadence at which a progressive display or a
+ * tile exchange sees new samples.  hr_flush / hr_readback launch whatever is pending. */
+int hr_frame_pass_batch(hr_ctx *ctx, int32_t max_ray_depth, int32_t *batch);
 /* enqueue the remaining stages of every pass in flight (asynchronous): after it, work
  * the caller puts on the ctx stream sees every requested sample in the buffer */
 int hr_flush(hr_ctx *ctx);

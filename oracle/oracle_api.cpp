@@ -381,6 +381,11 @@ int ora_readback_progressive(hr_ctx *ctx, const float **rgba, int32_t *w, int32_
     if (rc == HR_OK && passes) *passes = ctx->passesSinceClear;
     return rc;
 }
+int ora_frame_pass_batch(hr_ctx *, int32_t, int32_t *batch)
+{
+    if (batch) *batch = 1;
+    return HR_OK;
+}
 int ora_synchronize(hr_ctx *) { return HR_OK; }
 int ora_flush(hr_ctx *) { return HR_OK; }
 

