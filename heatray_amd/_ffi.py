@@ -151,7 +151,7 @@ ABI_SYMBOLS = [
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
     "display", "display_readback", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
-    "frame_pass_batch",
+    "frame_pass_batch", "interactive_blocks_set",
 ]
 
 
@@ -317,6 +317,14 @@ class Engine:
 
     def render_pass(self, params):
         self._call("render_pass", C.byref(params))
+
+    def set_interactive_blocks(self, coords_xy):
+        """coords_xy: (ny, nx, 2) integer array in texture memory order, or None for the unshuffled list."""
+        if coords_xy is None:
+            self._call("interactive_blocks_set", None, C.c_int32(0), C.c_int32(0))
+            return
+        a = np.ascontiguousarray(coords_xy, dtype=np.int32)
+        self._call("interactive_blocks_set", a.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int32(a.shape[1]), C.c_int32(a.shape[0]))
 
     def pass_batch(self, max_ray_depth):
         b = C.c_int32(0)

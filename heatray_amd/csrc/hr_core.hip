@@ -138,6 +138,7 @@ struct hr_ctx {
     std::vector<Texture> textures;
     std::vector<hr_material> materials;
     hr_lights lights{};
+    int32_t blockNx = 0, blockNy = 0, blockCoords[32] = {0};
     bool committed = false, sceneDirty = true, hasPassthrough = false;
     // Entity-space vertex data of the live geometries stays resident between commits: a commit after transform-only edits
     // (Scene::applyTransform while the user drags a slider) re-runs assemble + LBVH without staging or re-uploading it.
@@ -916,6 +917,22 @@ int hr_lights_set(hr_ctx *c, const hr_lights *l)
     return HR_OK;
 }
 
+int hr_interactive_blocks_set(hr_ctx *c, const int32_t *coords, int32_t nx, int32_t ny)
+{
+    ENTER(c);
+    if (!coords) {
+        c->blockNx = c->blockNy = 0;
+    } else {
+        if (nx <= 0 || ny <= 0 || nx * ny > 16) FAIL(c, HR_ERR_INVALID, "block table: nx*ny must be 1..16");
+        for (int i = 0; i < nx * ny; ++i)
+            if (coords[2 * i] < 0 || coords[2 * i + 1] < 0) FAIL(c, HR_ERR_INVALID, "block table: negative coordinate");
+        c->blockNx = nx, c->blockNy = ny;
+        std::memcpy(c->blockCoords, coords, sizeof(int32_t) * 2 * (size_t)(nx * ny));
+    }
+    c->sceneDirty = true;
+    return HR_OK;
+}
+
 // ----------------------------------------------------------------------------------- sample tables
 static int setTable(hr_ctx *c, float2 **dst, const float *src, size_t n)
 {
@@ -1091,6 +1108,8 @@ static int uploadScene(hr_ctx *c)
     s.lights = c->lights;
     s.seq = c->dSeq, s.aperture = c->dAperture, s.seqOffsets = c->dSeqOffsets;
     s.nSeq = c->nSeq, s.seqLen = c->seqLen, s.nSeqOffsets = c->nSeqOffsets;
+    s.blockNx = c->blockNx, s.blockNy = c->blockNy;
+    std::memcpy(s.blockCoords, c->blockCoords, sizeof(s.blockCoords));
     HIP_TRY(c, hipMemcpy(c->dScene, &s, sizeof(SceneDev), hipMemcpyHostToDevice));
     // rays can outlive maxRayDepth only by passing through single-sided / alpha-masked surfaces
     c->hasPassthrough = false;

@@ -833,7 +833,7 @@ HRD bool generatePrimary(const SceneDev &S, const hr_pass_params &pp, int W, int
 {
     const float Wf = (float)W, Hf = (float)H;
     const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
-    if (pp.interactive_mode != 0) { // :42-57, identity block layout
+    if (pp.interactive_mode != 0) { // :42-57; block table: hr_interactive_blocks_set (the unshuffled list by default)
         const int bsx = pp.block_size[0], bsy = pp.block_size[1];
         const int bix = (int)(fcx - 0.5f) / bsx, biy = (int)(fcy - 0.5f) / bsy;
         float randX = randomRL((float)bix, (float)biy);
@@ -842,6 +842,7 @@ HRD bool generatePrimary(const SceneDev &S, const hr_pass_params &pp, int W, int
         float sv = (1.0f / (float)bsy) * (float)pp.current_block_pixel[1] + randY;
         int tx = (int)floor_(su * (float)bsx) % bsx, ty = (int)floor_(sv * (float)bsy) % bsy;
         int sampleX = ty, sampleY = tx;
+        if (S.blockNx == bsx && S.blockNy == bsy) sampleX = S.blockCoords[2 * (ty * bsx + tx)], sampleY = S.blockCoords[2 * (ty * bsx + tx) + 1];
         int thisX = (int)(fcx - 0.5f) % bsx, thisY = (int)(fcy - 0.5f) % bsy;
         if (thisX != sampleX || thisY != sampleY) return false;
     }

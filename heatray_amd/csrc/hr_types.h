@@ -85,6 +85,9 @@ struct SceneDev {
     // sample tables
     const float2 *seq, *aperture, *seqOffsets;
     int32_t nSeq, seqLen, nSeqOffsets;
+    // interactive-mode block table (hr_interactive_blocks_set); blockNx == 0: the unshuffled list
+    int32_t blockNx, blockNy;
+    int32_t blockCoords[32];
 };
 
 // ---- counters ---------------------------------------------------------------------------------

@@ -12,10 +12,14 @@
 #define HR_HOST_HAS_RANDOM_H 1
 #endif
 
+#include <algorithm>
 #include <assert.h>
 #include <chrono>
 #include <cmath>
+#include <random>
+#include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 PassGenerator::~PassGenerator()
 {
@@ -95,10 +99,11 @@ void PassGenerator::resize(RLint newWidth, RLint newHeight)
 
 void PassGenerator::renderPass(const RenderOptions& newOptions, PassCompleteCallback callback)
 {
-    m_passCompleteCallback = callback;
+    // The callback travels WITH the job: the reference stores it in a member on the caller's thread and reads it on the worker
+    // without synchronisation (PassGenerator.cpp:117 of the reference), a data race this layer does not reproduce.
     RenderOptions options = newOptions;
-    enqueue([this, options] {
-        runRenderFrameJob(options);
+    enqueue([this, options, callback] {
+        runRenderFrameJob(options, callback);
         return false;
     });
 }
@@ -161,6 +166,30 @@ bool PassGenerator::runInitJob(const RLint renderWidth, const RLint renderHeight
 
     m_scene = Scene::create();
     m_environmentLight = m_scene->lighting()->addEnvironmentLight();
+
+    // The block pixel offsets of interactive rendering (PassGenerator.cpp:267-294 of the reference): the list of (row, col) pairs of
+    // a block, shuffled "so that there is some inherit randomness to make the visualization less regular", handed to the ray
+    // core as a table instead of an RL texture.  HEATRAY_BLOCK_SHUFFLE_SEED makes the shuffle reproducible (tests).
+    {
+        std::vector<int32_t> coords;
+        for (int row = 0; row < RenderOptions::kInteractiveBlockSize.x; ++row) {
+            for (int col = 0; col < RenderOptions::kInteractiveBlockSize.y; ++col) {
+                coords.push_back(row);
+                coords.push_back(col);
+            }
+        }
+        std::vector<int> order(coords.size() / 2);
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        const char* seed = getenv("HEATRAY_BLOCK_SHUFFLE_SEED");
+        std::mt19937 generator(seed ? (unsigned)atoi(seed) : std::random_device()());
+        std::shuffle(order.begin(), order.end(), generator);
+        std::vector<int32_t> shuffled(coords.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            shuffled[2 * i] = coords[2 * order[i]];
+            shuffled[2 * i + 1] = coords[2 * order[i] + 1];
+        }
+        if (!HRFunc(hr_interactive_blocks_set(m_context, shuffled.data(), RenderOptions::kInteractiveBlockSize.x, RenderOptions::kInteractiveBlockSize.y))) return false;
+    }
     return true;
 }
 
@@ -203,7 +232,7 @@ int visualizerModeOf(PassGenerator::RenderOptions::DebugVisualizationMode mode)
 } // namespace
 
 // PassGenerator.cpp:325-401 of the reference: the per-pass driver.
-void PassGenerator::runRenderFrameJob(const RenderOptions& newOptions)
+void PassGenerator::runRenderFrameJob(const RenderOptions& newOptions, const PassCompleteCallback& passCompleteCallback)
 {
     const auto start = std::chrono::steady_clock::now();
 
@@ -279,8 +308,8 @@ void PassGenerator::runRenderFrameJob(const RenderOptions& newOptions)
         }
 
         const float passTime = std::chrono::duration<float>(std::chrono::steady_clock::now() - start).count();
-        if (m_passCompleteCallback) {
-            m_passCompleteCallback(jobCompleted, m_resultPixels, passTime, m_currentSampleIndex);
+        if (passCompleteCallback) {
+            passCompleteCallback(jobCompleted, m_resultPixels, passTime, m_currentSampleIndex);
         }
     } while (!jobCompleted);
 }

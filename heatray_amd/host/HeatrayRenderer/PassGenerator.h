@@ -177,7 +177,7 @@ private:
 
     bool runInitJob(const RLint renderWidth, const RLint renderHeight);
     void runResizeJob(const RLint newRenderWidth, const RLint newRenderHeight);
-    void runRenderFrameJob(const RenderOptions& newOptions);
+    void runRenderFrameJob(const RenderOptions& newOptions, const PassCompleteCallback& passCompleteCallback);
     void runDestroyJob();
 
     // ---- worker thread: a FIFO of closures; a closure returning true ends the thread.
@@ -198,7 +198,6 @@ private:
     std::shared_ptr<openrl::PixelPackBuffer> m_resultPixels = nullptr;
     std::shared_ptr<EnvironmentLight> m_environmentLight = nullptr;
 
-    PassCompleteCallback m_passCompleteCallback;
     unsigned int m_currentSampleIndex = 0;
 
     RenderOptions m_renderOptions;

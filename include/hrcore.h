@@ -341,6 +341,13 @@ typedef struct hr_kernel_times {
     uint32_t launches[HR_KERNEL_COUNT];
 } hr_kernel_times;
 
+/* Interactive 3x3 mode (perspective.rlsl:42-57): which pixel of a block is sampled in a sub-pass is looked up in a small table,
+ * the reference's interactiveBlockSamplesTexture (PassGenerator.cpp:267-294: the nx x ny list of (row, col) pairs, shuffled
+ * with std::random_device, uploaded as an RL_NEAREST / RL_REPEAT RGB texture).  coords_xy holds nx*ny integer pairs in the
+ * texture's memory order (texel (tx, ty) at index ty*nx + tx); the pair is what the shader reads as `.xy`.  NULL restores
+ * the unshuffled list (pair (ty, tx) at texel (tx, ty)), which is also the state of a new context.  nx*ny <= 16. */
+int hr_interactive_blocks_set(hr_ctx *ctx, const int32_t *coords_xy, int32_t nx, int32_t ny);
+
 /* replaces rlClear(RL_COLOR_BUFFER_BIT) (PassGenerator.cpp:439) */
 int hr_clear(hr_ctx *ctx);
 /* replaces rlRenderFrame() (PassGenerator.cpp:386): one sample per owned pixel.

@@ -208,6 +208,18 @@ int ora_lights_set(hr_ctx *ctx, const hr_lights *l)
     return HR_OK;
 }
 
+int ora_interactive_blocks_set(hr_ctx *ctx, const int32_t *coords, int32_t nx, int32_t ny)
+{
+    if (!coords) {
+        ctx->c.blockNx = ctx->c.blockNy = 0;
+        return HR_OK;
+    }
+    if (nx <= 0 || ny <= 0 || nx * ny > 16) ORA_FAIL(ctx, HR_ERR_INVALID, "block table: nx*ny must be 1..16");
+    ctx->c.blockNx = nx, ctx->c.blockNy = ny;
+    std::memcpy(ctx->c.blockCoords, coords, sizeof(int32_t) * 2 * (size_t)(nx * ny));
+    return HR_OK;
+}
+
 int ora_sequences_set(hr_ctx *ctx, const float *seq, const float *ap, int32_t nSeq, int32_t len)
 {
     if (!seq || !ap || nSeq <= 0 || len <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "bad sequence table");

@@ -96,6 +96,7 @@ struct Context {
     int nSeq = 0, seqLen = 0;
     std::vector<vec2> seq, aperture;
     std::vector<vec2> seqOffsets;
+    int blockNx = 0, blockNy = 0, blockCoords[32] = {0}; // interactive-mode block table (0: the unshuffled list)
     // committed scene
     bool committed = false;
     std::vector<Tri> tris;       // submission order (prim id)

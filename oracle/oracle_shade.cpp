@@ -851,9 +851,8 @@ struct Shader {
     {
         const float W = (float)ctx.W, H = (float)ctx.H;
         const float fcx = (float)x + 0.5f, fcy = (float)y + 0.5f;
-        if (pp.interactive_mode != 0) { // :42-57 — the 3x3 block texture is shuffled with std::random_device in
-            // the reference (PassGenerator.cpp:276-278); this build defines the identity
-            // layout texel(i,j) = (i,j), sampled with RL_NEAREST/RL_REPEAT.
+        if (pp.interactive_mode != 0) { // :42-57 — the 3x3 block texture (RL_NEAREST / RL_REPEAT); the reference shuffles its
+            // texels with std::random_device (PassGenerator.cpp:276-278): the table is an input here, unshuffled by default.
             const int bsx = pp.block_size[0], bsy = pp.block_size[1];
             const int bix = (int)(fcx - 0.5f) / bsx, biy = (int)(fcy - 0.5f) / bsy;
             float randX = random((float)bix, (float)biy);
@@ -863,6 +862,8 @@ struct Shader {
             int tx = (int)floorf(su * (float)bsx) % bsx, ty = (int)floorf(sv * (float)bsy) % bsy;
             // texel (tx,ty) of the row-major coords list holds vec3(row=ty... ) : identity layout -> (ty, tx)
             int sampleX = ty, sampleY = tx;
+            // PassGenerator.cpp:267-294: the list may be shuffled; the host supplies it (ora_interactive_blocks_set)
+            if (ctx.blockNx == bsx && ctx.blockNy == bsy) sampleX = ctx.blockCoords[2 * (ty * bsx + tx)], sampleY = ctx.blockCoords[2 * (ty * bsx + tx) + 1];
             int thisX = (int)(fcx - 0.5f) % bsx, thisY = (int)(fcy - 0.5f) % bsy;
             if (thisX != sampleX || thisY != sampleY) return false;
         }

@@ -392,6 +392,24 @@ def test_interactive_block_mode(golden):
         imgs.append(eng.readback())
     assert_parity(imgs[0], imgs[1], "interactive")
     assert (imgs[0][..., 3] == 1.0).all()  # nine sub-passes sample every pixel of each 3x3 block once
+    # the reference shuffles the block table (PassGenerator.cpp:276-278): a host-supplied shuffled list on both engines
+    perm = np.random.default_rng(5).permutation(9)
+    coords = np.array([(i // 3, i % 3) for i in perm], dtype=np.int32).reshape(3, 3, 2)   # (row, col) pairs in texture order
+    shuffled = []
+    for eng in (core.create_engine(), oracle_lib.engine()):
+        sc.apply(eng, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        eng.set_interactive_blocks(coords)
+        eng.render_pass(sc.options.pass_params(0, current_block_pixel=(1, 2)))
+        first = eng.readback()
+        for by in range(3):
+            for bx in range(3):
+                if (bx, by) != (1, 2):
+                    eng.render_pass(sc.options.pass_params(0, current_block_pixel=(bx, by)))
+        shuffled.append((first, eng.readback()))
+    assert_parity(shuffled[0][0], shuffled[1][0], "interactive, shuffled table, one sub-pass")
+    assert_parity(shuffled[0][1], shuffled[1][1], "interactive, shuffled table")
+    assert (shuffled[0][1][..., 3] == 1.0).all()          # a permutation still covers every pixel exactly once
+    assert shuffled[0][0].tobytes() != imgs[0].tobytes()
 
 
 def test_tile_shards_equal_full_frame(golden):

@@ -81,3 +81,16 @@ def test_polygon_aperture_is_uniform_on_the_polygon():
         assert abs(inner - (np.pi * 0.25) / area) < 5e-3
     same = host.polygon_aperture(np.full((4, 2), 0.25, np.float32), 5)
     assert (same == same[0]).all()                                             # deterministic
+
+
+@pytest.mark.parametrize("san,env", [("tsan", {"TSAN_OPTIONS": "halt_on_error=1"}),
+                                     ("asan", {"ASAN_OPTIONS": "detect_leaks=1", "UBSAN_OPTIONS": "halt_on_error=1"})])
+def test_layer_threading_under_sanitizers(san, env):
+    # the layer's job queue, callbacks and the pixel hand-off, on the CPU under ThreadSanitizer and
+    # AddressSanitizer + UBSan, against the do-nothing C-ABI stub (tests/host/hrcore_stub.cpp; GPU sanitizers are not available)
+    subprocess.check_call(["make", "-C", HOST, san], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "tests", "host", f"host_threading_{san}")
+    out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-4000:])
+    assert "threading checks: ok" in out.stdout
+    assert "WARNING: ThreadSanitizer" not in out.stderr and "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr

@@ -135,3 +135,32 @@ def test_stats_and_ray_budget():
     # upper bound of SURVEY §8a: W*H*2*(depth+1) rays per pass
     assert st.rays_closest + st.rays_any <= 32 * 32 * 2 * 2 * (4 + 1)
     assert (img[..., 3] == 2.0).all()
+
+
+def test_interactive_block_table_is_an_input():
+    # perspective.rlsl:42-57 + PassGenerator.cpp:267-294: nine sub-passes of the 3x3 interactive mode sample every pixel exactly
+    # once, for the unshuffled block list and for any permutation of it the host uploads
+    sc = scenes.cornell_box(33, 21, bounces=1)
+    sc.options.enable_interactive_mode = True
+    def nine(eng):
+        for by in range(3):
+            for bx in range(3):
+                eng.render_pass(sc.options.pass_params(0, current_block_pixel=(bx, by)))
+        return eng.readback()
+    a = oracle_lib.engine()
+    sc.apply(a)
+    plain = nine(a)
+    assert (plain[..., 3] == 1.0).all()
+    b = oracle_lib.engine()
+    sc.apply(b)
+    perm = np.random.default_rng(1).permutation(9)
+    b.set_interactive_blocks(np.array([(i // 3, i % 3) for i in perm], dtype=np.int32).reshape(3, 3, 2))
+    b.render_pass(sc.options.pass_params(0, current_block_pixel=(0, 0)))
+    one = b.readback()
+    assert 0 < (one[..., 3] == 1.0).sum() < one[..., 3].size // 4      # one pixel of every block
+    b.clear()
+    shuffled = nine(b)
+    assert (shuffled[..., 3] == 1.0).all()
+    b.set_interactive_blocks(None)
+    b.clear()
+    assert nine(b).tobytes() == plain.tobytes()
