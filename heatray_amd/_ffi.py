@@ -64,7 +64,7 @@ class MeshDesc(C.Structure):
 class SceneInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint64), ("n_nodes", C.c_uint64), ("aabb_min", C.c_float * 3),
                 ("aabb_max", C.c_float * 3), ("ray_epsilon", C.c_float), ("build_ms", C.c_float),
-                ("bvh_levels", C.c_uint32), ("reserved", C.c_uint32)]
+                ("bvh_levels", C.c_uint32), ("refitted", C.c_uint32)]
 
 
 class TextureDesc(C.Structure):
@@ -240,6 +240,27 @@ class Engine:
         d.world_from_entity = (C.c_float * 16)(*m.T.reshape(-1))
         d.front_face_cw, d.is_occluder, d.material_id = int(front_face_cw), int(is_occluder), material_id
         gid = C.c_int32()
+        self._call("geom_add", C.byref(d), C.byref(gid))
+        return gid.value
+
+    def add_mesh_strided(self, buf, pos_off, nrm_off, uv_off, stride_floats, indices, mode=HR_TRIANGLES, world=None, is_occluder=True,
+                         material_id=0):
+        """One interleaved float buffer (n, stride_floats) holding positions / normals / uvs at the given float offsets."""
+        buf = np.ascontiguousarray(buf, dtype=np.float32)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1)
+        d = MeshDesc()
+        base = buf.ctypes.data
+        d.positions = C.cast(base + 4 * pos_off, f32p)
+        d.normals = C.cast(base + 4 * nrm_off, f32p)
+        if uv_off is not None:
+            d.uvs = C.cast(base + 4 * uv_off, f32p)
+        d.position_stride = d.normal_stride = d.uv_stride = 4 * stride_floats
+        d.n_vertices = buf.shape[0]
+        d.indices, d.n_indices, d.mode = _ptr(idx, u32p), idx.size, mode
+        m = np.eye(4, dtype=np.float32) if world is None else _f32(world).reshape(4, 4)
+        d.world_from_entity = (C.c_float * 16)(*m.T.reshape(-1))
+        d.front_face_cw, d.is_occluder, d.material_id = int(np.linalg.det(m.astype(np.float64)) < 0), int(is_occluder), material_id
+        gid = C.c_int32(-1)
         self._call("geom_add", C.byref(d), C.byref(gid))
         return gid.value
 

@@ -30,11 +30,12 @@ HRD uint32_t orderedFromFloat(float f)
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-HRD v3 fetch3(const float *a, uint32_t i) { return v3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
+HRD v3 fetch3(const float *a, uint32_t i, int stride) { const float *p = a + (size_t)i * stride; return v3(p[0], p[1], p[2]); }
 
 // ------------------------------------------------------------------------------------- assemble
 __global__ __launch_bounds__(256) void k_assemble(const GeomDev *__restrict__ geoms, int nGeoms, uint32_t nTris, Tri *__restrict__ tris,
-                                                  TriAttr *__restrict__ attrs, TriAttrExt *__restrict__ ext, uint32_t *__restrict__ bounds)
+                                                  const uint32_t *__restrict__ slotOfPrim, TriAttr *__restrict__ attrs,
+                                                  TriAttrExt *__restrict__ ext, uint32_t *__restrict__ bounds)
 {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     v3 lo(__builtin_inff()), hi(-__builtin_inff());
@@ -62,22 +63,22 @@ __global__ __launch_bounds__(256) void k_assemble(const GeomDev *__restrict__ ge
         }
         const uint32_t id[3] = {i0, i1, i2};
         // vertex.rlsl:27 — rl_Position = worldFromEntity * vec4(position, 1)
-        const v3 p0 = xformPoint(g.world, fetch3(g.pos, i0)), p1 = xformPoint(g.world, fetch3(g.pos, i1)),
-                 p2 = xformPoint(g.world, fetch3(g.pos, i2));
+        const v3 p0 = xformPoint(g.world, fetch3(g.pos, i0, g.posStride)), p1 = xformPoint(g.world, fetch3(g.pos, i1, g.posStride)),
+                 p2 = xformPoint(g.world, fetch3(g.pos, i2, g.posStride));
         const v3 e1 = p1 - p0, e2 = p2 - p0;
         Tri tr;
         tr.p = make_float4(p0.x, p0.y, p0.z, e1.x);
         tr.q = make_float4(e1.y, e1.z, e2.x, e2.y);
         tr.r = make_float4(e2.z, __uint_as_float(t), __uint_as_float(g.flags), 0.0f);
-        tris[t] = tr;
+        tris[slotOfPrim ? slotOfPrim[t] : t] = tr;
         TriAttr at;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             // vertex.rlsl:28-29 — normal = mat3(worldFromEntity) * normalAttribute
-            const v3 n = xformVector(g.world, fetch3(g.nrm, id[k]));
+            const v3 n = xformVector(g.world, fetch3(g.nrm, id[k], g.nrmStride));
             at.n[3 * k] = n.x, at.n[3 * k + 1] = n.y, at.n[3 * k + 2] = n.z;
-            at.uv[2 * k] = g.uv ? g.uv[2 * id[k]] : 0.0f;
-            at.uv[2 * k + 1] = g.uv ? g.uv[2 * id[k] + 1] : 0.0f;
+            at.uv[2 * k] = g.uv ? g.uv[(size_t)id[k] * g.uvStride] : 0.0f;
+            at.uv[2 * k + 1] = g.uv ? g.uv[(size_t)id[k] * g.uvStride + 1] : 0.0f;
         }
         at.matflags = (g.material & kMatMask) | (g.flags << 24);
         attrs[t] = at;
@@ -87,10 +88,10 @@ __global__ __launch_bounds__(256) void k_assemble(const GeomDev *__restrict__ ge
             for (int k = 0; k < 3; ++k) {
                 v3 tn(0.0f), bt(0.0f), cl(0.0f);
                 if (g.tan && g.bit) { // vertex.rlsl:35-38
-                    tn = xformVector(g.world, fetch3(g.tan, id[k]));
-                    bt = xformVector(g.world, fetch3(g.bit, id[k]));
+                    tn = xformVector(g.world, fetch3(g.tan, id[k], g.tanStride));
+                    bt = xformVector(g.world, fetch3(g.bit, id[k], g.bitStride));
                 }
-                if (g.col) cl = fetch3(g.col, id[k]); // vertex.rlsl:40-42
+                if (g.col) cl = fetch3(g.col, id[k], g.colStride); // vertex.rlsl:40-42
                 e.tan[3 * k] = tn.x, e.tan[3 * k + 1] = tn.y, e.tan[3 * k + 2] = tn.z;
                 e.bit[3 * k] = bt.x, e.bit[3 * k + 1] = bt.y, e.bit[3 * k + 2] = bt.z;
                 e.col[3 * k] = cl.x, e.col[3 * k + 1] = cl.y, e.col[3 * k + 2] = cl.z;
@@ -103,22 +104,74 @@ __global__ __launch_bounds__(256) void k_assemble(const GeomDev *__restrict__ ge
         lo = min3(min3(p0, q1), q2);
         hi = max3(max3(p0, q1), q2);
     }
-    // wave reduction, then one atomic per wave and component
+    // wave reduction, then block reduction through LDS, then one atomic per workgroup and component into one of kBoundSlots copies
+    // of the bounds (same-address atomics serialise: one per wave into a single copy cost 0.9 ms for a million triangles)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         lo.x = fmin_(lo.x, __shfl_xor(lo.x, o)), lo.y = fmin_(lo.y, __shfl_xor(lo.y, o)), lo.z = fmin_(lo.z, __shfl_xor(lo.z, o));
         hi.x = fmax_(hi.x, __shfl_xor(hi.x, o)), hi.y = fmax_(hi.y, __shfl_xor(hi.y, o)), hi.z = fmax_(hi.z, __shfl_xor(hi.z, o));
     }
-    if ((threadIdx.x & 63) == 0 && lo.x <= hi.x) {
-        atomicMin(&bounds[0], orderedFromFloat(lo.x)), atomicMin(&bounds[1], orderedFromFloat(lo.y)), atomicMin(&bounds[2], orderedFromFloat(lo.z));
-        atomicMax(&bounds[3], orderedFromFloat(hi.x)), atomicMax(&bounds[4], orderedFromFloat(hi.y)), atomicMax(&bounds[5], orderedFromFloat(hi.z));
+    __shared__ float red[4][6];
+    if ((threadIdx.x & 63) == 0) {
+        float *r = red[threadIdx.x >> 6];
+        r[0] = lo.x, r[1] = lo.y, r[2] = lo.z, r[3] = hi.x, r[4] = hi.y, r[5] = hi.z;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = red[0][k];
+        for (int w = 1; w < 4; ++w) v = k < 3 ? fmin_(v, red[w][k]) : fmax_(v, red[w][k]);
+        uint32_t *slot = bounds + 6 * (blockIdx.x & (kBoundSlots - 1));
+        if (k < 3) {
+            if (v != __builtin_inff()) atomicMin(&slot[k], orderedFromFloat(v));
+        } else {
+            if (v != -__builtin_inff()) atomicMax(&slot[k], orderedFromFloat(v));
+        }
     }
 }
 
-void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t nTris, Tri *tris, TriAttr *attrs, TriAttrExt *ext, uint32_t *bounds)
+__global__ void k_bounds_init(uint32_t *bounds)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6 * kBoundSlots) bounds[i] = (i % 6) < 3 ? 0xFFFFFFFFu : 0u;
+}
+
+void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t nTris, Tri *tris, const uint32_t *slotOfPrim, TriAttr *attrs,
+                    TriAttrExt *ext, uint32_t *bounds)
 {
     if (nTris == 0) return;
-    hipLaunchKernelGGL(k_assemble, dim3((nTris + 255) / 256), dim3(256), 0, st, geoms, nGeoms, nTris, tris, attrs, ext, bounds);
+    hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(6 * kBoundSlots), 0, st, bounds);
+    hipLaunchKernelGGL(k_assemble, dim3((nTris + 255) / 256), dim3(256), 0, st, geoms, nGeoms, nTris, tris, slotOfPrim, attrs, ext, bounds);
+}
+
+HRD float floatFromOrderedDev(uint32_t u)
+{
+    const uint32_t b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
+    return __uint_as_float(b);
+}
+__global__ void k_scene_consts(const uint32_t *__restrict__ bounds, SceneConsts *__restrict__ out, SceneDev *__restrict__ scene)
+{
+    SceneConsts c;
+    for (int k = 0; k < 3; ++k) {
+        uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+        for (int sl = 0; sl < kBoundSlots; ++sl) {
+            const uint32_t a = bounds[6 * sl + k], b = bounds[6 * sl + 3 + k];
+            lo = a < lo ? a : lo, hi = b > hi ? b : hi;
+        }
+        c.lo[k] = floatFromOrderedDev(lo), c.hi[k] = floatFromOrderedDev(hi);
+    }
+    // |hi - lo| with the contract's operation order: sqrt((x*x + y*y) + z*z), correctly rounded like the host's sqrtf
+    const float ex = c.hi[0] - c.lo[0], ey = c.hi[1] - c.lo[1], ez = c.hi[2] - c.lo[2];
+    c.diag = sqrt_(ex * ex + ey * ey + ez * ez);
+    c.pad = 1e-5f * c.diag;
+    c.eps = 1e-4f * c.diag;
+    c.areaSum = 0.0f, c.pad0 = c.pad1 = 0u;
+    *out = c;
+    if (scene) scene->rayEps = c.eps;
+}
+void launchSceneConsts(hipStream_t st, const uint32_t *bounds, SceneConsts *out, SceneDev *scene)
+{
+    hipLaunchKernelGGL(k_scene_consts, dim3(1), dim3(1), 0, st, bounds, out, scene);
 }
 
 // --------------------------------------------------------------------------------------- morton
@@ -137,9 +190,6 @@ HRD uint32_t quantize10(float c, float lo, float ext)
     q = fmin_(fmax_(q, 0.0f), 1023.0f);
     return (uint32_t)q;
 }
-struct Box6 {
-    float lo[3], hi[3];
-};
 HRD void triBounds(const Tri &t, v3 &bl, v3 &bh)
 {
     const v3 v0(t.p.x, t.p.y, t.p.z), e1(t.p.w, t.q.x, t.q.y), e2(t.q.z, t.q.w, t.r.x);
@@ -345,10 +395,44 @@ HRD uint32_t quantExponent(float ext)
     return e < 1u ? 1u : (e > 254u ? 254u : e);
 }
 
+// Quantise the child boxes of a node against the node's own box (origin + q * 2^e, 8 bits per plane, lo rounded down, hi rounded
+// up) and pack the 64-byte record (hr_types.h).  Shared by the collapse and by the refit.
+HRD Node4 encodeNode4(const Box6 *cb, const Box6 &nb, int nValid, int nInner, uint32_t innerBase, int leafKey)
+{
+    uint32_t e[3];
+    float inv[3];
+    for (int k = 0; k < 3; ++k) {
+        e[k] = quantExponent(nb.hi[k] - nb.lo[k]);
+        inv[k] = 1.0f / __uint_as_float(e[k] << 23);
+    }
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int c = 0; c < 4; ++c) {
+        for (int k = 0; k < 3; ++k) {
+            uint32_t lo8 = 255u, hi8 = 0u; // no child: inverted box (the traversal also checks the child count)
+            if (c < nValid) {
+                const float fl = floor_((cb[c].lo[k] - nb.lo[k]) * inv[k]);
+                const float fh = __builtin_ceilf((cb[c].hi[k] - nb.lo[k]) * inv[k]);
+                lo8 = (uint32_t)fmin_(fmax_(fl, 0.0f), 255.0f);
+                hi8 = (uint32_t)fmin_(fmax_(fh, 0.0f), 255.0f);
+            }
+            qlo[k] |= lo8 << (8 * c);
+            qhi[k] |= hi8 << (8 * c);
+        }
+    }
+    Node4 nd;
+    nd.a = make_float4(nb.lo[0], nb.lo[1], nb.lo[2],
+                       __uint_as_float(e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)nInner << 24) | ((uint32_t)nValid << 27)));
+    nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+    nd.c = make_uint4(qhi[1], qhi[2], innerBase, (uint32_t)leafKey);
+    nd.d = make_uint4(0u, 0u, 0u, 0u);
+    return nd;
+}
+
 __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ knodes, const Box6 *__restrict__ leafBox,
                                                    const Box6 *__restrict__ nodeBox, int *__restrict__ binOf, uint32_t levelStart,
                                                    uint32_t levelEnd, uint32_t *__restrict__ counter, uint32_t *__restrict__ leafCounter,
-                                                   const Tri *__restrict__ sorted, Tri *__restrict__ finalTris, Node4 *__restrict__ out)
+                                                   const Tri *__restrict__ sorted, Tri *__restrict__ finalTris, Node4 *__restrict__ out,
+                                                   Box6 *__restrict__ nodeBoxOut)
 {
     const uint32_t i = levelStart + blockIdx.x * 256 + threadIdx.x;
     if (i >= levelEnd) return;
@@ -396,41 +480,94 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
         }
         for (int k = 0; k < 3; ++k) nb.lo[k] = fmin_(nb.lo[k], cb[c].lo[k]), nb.hi[k] = fmax_(nb.hi[k], cb[c].hi[k]);
     }
-    uint32_t e[3];
-    float inv[3];
-    for (int k = 0; k < 3; ++k) {
-        e[k] = quantExponent(nb.hi[k] - nb.lo[k]);
-        inv[k] = 1.0f / __uint_as_float(e[k] << 23);
-    }
-    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
-    for (int c = 0; c < 4; ++c) {
-        for (int k = 0; k < 3; ++k) {
-            uint32_t lo8 = 255u, hi8 = 0u; // no child: inverted box (the traversal also checks the child count)
-            if (c < nValid) {
-                const float fl = floor_((cb[c].lo[k] - nb.lo[k]) * inv[k]);
-                const float fh = __builtin_ceilf((cb[c].hi[k] - nb.lo[k]) * inv[k]);
-                lo8 = (uint32_t)fmin_(fmax_(fl, 0.0f), 255.0f);
-                hi8 = (uint32_t)fmin_(fmax_(fh, 0.0f), 255.0f);
-            }
-            qlo[k] |= lo8 << (8 * c);
-            qhi[k] |= hi8 << (8 * c);
-        }
-    }
     // child j >= nInner is triangle top - j with top = leafBase + nValid - 1: its reference ~(top - j) = ~top + j, so that a
     // child reference is `base + slot` for both kinds (base = innerBase or leafKey)
     const int leafKey = ~((int)leafBase + nValid - 1);
-    Node4 nd;
-    nd.a = make_float4(nb.lo[0], nb.lo[1], nb.lo[2],
-                       __uint_as_float(e[0] | (e[1] << 8) | (e[2] << 16) | ((uint32_t)nInner << 24) | ((uint32_t)nValid << 27)));
-    nd.b = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
-    nd.c = make_uint4(qhi[1], qhi[2], innerBase, (uint32_t)leafKey);
-    nd.d = make_uint4(0u, 0u, 0u, 0u);
-    out[i] = nd;
+    out[i] = encodeNode4(cb, nb, nValid, nInner, innerBase, leafKey);
+    nodeBoxOut[i] = nb;
+}
+
+// sum over the workgroup, then ONE float atomic (heuristic only: the order of the additions does not matter)
+HRD void blockAreaAdd(float area, SceneConsts *consts)
+{
+    __shared__ float part[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) area += __shfl_xor(area, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = area;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = (part[0] + part[1]) + (part[2] + part[3]);
+        if (t > 0.0f) atomicAdd(&consts->areaSum, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------- refit
+// One level of a bottom-up refit (levels are contiguous index ranges: nodes are allocated breadth-first).  A node's child
+// boxes come from its triangles (leaf children; padded like at build time) and from the boxes its inner children wrote in
+// the previous launch; its own box goes to nodeBox for the level above.  Same encoder as the build: conservative by construction.
+__global__ __launch_bounds__(256) void k_refit4(Node4 *__restrict__ nodes, Box6 *__restrict__ nodeBox, const Tri *__restrict__ tris,
+                                                uint32_t levelStart, uint32_t levelEnd, SceneConsts *__restrict__ consts)
+{
+    const uint32_t i = levelStart + blockIdx.x * 256 + threadIdx.x;
+    float area = 0.0f;
+    if (i < levelEnd) {
+        const float pad = consts->pad;
+        const Node4 nd = nodes[i];
+        const uint32_t meta = __float_as_uint(nd.a.w);
+        const int nInner = (int)((meta >> 24) & 7u), nValid = (int)(meta >> 27);
+        const uint32_t innerBase = nd.c.z;
+        const int leafKey = (int)nd.c.w;
+        Box6 cb[4];
+        Box6 nb;
+        for (int k = 0; k < 3; ++k) nb.lo[k] = __builtin_inff(), nb.hi[k] = -__builtin_inff();
+        for (int c = 0; c < nValid; ++c) {
+            if (c < nInner) {
+                cb[c] = nodeBox[innerBase + (uint32_t)c];
+            } else {
+                v3 bl, bh;
+                triBounds(tris[~(leafKey + c)], bl, bh);
+                cb[c].lo[0] = bl.x - pad, cb[c].lo[1] = bl.y - pad, cb[c].lo[2] = bl.z - pad;
+                cb[c].hi[0] = bh.x + pad, cb[c].hi[1] = bh.y + pad, cb[c].hi[2] = bh.z + pad;
+            }
+            for (int k = 0; k < 3; ++k) nb.lo[k] = fmin_(nb.lo[k], cb[c].lo[k]), nb.hi[k] = fmax_(nb.hi[k], cb[c].hi[k]);
+        }
+        nodes[i] = encodeNode4(cb, nb, nValid, nInner, innerBase, leafKey);
+        nodeBox[i] = nb;
+        area = boxArea(nb);
+    }
+    blockAreaAdd(area, consts); // tree-quality heuristic: sum of node areas
+}
+
+void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts)
+{
+    (void)nTris;
+    for (int level = tree.levels - 1; level >= 0; --level) {
+        const uint32_t a = tree.levelStart[level], b = tree.levelStart[level + 1];
+        if (b > a) hipLaunchKernelGGL(k_refit4, dim3((b - a + 255) / 256), dim3(256), 0, st, tree.nodes, tree.nodeBox, tree.tris, a, b, consts);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_slot_of_prim(const Tri *__restrict__ leafTris, uint32_t n, uint32_t *__restrict__ slotOfPrim)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) slotOfPrim[__float_as_uint(leafTris[i].r.y)] = i;
+}
+
+__global__ __launch_bounds__(256) void k_area_sum(const Box6 *__restrict__ nodeBox, uint32_t n, SceneConsts *__restrict__ consts)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    blockAreaAdd(i < n ? boxArea(nodeBox[i]) : 0.0f, consts);
+}
+void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts)
+{
+    if (n) hipLaunchKernelGGL(k_area_sum, dim3((n + 255) / 256), dim3(256), 0, st, nodeBox, n, consts);
 }
 
 int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, BuildResult *out)
 {
-    out->nodes = nullptr, out->tris = nullptr, out->nNodes = 0, out->rootLeafCount = 0, out->levels = 0;
+    out->nodes = nullptr, out->tris = nullptr, out->nodeBox = nullptr, out->slotOfPrim = nullptr;
+    out->nNodes = 0, out->rootLeafCount = 0, out->levels = 0;
+    for (uint32_t &v : out->levelStart) v = 0;
     if (n == 0) return 0;
     if (n >= (1u << 28)) return 2;
     const uint32_t nBlocks = (n + kSortTile - 1) / kSortTile;
@@ -489,6 +626,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)n));
         int *binOf = nullptr;
         HR_CHECK(hipMalloc(&out->nodes, sizeof(Node4) * (size_t)nMax));
+        HR_CHECK(hipMalloc(&out->nodeBox, sizeof(Box6) * (size_t)nMax));
         HR_CHECK(hipMalloc(&binOf, 4ull * nMax));
         const int rootBin = 0;
         const uint32_t init[2] = {1u, 0u};
@@ -498,7 +636,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         for (int level = 0; level < 64 && levelEnd > levelStart; ++level) {
             const uint32_t cnt = levelEnd - levelStart;
             hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, total,
-                               total + 1, sorted, finalTris, out->nodes);
+                               total + 1, sorted, finalTris, out->nodes, out->nodeBox);
             uint32_t newEnd = 0;
             HR_CHECK(hipMemcpyAsync(&newEnd, total, 4, hipMemcpyDeviceToHost, st));
             HR_CHECK(hipStreamSynchronize(st));
@@ -506,6 +644,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
                 rc = 4;
                 break;
             }
+            out->levelStart[level] = levelStart, out->levelStart[level + 1] = levelEnd;
             levelStart = levelEnd;
             levelEnd = newEnd;
             out->levels = level + 1;
@@ -519,6 +658,8 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         if (placed != n && rc == 0) rc = 5; // every triangle is the leaf of exactly one node
     }
     out->tris = finalTris ? finalTris : sorted;
+    HR_CHECK(hipMalloc(&out->slotOfPrim, 4ull * n));
+    hipLaunchKernelGGL(k_slot_of_prim, dim3(g256), dim3(256), 0, st, out->tris, n, out->slotOfPrim);
     HR_CHECK(hipStreamSynchronize(st));
     hipFree(keysA), hipFree(keysB), hipFree(valsA), hipFree(valsB), hipFree(blockHist), hipFree(leafBox), hipFree(total);
     if (knodes) hipFree(knodes);

@@ -18,20 +18,26 @@ using namespace hr;
 namespace {
 
 struct Texture {
-    float *dpx = nullptr;
+    void *dpx = nullptr;
     TexDesc desc{};
     bool alive = false;
 };
 
+// One submesh.  Its vertex attributes and indices live in ONE device block, uploaded when the mesh is added (straight from the
+// caller's planar buffers through a pinned staging ring, with the caller's strides: nothing is de-interleaved or kept on the host).
 struct Geom {
     bool alive = false;
     int nVerts = 0;
-    std::vector<float> pos, nrm, uv, tan, bit, col;
-    std::vector<uint32_t> idx;
+    uint32_t nIdx = 0;
     int mode = HR_TRIANGLES;
     float world[16];
     int frontFaceCW = 0, isOccluder = 1, material = 0;
-    uint32_t nTris() const { return mode == HR_TRIANGLE_STRIP ? (idx.size() >= 3 ? (uint32_t)idx.size() - 2 : 0u) : (uint32_t)(idx.size() / 3); }
+    char *dBlock = nullptr;
+    size_t blockBytes = 0;
+    size_t off[7] = {0, 0, 0, 0, 0, 0, 0}; // byte offsets of pos, nrm, uv, tan, bit, col, idx in the block
+    bool has[6] = {false, false, false, false, false, false};
+    int stride[6] = {3, 3, 2, 3, 3, 3};     // floats between consecutive vertices
+    uint32_t nTris() const { return mode == HR_TRIANGLE_STRIP ? (nIdx >= 3 ? nIdx - 2 : 0u) : nIdx / 3; }
 };
 
 } // namespace
@@ -140,18 +146,30 @@ struct hr_ctx {
     hr_lights lights{};
     int32_t blockNx = 0, blockNy = 0, blockCoords[32] = {0};
     bool committed = false, sceneDirty = true, hasPassthrough = false;
-    // Entity-space vertex data of the live geometries stays resident between commits: a commit after transform-only edits
-    // (Scene::applyTransform while the user drags a slider) re-runs assemble + LBVH without staging or re-uploading it.
-    struct GeomOff {
-        size_t pos, nrm, uv, tan, bit, col, idx;
-    };
-    std::vector<GeomOff> geomOffs;
-    float *dGeomF = nullptr;
-    uint32_t *dGeomI = nullptr;
-    bool geomCacheValid = false;
+    // What changed since the last commit decides what a commit does: a change of the set of geometries rebuilds the tree, a
+    // change of transforms only (Scene::applyTransform while the user drags a slider) REFITS it — same topology, every box
+    // recomputed bottom-up on the device, no allocation, one synchronisation at the end.
+    bool topologyDirty = true, transformDirty = false;
+    int tuneRefit = 1;        // HR_TUNE="refit=0": always rebuild
+    // persistent device arrays of the committed scene (grow-only capacities, reused across commits)
+    GeomDev *dG = nullptr;
+    size_t dGCap = 0;
+    Tri *trisPrim = nullptr;  // prim-order triangles (input of a full build)
+    size_t trisPrimCap = 0;
+    size_t attrsCap = 0, attrsExtCap = 0;
+    BuildResult tree{};       // nodes, leaf-order triangles, node boxes, prim -> slot map, level ranges
+    uint32_t treeTris = 0;
+    SceneConsts *dConsts = nullptr;
+    SceneConsts *hConsts = nullptr; // pinned
+    float builtAreaPerDiag2 = 0.0f; // areaSum / diag^2 right after the last full build (refit quality reference)
+    // pinned staging ring for mesh uploads
+    char *stage[2] = {nullptr, nullptr};
+    hipEvent_t stageEv[2] = {nullptr, nullptr};
+    bool stageBusy[2] = {false, false};
+    int stageTurn = 0;
     hr_scene_info info{};
 
-    // scene (device)
+    // scene (device); nodes / tris alias tree.nodes / tree.tris
     Node4 *nodes = nullptr;
     Tri *tris = nullptr;
     TriAttr *attrs = nullptr;
@@ -314,10 +332,28 @@ static void freeQueues(hr_ctx *c)
     c->queueCapacity = 0;
 }
 
+static void freeTree(hr_ctx *c)
+{
+    hipFree(c->tree.nodes), hipFree(c->tree.tris), hipFree(c->tree.nodeBox), hipFree(c->tree.slotOfPrim);
+    c->tree = BuildResult{};
+    c->nodes = nullptr, c->tris = nullptr, c->treeTris = 0;
+}
 static void freeSceneDevice(hr_ctx *c)
 {
-    hipFree(c->nodes), hipFree(c->tris), hipFree(c->attrs), hipFree(c->attrsExt);
-    c->nodes = nullptr, c->tris = nullptr, c->attrs = nullptr, c->attrsExt = nullptr;
+    freeTree(c);
+    hipFree(c->attrs), hipFree(c->attrsExt), hipFree(c->trisPrim), hipFree(c->dG);
+    c->attrs = nullptr, c->attrsExt = nullptr, c->trisPrim = nullptr, c->dG = nullptr;
+    c->attrsCap = c->attrsExtCap = c->trisPrimCap = c->dGCap = 0;
+}
+
+template <class T> static int ensureCap(hr_ctx *c, T **p, size_t *cap, size_t need)
+{
+    if (*cap >= need && *p) return HR_OK;
+    hipFree(*p);
+    *p = nullptr, *cap = 0;
+    HIP_TRY(c, hipMalloc((void **)p, sizeof(T) * (need ? need : 1)));
+    *cap = need;
+    return HR_OK;
 }
 
 extern "C" {
@@ -359,7 +395,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -386,7 +422,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         std::memset(G.statusOrder, 0, sizeof(G.statusOrder));
     }
     if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
-        hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, 64) != hipSuccess ||
+        hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, sizeof(uint32_t) * 6 * kBoundSlots) != hipSuccess ||
         hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters) * kMaxSlots) != hipSuccess) {
         delete c;
         return HR_ERR_DEVICE;
@@ -412,7 +448,13 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->fbInternal);
     if (c->pinned) hipHostFree(c->pinned);
     hipFree(c->dDisplay);
-    hipFree(c->dGeomF), hipFree(c->dGeomI);
+    for (Geom &g : c->geoms) hipFree(g.dBlock);
+    for (int k = 0; k < 2; ++k) {
+        if (c->stage[k]) hipHostFree(c->stage[k]);
+        if (c->stageEv[k]) hipEventDestroy(c->stageEv[k]);
+    }
+    hipFree(c->dConsts);
+    if (c->hConsts) hipHostFree(c->hConsts);
     if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
     hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dCounters);
@@ -643,13 +685,27 @@ int hr_frame_device_ptr(hr_ctx *c, void **deviceRgba)
 }
 
 // --------------------------------------------------------------------------------------- geometry
-static void copyAttr(std::vector<float> &dst, const float *src, int stride, int comps, int n)
+static const size_t kStageBytes = (size_t)16 << 20;
+
+// host bytes -> device through the pinned ring: while the DMA of one half runs, the CPU fills the other
+static int stagedUpload(hr_ctx *c, char *dst, const char *src, size_t bytes)
 {
-    dst.clear();
-    if (!src) return;
-    if (stride == 0) stride = comps * (int)sizeof(float);
-    dst.resize((size_t)n * comps);
-    for (int i = 0; i < n; ++i) std::memcpy(&dst[(size_t)i * comps], (const char *)src + (size_t)i * stride, comps * sizeof(float));
+    for (int k = 0; k < 2; ++k) {
+        if (!c->stage[k]) {
+            HIP_TRY(c, hipHostMalloc((void **)&c->stage[k], kStageBytes, hipHostMallocDefault));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->stageEv[k], hipEventDisableTiming));
+        }
+    }
+    for (size_t at = 0; at < bytes; at += kStageBytes) {
+        const size_t len = bytes - at < kStageBytes ? bytes - at : kStageBytes;
+        const int k = c->stageTurn++ & 1;
+        if (c->stageBusy[k]) HIP_TRY(c, hipEventSynchronize(c->stageEv[k]));
+        std::memcpy(c->stage[k], src + at, len);
+        HIP_TRY(c, hipMemcpyAsync(dst + at, c->stage[k], len, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->stageEv[k], c->stream));
+        c->stageBusy[k] = true;
+    }
+    return HR_OK;
 }
 
 int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
@@ -658,23 +714,53 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     if (!d || !d->positions || !d->normals || !d->indices || d->n_vertices <= 0 || d->n_indices < 0)
         FAIL(c, HR_ERR_INVALID, "mesh needs positions, normals, indices");
     if (d->mode != HR_TRIANGLES && d->mode != HR_TRIANGLE_STRIP) FAIL(c, HR_ERR_INVALID, "unsupported draw mode");
-    for (int i = 0; i < d->n_indices; ++i)
-        if (d->indices[i] >= (uint32_t)d->n_vertices) FAIL(c, HR_ERR_INVALID, "index out of range");
+    {
+        uint32_t worst = 0; // (a plain max reduction: vectorises)
+        for (int i = 0; i < d->n_indices; ++i) worst = d->indices[i] > worst ? d->indices[i] : worst;
+        if (d->n_indices > 0 && worst >= (uint32_t)d->n_vertices) FAIL(c, HR_ERR_INVALID, "index out of range");
+    }
+    const float *src[6] = {d->positions, d->normals, d->uvs, d->tangents, d->bitangents, d->colors};
+    const int32_t strideB[6] = {d->position_stride, d->normal_stride, d->uv_stride, d->tangent_stride, d->bitangent_stride, d->color_stride};
+    const int comps[6] = {3, 3, 2, 3, 3, 3};
     Geom g;
     g.alive = true;
     g.nVerts = d->n_vertices;
-    copyAttr(g.pos, d->positions, d->position_stride, 3, d->n_vertices);
-    copyAttr(g.nrm, d->normals, d->normal_stride, 3, d->n_vertices);
-    copyAttr(g.uv, d->uvs, d->uv_stride, 2, d->n_vertices);
-    copyAttr(g.tan, d->tangents, d->tangent_stride, 3, d->n_vertices);
-    copyAttr(g.bit, d->bitangents, d->bitangent_stride, 3, d->n_vertices);
-    copyAttr(g.col, d->colors, d->color_stride, 3, d->n_vertices);
-    g.idx.assign(d->indices, d->indices + d->n_indices);
+    g.nIdx = (uint32_t)d->n_indices;
     g.mode = d->mode;
     std::memcpy(g.world, d->world_from_entity, sizeof(g.world));
     g.frontFaceCW = d->front_face_cw, g.isOccluder = d->is_occluder, g.material = d->material_id;
-    c->geoms.push_back(std::move(g));
-    c->committed = false, c->geomCacheValid = false;
+    // layout of the device block: every attribute as the caller holds it (its stride included), then the indices
+    size_t bytesOf[6] = {0, 0, 0, 0, 0, 0}, total = 0;
+    std::vector<float> tight[6]; // only for strides that are not a multiple of four bytes (re-packed on the host)
+    for (int a = 0; a < 6; ++a) {
+        if (!src[a]) continue;
+        g.has[a] = true;
+        int sb = strideB[a] == 0 ? comps[a] * (int)sizeof(float) : strideB[a];
+        if (sb < comps[a] * (int)sizeof(float) && sb != 0) FAIL(c, HR_ERR_INVALID, "attribute stride smaller than the attribute");
+        if (sb % 4 != 0) {
+            tight[a].resize((size_t)g.nVerts * comps[a]);
+            for (int i = 0; i < g.nVerts; ++i) std::memcpy(&tight[a][(size_t)i * comps[a]], (const char *)src[a] + (size_t)i * sb, comps[a] * sizeof(float));
+            sb = comps[a] * (int)sizeof(float);
+        }
+        g.stride[a] = sb / 4;
+        bytesOf[a] = (size_t)(g.nVerts - 1) * sb + comps[a] * sizeof(float);
+        g.off[a] = total;
+        total += (bytesOf[a] + 15) & ~(size_t)15;
+    }
+    g.off[6] = total;
+    total += ((size_t)g.nIdx * 4 + 15) & ~(size_t)15;
+    g.blockBytes = total;
+    HIP_TRY(c, hipMalloc((void **)&g.dBlock, total ? total : 16));
+    int rc = HR_OK;
+    for (int a = 0; a < 6 && rc == HR_OK; ++a)
+        if (g.has[a]) rc = stagedUpload(c, g.dBlock + g.off[a], tight[a].empty() ? (const char *)src[a] : (const char *)tight[a].data(), bytesOf[a]);
+    if (rc == HR_OK && g.nIdx) rc = stagedUpload(c, g.dBlock + g.off[6], (const char *)d->indices, (size_t)g.nIdx * 4);
+    if (rc != HR_OK) {
+        hipFree(g.dBlock);
+        return rc;
+    }
+    c->geoms.push_back(g);
+    c->committed = false, c->topologyDirty = true;
     if (out) *out = (hr_geom_id)c->geoms.size() - 1;
     return HR_OK;
 }
@@ -683,8 +769,10 @@ int hr_geom_remove(hr_ctx *c, hr_geom_id id)
 {
     ENTER(c);
     if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive) FAIL(c, HR_ERR_INVALID, "bad geom id");
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); // an upload of this mesh may still be in flight
+    hipFree(c->geoms[id].dBlock);
     c->geoms[id] = Geom();
-    c->committed = false, c->geomCacheValid = false;
+    c->committed = false, c->topologyDirty = true;
     return HR_OK;
 }
 
@@ -693,40 +781,31 @@ int hr_geom_set_transform(hr_ctx *c, hr_geom_id id, const float m[16])
     ENTER(c);
     if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive || !m) FAIL(c, HR_ERR_INVALID, "bad geom id");
     std::memcpy(c->geoms[id].world, m, 16 * sizeof(float));
-    c->committed = false;
+    c->committed = false, c->transformDirty = true;
     return HR_OK;
 }
 
 int hr_scene_clear(hr_ctx *c)
 {
     ENTER(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (Geom &g : c->geoms) hipFree(g.dBlock);
     c->geoms.clear();
-    c->committed = false, c->geomCacheValid = false;
+    c->committed = false, c->topologyDirty = true;
     return HR_OK;
-}
-
-static inline float floatFromOrdered(uint32_t u)
-{
-    uint32_t b = (u & 0x80000000u) ? (u ^ 0x80000000u) : ~u;
-    float f;
-    std::memcpy(&f, &b, 4);
-    return f;
 }
 
 // Device temporaries and timing events of one commit: released on every exit path.
 namespace {
 struct CommitScratch {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    GeomDev *dG = nullptr;
-    Tri *trisPrim = nullptr;
     BuildResult br{};
     bool keepBuild = false;
     ~CommitScratch()
     {
         if (e0) hipEventDestroy(e0);
         if (e1) hipEventDestroy(e1);
-        hipFree(dG), hipFree(trisPrim);
-        if (!keepBuild) hipFree(br.nodes), hipFree(br.tris);
+        if (!keepBuild) hipFree(br.nodes), hipFree(br.tris), hipFree(br.nodeBox), hipFree(br.slotOfPrim);
     }
 };
 } // namespace
@@ -735,113 +814,102 @@ int hr_scene_commit(hr_ctx *c)
 {
     ENTER(c);
     QUIESCE(c);
-    // until this call succeeds there is no scene to render: a failed re-commit must not leave `committed` set over freed arrays
+    // until this call succeeds there is no scene to render: a failed re-commit must not leave `committed` set over stale arrays
     c->committed = false, c->sceneDirty = true;
     CommitScratch cs;
     HIP_TRY(c, hipEventCreate(&cs.e0));
     HIP_TRY(c, hipEventCreate(&cs.e1));
     HIP_TRY(c, hipEventRecord(cs.e0, c->stream));
-    freeSceneDevice(c);
-    c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
-    c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0;
-    // ---- stage every live geometry into one device buffer (skipped when only transforms changed since the last commit)
+    if (!c->dConsts) {
+        HIP_TRY(c, hipMalloc(&c->dConsts, sizeof(SceneConsts)));
+        HIP_TRY(c, hipHostMalloc((void **)&c->hConsts, sizeof(SceneConsts), hipHostMallocDefault));
+    }
+    // ---- descriptors of the live geometries (their data is on the device already: hr_geom_add)
     std::vector<GeomDev> gd;
-    std::vector<float> stageF;
-    std::vector<uint32_t> stageI;
-    typedef hr_ctx::GeomOff Off;
-    const bool reuse = c->geomCacheValid;
-    std::vector<Off> offs;
     uint32_t nTris = 0;
     bool anyExt = false;
-    const size_t none = (size_t)-1;
-    auto push = [&](const std::vector<float> &v) {
-        if (v.empty()) return none;
-        size_t o = stageF.size();
-        stageF.insert(stageF.end(), v.begin(), v.end());
-        return o;
-    };
     for (const Geom &g : c->geoms) {
         if (!g.alive || g.nTris() == 0) continue;
         GeomDev d{};
-        if (!reuse) {
-            Off o;
-            o.pos = push(g.pos), o.nrm = push(g.nrm), o.uv = push(g.uv), o.tan = push(g.tan), o.bit = push(g.bit), o.col = push(g.col);
-            o.idx = stageI.size();
-            stageI.insert(stageI.end(), g.idx.begin(), g.idx.end());
-            offs.push_back(o);
-        }
+        const float *at[6];
+        for (int a = 0; a < 6; ++a) at[a] = g.has[a] ? reinterpret_cast<const float *>(g.dBlock + g.off[a]) : nullptr;
+        d.pos = at[0], d.nrm = at[1], d.uv = at[2], d.tan = at[3], d.bit = at[4], d.col = at[5];
+        d.posStride = g.stride[0], d.nrmStride = g.stride[1], d.uvStride = g.stride[2], d.tanStride = g.stride[3], d.bitStride = g.stride[4],
+        d.colStride = g.stride[5];
+        d.idx = reinterpret_cast<const uint32_t *>(g.dBlock + g.off[6]);
         d.triOffset = nTris, d.nTris = g.nTris(), d.strip = g.mode == HR_TRIANGLE_STRIP;
-        d.flags = (g.frontFaceCW ? TF_FRONT_CW : 0u) | (g.isOccluder ? 0u : TF_NON_OCCLUDER) | (!g.uv.empty() ? TF_HAS_UV : 0u) |
-                  ((!g.tan.empty() && !g.bit.empty()) ? TF_HAS_TANGENTS : 0u) | (!g.col.empty() ? TF_HAS_COLORS : 0u);
+        d.flags = (g.frontFaceCW ? TF_FRONT_CW : 0u) | (g.isOccluder ? 0u : TF_NON_OCCLUDER) | (g.has[2] ? TF_HAS_UV : 0u) |
+                  ((g.has[3] && g.has[4]) ? TF_HAS_TANGENTS : 0u) | (g.has[5] ? TF_HAS_COLORS : 0u);
         d.material = (uint32_t)g.material;
         std::memcpy(d.world, g.world, sizeof(d.world));
         if (d.flags & (TF_HAS_TANGENTS | TF_HAS_COLORS)) anyExt = true;
         nTris += d.nTris;
         gd.push_back(d);
     }
-    if (!reuse) {
-        hipFree(c->dGeomF), hipFree(c->dGeomI);
-        c->dGeomF = nullptr, c->dGeomI = nullptr;
-        c->geomCacheValid = false;
-        c->geomOffs = offs;
-    }
     std::memset(&c->info, 0, sizeof(c->info));
-    c->hScene.rayEps = 0.0f;
-    if (nTris > 0) {
-        if (!reuse) {
-            HIP_TRY(c, hipMalloc(&c->dGeomF, stageF.size() * sizeof(float)));
-            HIP_TRY(c, hipMalloc(&c->dGeomI, stageI.size() * sizeof(uint32_t)));
-            HIP_TRY(c, hipMemcpyAsync(c->dGeomF, stageF.data(), stageF.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->dGeomI, stageI.data(), stageI.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream)); // the staging vectors go out of scope with this call
-            c->geomCacheValid = true;
+    c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
+    c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0, c->hScene.rayEps = 0.0f;
+    if (nTris == 0) {
+        freeTree(c);
+    } else {
+        int rc = ensureCap(c, &c->dG, &c->dGCap, gd.size());
+        if (rc == HR_OK) rc = ensureCap(c, &c->attrs, &c->attrsCap, (size_t)nTris);
+        if (rc == HR_OK && anyExt) rc = ensureCap(c, &c->attrsExt, &c->attrsExtCap, (size_t)nTris);
+        if (rc != HR_OK) return rc;
+        TriAttrExt *ext = anyExt ? c->attrsExt : nullptr;
+        HIP_TRY(c, hipMemcpyAsync(c->dG, gd.data(), gd.size() * sizeof(GeomDev), hipMemcpyHostToDevice, c->stream));
+        // A commit after transform edits only keeps the tree's topology: triangles are re-assembled straight into their leaf
+        // slots and every level is refitted bottom-up.  No allocation, no host round trip before the last kernel.
+        bool refit = c->tuneRefit && !c->topologyDirty && c->tree.nodes && c->treeTris == nTris && c->tree.rootLeafCount == 0;
+        if (refit) {
+            launchAssemble(c->stream, c->dG, (int)gd.size(), nTris, c->tree.tris, c->tree.slotOfPrim, c->attrs, ext, c->dScratch);
+            launchSceneConsts(c->stream, c->dScratch, c->dConsts, nullptr);
+            refitLBVH(c->stream, c->tree, nTris, c->dConsts);
+            HIP_TRY(c, hipMemcpyAsync(c->hConsts, c->dConsts, sizeof(SceneConsts), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            // A refitted tree is only as good as its topology still fits the geometry: when the boxes have grown out of proportion
+            // (objects moved far apart; a rotation by 45 degrees alone inflates axis-aligned boxes 2-3 x), rebuild.  Translations and
+            // uniform scales of the whole scene keep the ratio at 1.
+            const SceneConsts &k = *c->hConsts;
+            const float now = k.diag > 0.0f ? k.areaSum / (k.diag * k.diag) : 0.0f;
+            if (c->builtAreaPerDiag2 > 0.0f && now > 4.0f * c->builtAreaPerDiag2) refit = false;
         }
-        float *dF = c->dGeomF;
-        uint32_t *dI = c->dGeomI;
-        HIP_TRY(c, hipMalloc(&cs.dG, gd.size() * sizeof(GeomDev)));
-        HIP_TRY(c, hipMalloc(&cs.trisPrim, sizeof(Tri) * (size_t)nTris));
-        HIP_TRY(c, hipMalloc(&c->attrs, sizeof(TriAttr) * (size_t)nTris));
-        if (anyExt) HIP_TRY(c, hipMalloc(&c->attrsExt, sizeof(TriAttrExt) * (size_t)nTris));
-        for (size_t i = 0; i < gd.size(); ++i) {
-            const Off &o = c->geomOffs[i];
-            gd[i].pos = dF + o.pos, gd[i].nrm = dF + o.nrm;
-            gd[i].uv = o.uv == none ? nullptr : dF + o.uv;
-            gd[i].tan = o.tan == none ? nullptr : dF + o.tan;
-            gd[i].bit = o.bit == none ? nullptr : dF + o.bit;
-            gd[i].col = o.col == none ? nullptr : dF + o.col;
-            gd[i].idx = dI + o.idx;
+        if (!refit) {
+            rc = ensureCap(c, &c->trisPrim, &c->trisPrimCap, (size_t)nTris);
+            if (rc != HR_OK) return rc;
+            launchAssemble(c->stream, c->dG, (int)gd.size(), nTris, c->trisPrim, nullptr, c->attrs, ext, c->dScratch);
+            launchSceneConsts(c->stream, c->dScratch, c->dConsts, nullptr);
+            HIP_TRY(c, hipMemcpyAsync(c->hConsts, c->dConsts, sizeof(SceneConsts), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const SceneConsts k = *c->hConsts;
+            const int brc = buildLBVH(c->stream, c->trisPrim, nTris, k.lo, k.hi, k.pad, &cs.br);
+            if (brc != 0) FAIL(c, HR_ERR_DEVICE, brc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
+            // the traversal stack holds at most 3 entries per level of inner nodes (hr_trace.h)
+            if (3 * cs.br.levels > kStackLDS + kStackOvf) FAIL(c, HR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+            freeTree(c);
+            c->tree = cs.br, cs.keepBuild = true;
+            c->treeTris = nTris;
+            launchAreaSum(c->stream, c->tree.nodeBox, (uint32_t)c->tree.nNodes, c->dConsts);
+            HIP_TRY(c, hipMemcpyAsync(c->hConsts, c->dConsts, sizeof(SceneConsts), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->builtAreaPerDiag2 = c->hConsts->diag > 0.0f ? c->hConsts->areaSum / (c->hConsts->diag * c->hConsts->diag) : 0.0f;
         }
-        HIP_TRY(c, hipMemcpyAsync(cs.dG, gd.data(), gd.size() * sizeof(GeomDev), hipMemcpyHostToDevice, c->stream));
-        const uint32_t initB[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-        HIP_TRY(c, hipMemcpyAsync(c->dScratch, initB, sizeof(initB), hipMemcpyHostToDevice, c->stream));
-        launchAssemble(c->stream, cs.dG, (int)gd.size(), nTris, cs.trisPrim, c->attrs, c->attrsExt, c->dScratch);
-        uint32_t ob[6];
-        HIP_TRY(c, hipMemcpyAsync(ob, c->dScratch, sizeof(ob), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        float lo[3], hi[3];
-        for (int k = 0; k < 3; ++k) lo[k] = floatFromOrdered(ob[k]), hi[k] = floatFromOrdered(ob[3 + k]);
-        // |hi - lo| with the contract's operation order: sqrt((x*x + y*y) + z*z)
-        const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-        const float diag = sqrtf(ex * ex + ey * ey + ez * ez);
-        const float pad = 1e-5f * diag;
-        const int rc = buildLBVH(c->stream, cs.trisPrim, nTris, lo, hi, pad, &cs.br);
-        if (rc != 0) FAIL(c, HR_ERR_DEVICE, rc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
-        // the traversal stack holds at most 3 entries per level of inner nodes (hr_trace.h)
-        if (3 * cs.br.levels > kStackLDS + kStackOvf) FAIL(c, HR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
-        cs.keepBuild = true;
-        c->nodes = cs.br.nodes, c->tris = cs.br.tris;
-        c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = c->attrsExt;
-        c->hScene.nTris = (int)nTris, c->hScene.nNodes = cs.br.nNodes, c->hScene.rootLeafCount = cs.br.rootLeafCount;
-        c->hScene.rayEps = 1e-4f * diag;
-        for (int k = 0; k < 3; ++k) c->info.aabb_min[k] = lo[k], c->info.aabb_max[k] = hi[k];
-        c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)cs.br.nNodes, c->info.ray_epsilon = c->hScene.rayEps;
-        c->info.bvh_levels = (uint32_t)cs.br.levels;
+        const SceneConsts &k = *c->hConsts;
+        c->nodes = c->tree.nodes, c->tris = c->tree.tris;
+        c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = ext;
+        c->hScene.nTris = (int)nTris, c->hScene.nNodes = c->tree.nNodes, c->hScene.rootLeafCount = c->tree.rootLeafCount;
+        c->hScene.rayEps = k.eps; // 1e-4 |diagonal|, SURVEY §8a a6
+        for (int q = 0; q < 3; ++q) c->info.aabb_min[q] = k.lo[q], c->info.aabb_max[q] = k.hi[q];
+        c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)c->tree.nNodes, c->info.ray_epsilon = k.eps;
+        c->info.bvh_levels = (uint32_t)c->tree.levels;
+        c->info.refitted = refit ? 1u : 0u;
     }
     HIP_TRY(c, hipEventRecord(cs.e1, c->stream));
     HIP_TRY(c, hipEventSynchronize(cs.e1));
     hipEventElapsedTime(&c->info.build_ms, cs.e0, cs.e1);
     c->committed = true;
     c->sceneDirty = true;
+    c->topologyDirty = false, c->transformDirty = false;
     return HR_OK;
 }
 
@@ -860,20 +928,14 @@ int hr_texture_create(hr_ctx *c, const hr_texture_desc *d, const void *pixels, h
     if (!d || !pixels || d->width <= 0 || d->height <= 0 || (d->channels != 1 && d->channels != 3 && d->channels != 4))
         FAIL(c, HR_ERR_INVALID, "bad texture descriptor");
     const size_t n = (size_t)d->width * d->height * d->channels;
-    std::vector<float> tmp;
-    const float *src = (const float *)pixels;
-    if (d->dtype == HR_TEX_U8) { // normalised: float(byte) / 255.0f
-        tmp.resize(n);
-        const uint8_t *p = (const uint8_t *)pixels;
-        for (size_t i = 0; i < n; ++i) tmp[i] = (float)p[i] / 255.0f;
-        src = tmp.data();
-    } else if (d->dtype != HR_TEX_F32) {
-        FAIL(c, HR_ERR_INVALID, "bad texture dtype");
-    }
+    if (d->dtype != HR_TEX_U8 && d->dtype != HR_TEX_F32) FAIL(c, HR_ERR_INVALID, "bad texture dtype");
+    // 8-bit data stays 8-bit in HBM (a quarter of the footprint and of the bytes per texel fetched; the sampler normalises
+    // float(byte) / 255.0f on fetch, the conversion the reference's loader would otherwise leave to the RL texture unit)
+    const size_t bytes = n * (d->dtype == HR_TEX_U8 ? 1 : sizeof(float));
     Texture t;
-    HIP_TRY(c, hipMalloc(&t.dpx, n * sizeof(float)));
-    HIP_TRY(c, hipMemcpy(t.dpx, src, n * sizeof(float), hipMemcpyHostToDevice));
-    t.desc = TexDesc{t.dpx, d->width, d->height, d->channels, d->wrap_s, d->wrap_t, d->filter};
+    HIP_TRY(c, hipMalloc(&t.dpx, bytes));
+    HIP_TRY(c, hipMemcpy(t.dpx, pixels, bytes, hipMemcpyHostToDevice));
+    t.desc = TexDesc{t.dpx, d->width, d->height, d->channels, d->wrap_s, d->wrap_t, d->filter, d->dtype, 0};
     t.alive = true;
     c->textures.push_back(t);
     c->sceneDirty = true;
@@ -1068,7 +1130,7 @@ int hr_multiscatter_lut_generate(hr_ctx *c, float *out, hr_tex_id *outTex)
     if (outTex) { // loadMultiscatterTexture: LINEAR + CLAMP_TO_EDGE sampler (TextureLoader.cpp:36-41)
         Texture t;
         t.dpx = lut;
-        t.desc = TexDesc{lut, 128, 128, 1, HR_WRAP_CLAMP_TO_EDGE, HR_WRAP_CLAMP_TO_EDGE, HR_FILTER_LINEAR};
+        t.desc = TexDesc{lut, 128, 128, 1, HR_WRAP_CLAMP_TO_EDGE, HR_WRAP_CLAMP_TO_EDGE, HR_FILTER_LINEAR, HR_TEX_F32, 0};
         t.alive = true;
         c->textures.push_back(t);
         c->sceneDirty = true;

@@ -81,9 +81,12 @@ void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const floa
 size_t hitRecordSize();
 
 // ---- hr_build.hip
-// Per-geometry descriptor for the assemble kernel; all pointers are device pointers.
+// Per-geometry descriptor for the assemble kernel; all pointers are device pointers.  Attributes are addressed with a stride
+// (in floats), exactly as the caller handed them over (rlVertexAttribBuffer's stride, Mesh.cpp:104-132): nothing is
+// de-interleaved on the host.
 struct GeomDev {
-    const float *pos, *nrm, *uv, *tan, *bit, *col; // tightly packed, may be null (uv..col)
+    const float *pos, *nrm, *uv, *tan, *bit, *col; // may be null (uv..col)
+    int32_t posStride, nrmStride, uvStride, tanStride, bitStride, colStride; // floats between consecutive vertices
     const uint32_t *idx;
     uint32_t triOffset; // first global triangle (prim id) of this geometry
     uint32_t nTris;
@@ -93,19 +96,43 @@ struct GeomDev {
     float world[16];
 };
 
-struct BuildResult {
-    Node4 *nodes;
-    Tri *tris;
-    int32_t nNodes, rootLeafCount;
-    int32_t levels; // levels of 4-wide inner nodes (the traversal stack holds at most 3 entries per level)
+static const int kBoundSlots = 64; // copies of the scene bounds the assemble kernel reduces into (6 ordered uints each)
+struct Box6 {
+    float lo[3], hi[3];
 };
 
-// scene bounds as float-ordered uints: lo.xyz, hi.xyz
-void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t nTris, Tri *trisPrimOrder, TriAttr *attrs, TriAttrExt *ext,
-                    uint32_t *boundsOrdered);
-// Full LBVH build from assembled triangles; allocates scratch internally; returns device arrays (hipMalloc).
+// Scene constants derived from the bounds on the device (so that a refit needs no host round trip before its kernels):
+// diag = |hi - lo| with the contract's operation order, pad = 1e-5 diag (leaf boxes), eps = 1e-4 diag (ray epsilon)
+struct SceneConsts {
+    float lo[3], hi[3];
+    float diag, pad, eps;
+    float areaSum; // sum of the node boxes' surface areas after the last build / refit (tree-quality heuristic only)
+    uint32_t pad0, pad1;
+};
+
+static const int kMaxLevels = 64;
+struct BuildResult {
+    Node4 *nodes;
+    Tri *tris;            // leaf order
+    Box6 *nodeBox;        // float box of every node (a refit passes child boxes upwards through it)
+    uint32_t *slotOfPrim; // prim id -> position in `tris`
+    int32_t nNodes, rootLeafCount;
+    int32_t levels; // levels of 4-wide inner nodes (the traversal stack holds at most 3 entries per level)
+    uint32_t levelStart[kMaxLevels + 1]; // nodes of level L are [levelStart[L], levelStart[L + 1]) (breadth-first allocation)
+};
+
+// scene bounds as float-ordered uints: lo.xyz, hi.xyz.  slotOfPrim != null: triangles go to their leaf slot (refit), else prim order.
+void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t nTris, Tri *tris, const uint32_t *slotOfPrim, TriAttr *attrs,
+                    TriAttrExt *ext, uint32_t *boundsOrdered);
+// bounds (ordered uints) -> SceneConsts, and the ray epsilon straight into the device scene block
+void launchSceneConsts(hipStream_t st, const uint32_t *boundsOrdered, SceneConsts *out, SceneDev *scene);
+// Full LBVH build from assembled triangles (prim order); allocates scratch internally; returns device arrays (hipMalloc).
 int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad,
               BuildResult *out);
+// Refit: the tree keeps its topology; every node's child boxes are recomputed bottom-up from the triangles in `tree.tris`
+// (already moved by launchAssemble) and re-quantised.  Level by level, no host synchronisation.
+void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts);
+void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts);
 
 void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, float2 *out);
 void launchMultiscatterLUT(hipStream_t st, const float2 *sobol4096, float *out128x128);

@@ -18,7 +18,15 @@ HRD int wrapIndex(int i, int n, int mode)
 
 HRD v4 texel(const TexDesc &t, int x, int y)
 {
-    const float *p = t.px + ((size_t)y * t.w + x) * t.c;
+    const size_t at = ((size_t)y * t.w + x) * t.c;
+    float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (t.dtype == HR_TEX_U8) { // openrl::Texture with RL_UNSIGNED_BYTE data: a quarter of the bytes of a float copy per texel fetched
+        const uint8_t *b = reinterpret_cast<const uint8_t *>(t.px) + at;
+        for (int k = 0; k < t.c; ++k) p[k] = (float)b[k] / 255.0f;
+    } else {
+        const float *f = reinterpret_cast<const float *>(t.px) + at;
+        for (int k = 0; k < t.c; ++k) p[k] = f[k];
+    }
     v4 r;
     if (t.c == 1) { // RL_LUMINANCE
         r.x = r.y = r.z = p[0];

@@ -48,9 +48,11 @@ static const uint32_t kMatMask = 0x00FFFFFFu;
 
 // ---- textures ---------------------------------------------------------------------------------
 struct TexDesc {
-    const float *px; // w*h*c floats, row 0 = bottom
+    const void *px; // w*h*c floats or bytes (dtype), row 0 = bottom
     int32_t w, h, c;
     int32_t wrapS, wrapT, filter;
+    int32_t dtype;  // HR_TEX_F32, or HR_TEX_U8: bytes stay bytes in HBM and are normalised on fetch as float(byte) / 255.0f
+    int32_t pad;
 };
 
 // ---- ray queues (structure of arrays, one float4 / int4 stream per field group) -----------------

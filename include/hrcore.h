@@ -132,7 +132,7 @@ typedef struct hr_scene_info {
     float ray_epsilon; /* self-intersection t_min, 1e-4 * |aabb diagonal| */
     float build_ms;
     uint32_t bvh_levels; /* levels of inner nodes of the acceleration structure (0 for the oracle's brute force / a leaf root) */
-    uint32_t reserved;
+    uint32_t refitted;   /* 1: the last commit kept the tree's topology and refitted its boxes (transform-only edits) */
 } hr_scene_info;
 int hr_scene_get_info(hr_ctx *ctx, hr_scene_info *out);
 

@@ -741,6 +741,118 @@ def test_scene_edit_sequences_keep_parity(golden):
     assert g.scene_info().n_triangles == o.scene_info().n_triangles
 
 
+def _random_transform(rng, scale_range=(0.7, 1.4), shift=0.6, angle=0.8):
+    ang = rng.uniform(-angle, angle, 3)
+    cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+    rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    m = np.eye(4)
+    m[:3, :3] = (rx @ ry @ rz) * rng.uniform(*scale_range)
+    m[:3, 3] = rng.uniform(-shift, shift, 3)
+    return m.astype(np.float32)
+
+
+def test_hundred_random_edit_steps_refit_and_rebuild(golden):
+    # a commit after transform-only edits REFITS the tree (same topology, boxes recomputed bottom-up on the
+    # device); adding / removing geometry, or a refit whose boxes have degenerated, rebuilds it.  The hit is defined by the
+    # triangle test alone, so every state must trace and render exactly like the oracle's freshly built scene.
+    rng = np.random.default_rng(2026)
+    sc = scenes.triangle_soup(6000, width=48, height=32, bounces=3, passes=8, env=True, n_materials=6)
+    g, o = core.create_engine(), oracle_lib.engine()
+    for eng in (g, o):
+        sc.apply(eng, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    n_geoms = len(sc.meshes)
+    live = list(range(n_geoms))
+    cur = {gid: np.eye(4, dtype=np.float32) for gid in live}   # worldFromEntity of every submesh, as Scene keeps it
+    def place(gid, m):
+        cur[gid] = m
+        g.set_transform(gid, m), o.set_transform(gid, m)
+    tri_n = np.tile(np.array([0, 0, 1], np.float32), (3, 1))
+    n_rays = 3000
+    refits = rebuilds = 0
+    for step in range(100):
+        kind = rng.choice(["one", "all", "far", "add", "remove"], p=[0.45, 0.3, 0.05, 0.1, 0.1])
+        expect_refit = True
+        if kind == "one":                                    # one submesh moves a little (a dragged object): its triangles share
+            gid = int(rng.choice(live))                      # leaves with the others', whose boxes grow; small motions stay refits
+            place(gid, (_random_transform(rng, scale_range=(0.99, 1.01), shift=0.01, angle=0.01) @ cur[gid]).astype(np.float32))
+            expect_refit = None
+        elif kind == "all":                                  # Scene::applyTransform: the whole scene, rigidly (Scene.cpp:38-49)
+            big = step % 3 == 0                              # a large rotation inflates every axis-aligned box: refit or rebuild
+            m = _random_transform(rng, scale_range=(0.5, 2.0), shift=2.0, angle=0.8 if big else 0.15)
+            for gid in live:                                 # transform * submesh.transform for every submesh
+                place(gid, (m @ cur[gid]).astype(np.float32))
+            expect_refit = None if big else True
+        elif kind == "far":                                  # one submesh flung far away: the refitted boxes degenerate -> rebuild
+            gid = int(rng.choice(live))
+            place(gid, _random_transform(rng, shift=40.0))
+            expect_refit = None
+        elif kind == "add":
+            p = rng.uniform(-0.8, 0.8, (3, 3)).astype(np.float32)
+            a, b = g.add_mesh(p, tri_n, [0, 1, 2], material_id=1), o.add_mesh(p, tri_n, [0, 1, 2], material_id=1)
+            assert a == b
+            live.append(a)
+            cur[a] = np.eye(4, dtype=np.float32)
+            expect_refit = False
+        else:
+            if len(live) > n_geoms:
+                gid = live.pop()
+                g.remove_mesh(gid), o.remove_mesh(gid)
+                expect_refit = False
+        g.commit(), o.commit()
+        gi, oi = g.scene_info(), o.scene_info()
+        assert gi.n_triangles == oi.n_triangles
+        assert list(gi.aabb_min) == list(oi.aabb_min) and list(gi.aabb_max) == list(oi.aabb_max) and gi.ray_epsilon == oi.ray_epsilon
+        if expect_refit is not None:
+            assert bool(gi.refitted) == expect_refit, (step, kind)
+        refits += int(gi.refitted)
+        rebuilds += int(not gi.refitted)
+        lo, hi = np.array(gi.aabb_min), np.array(gi.aabb_max)
+        org = rng.uniform(lo - 0.2, hi + 0.2, (n_rays, 3)).astype(np.float32)
+        tgt = rng.uniform(lo, hi, (n_rays, 3))
+        d = tgt - org
+        d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-20)).astype(np.float32)
+        hg, ho = g.debug_trace(org, d), o.debug_trace(org, d)
+        assert hg.tobytes() == ho.tobytes(), f"step {step} ({kind}): {(hg != ho).sum()} of {n_rays} hits differ"
+        if step % 10 == 9:                                   # and through the whole path
+            for eng in (g, o):
+                eng.clear()
+                for s_ in range(2):
+                    eng.render_pass(sc.options.pass_params(s_))
+            assert_parity(g.readback(), o.readback(), f"render after edit step {step} ({kind})")
+    assert refits >= 40 and rebuilds >= 5, (refits, rebuilds)
+
+
+def test_strided_and_interleaved_vertex_buffers(golden):
+    # rlVertexAttribBuffer takes a byte stride (Mesh.cpp:104-132): attributes interleaved in one buffer, and padded planar
+    # buffers, reach the device as they are and are read with their stride
+    sc = scenes.multi_material(64, 36, bounces=3, textured=True)
+    g, o = core.create_engine(), oracle_lib.engine()
+    sc.apply(o, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    plain = sc.meshes
+    inter = []
+    for me in plain:
+        n = me.positions.shape[0]
+        buf = np.zeros((n, 11), np.float32)                  # pos(3) pad(1) nrm(3) uv(2) pad(2)
+        buf[:, 0:3], buf[:, 4:7] = me.positions, me.normals
+        if me.uvs is not None:
+            buf[:, 7:9] = me.uvs
+        inter.append(buf)
+    sc.meshes = []
+    sc.apply(g, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    sc.meshes = plain
+    for me, buf in zip(plain, inter):
+        g.add_mesh_strided(buf, pos_off=0, nrm_off=4, uv_off=7 if me.uvs is not None else None, stride_floats=11, indices=me.indices,
+                           mode=me.mode, world=me.world, is_occluder=me.is_occluder, material_id=me.material_id)
+    g.commit()
+    for eng in (g, o):
+        eng.clear()
+        for s_ in range(2):
+            eng.render_pass(sc.options.pass_params(s_))
+    assert_parity(g.readback(), o.readback(), "interleaved vertex buffers")
+
+
 @pytest.mark.parametrize("tune,passes", [("batch=1", 24), ("", 288)])
 def test_progressive_readback_never_drains_and_holds_complete_passes(golden, monkeypatch, tune, passes):
     # hr_readback_progressive: whatever is in the buffer is a prefix of the passes, complete, bit-identical to the oracle's
