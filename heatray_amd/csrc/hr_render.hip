@@ -518,28 +518,33 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
         return lo;
     };
     for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock) {
-        // ---- regroup the workgroup's items: rays that hit something first, misses after them, so that the long material
-        // shaders run on full waves instead of on the ~46 % of lanes that hit (the results do not depend on who shades what)
-        bool hit0 = false;
+        // ---- regroup the workgroup's items by shader: PBR hits first, then glass hits, then everything else (misses), so that the
+        // long material shaders run on full, uniform waves instead of on the ~46 % of lanes that hit, split between two shaders
+        // (the results do not depend on who shades what)
+        int cls = 2;
         {
             const uint32_t i0 = base + threadIdx.x;
             if (i0 < total) {
                 const int s0 = findSeg(i0);
-                hit0 = tbl->seg[s0].hits[i0 - segStart[2 * s0]].prim != kMissPrim;
+                const uint32_t hp = tbl->seg[s0].hits[i0 - segStart[2 * s0]].prim;
+                if (hp != kMissPrim) {
+                    const uint32_t mid0 = S.attrs[hp & 0x7FFFFFFFu].matflags & kMatMask;
+                    cls = (mid0 < (uint32_t)S.nMaterials && S.materials[mid0].type == HR_MAT_GLASS) ? 1 : 0;
+                }
             }
         }
-        const unsigned long long hitMask = __ballot(hit0);
-        if (lane == 0) waveHits[wave] = (uint32_t)__popcll(hitMask);
+        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1);
+        if (lane == 0) waveHits[wave] = (uint32_t)__popcll(m0) | ((uint32_t)__popcll(m1) << 16);
         __syncthreads();
-        uint32_t hitsBefore = 0, hitsTotal = 0;
+        uint32_t before0 = 0, before1 = 0, total0 = 0, total1 = 0;
         for (uint32_t w = 0; w < (uint32_t)(kShadeBlock / 64); ++w) {
-            const uint32_t cnt = waveHits[w];
-            hitsBefore += (w < wave) ? cnt : 0u;
-            hitsTotal += cnt;
+            const uint32_t cnt = waveHits[w], c0 = cnt & 0xFFFFu, c1 = cnt >> 16;
+            before0 += (w < wave) ? c0 : 0u, before1 += (w < wave) ? c1 : 0u;
+            total0 += c0, total1 += c1;
         }
         {
-            const uint32_t rankHit = (uint32_t)__popcll(hitMask & ltMask), rankMiss = lane - rankHit;
-            const uint32_t pos = hit0 ? hitsBefore + rankHit : hitsTotal + (wave * 64u - hitsBefore) + rankMiss;
+            const uint32_t r0 = (uint32_t)__popcll(m0 & ltMask), r1 = (uint32_t)__popcll(m1 & ltMask), r2 = lane - r0 - r1;
+            const uint32_t pos = cls == 0 ? before0 + r0 : (cls == 1 ? total0 + before1 + r1 : total0 + total1 + (wave * 64u - before0 - before1) + r2);
             order[pos] = (uint16_t)threadIdx.x;
         }
         if (threadIdx.x == 0) {
