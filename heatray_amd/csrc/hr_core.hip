@@ -882,10 +882,11 @@ int hr_scene_commit(hr_ctx *c)
             HIP_TRY(c, hipMemcpyAsync(c->hConsts, c->dConsts, sizeof(SceneConsts), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             const SceneConsts k = *c->hConsts;
-            const int brc = buildLBVH(c->stream, c->trisPrim, nTris, k.lo, k.hi, k.pad, &cs.br);
+            const int brc = buildLBVH(c->stream, c->trisPrim, nTris, k.lo, k.hi, k.pad, c->dConsts, &cs.br);
             if (brc != 0) FAIL(c, HR_ERR_DEVICE, brc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
             // the traversal stack holds at most 3 entries per level of inner nodes (hr_trace.h)
             if (3 * cs.br.levels > kStackLDS + kStackOvf) FAIL(c, HR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+        if (cs.br.triSlots >= (1u << 28)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: triangle slots do not fit a 28-bit leaf reference");
             freeTree(c);
             c->tree = cs.br, cs.keepBuild = true;
             c->treeTris = nTris;
@@ -899,6 +900,7 @@ int hr_scene_commit(hr_ctx *c)
         c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = ext;
         c->hScene.nTris = (int)nTris, c->hScene.nNodes = c->tree.nNodes, c->hScene.rootLeafCount = c->tree.rootLeafCount;
         c->hScene.rayEps = k.eps; // 1e-4 |diagonal|, SURVEY §8a a6
+        for (int q = 0; q < 3; ++q) c->hScene.gridLo[q] = k.gridLo[q], c->hScene.gridCell[q] = k.gridCell[q], c->hScene.gridExpM7[q] = k.gridExpM7[q];
         for (int q = 0; q < 3; ++q) c->info.aabb_min[q] = k.lo[q], c->info.aabb_max[q] = k.hi[q];
         c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)c->tree.nNodes, c->info.ray_epsilon = k.eps;
         c->info.bvh_levels = (uint32_t)c->tree.levels;

@@ -108,6 +108,9 @@ struct SceneConsts {
     float diag, pad, eps;
     float areaSum; // sum of the node boxes' surface areas after the last build / refit (tree-quality heuristic only)
     uint32_t pad0, pad1;
+    float gridLo[3], gridCell[3]; // frame grid of the 32-byte nodes (hr_types.h)
+    int32_t gridExpM7[3];
+    uint32_t pad2;
 };
 
 static const int kMaxLevels = 64;
@@ -118,6 +121,7 @@ struct BuildResult {
     uint32_t *slotOfPrim; // prim id -> position in `tris`
     int32_t nNodes, rootLeafCount;
     int32_t levels; // levels of 4-wide inner nodes (the traversal stack holds at most 3 entries per level)
+    uint32_t triSlots;    // entries of `tris` (32-byte nodes: 4 per node, some unused)
     uint32_t levelStart[kMaxLevels + 1]; // nodes of level L are [levelStart[L], levelStart[L + 1]) (breadth-first allocation)
 };
 
@@ -128,7 +132,7 @@ void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t n
 void launchSceneConsts(hipStream_t st, const uint32_t *boundsOrdered, SceneConsts *out, SceneDev *scene);
 // Full LBVH build from assembled triangles (prim order); allocates scratch internally; returns device arrays (hipMalloc).
 int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad,
-              BuildResult *out);
+              const SceneConsts *deviceConsts, BuildResult *out);
 // Refit: the tree keeps its topology; every node's child boxes are recomputed bottom-up from the triangles in `tree.tris`
 // (already moved by launchAssemble) and re-quantised.  Level by level, no host synchronisation.
 void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts);

@@ -269,6 +269,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     best.prim = kMissPrim, best.t = 0, best.u = 0, best.v = 0;
     int ovf[kStackOvf];
     const float tmin = S.rayEps;
+#if HR_NODE32
+    const GridK gk = gridOf(S);
+#endif
     const int rootRef = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
 
     uint32_t poolLo = 0, poolHi = 0; // wave-uniform: indices this wave has reserved and not handed out yet
@@ -334,7 +337,10 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                     o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
                     tmax = a.w, tlim = a.w;
                     idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
-                    oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
+                    {
+                        const RayK f = rayFrame(S, o, idx, idy, idz);
+                        oix = f.oix, oiy = f.oiy, oiz = f.oiz;
+                    }
                     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
                     sp = 0;
                     pend = 0;
@@ -367,7 +373,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                 ++mySteps;
 #endif
                 const RayK rk{idx, idy, idz, oix, oiy, oiz};
+#if HR_NODE32
+                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, gk, tmin, tlim);
+#else
                 nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny);
+#endif
             }
             // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
             // postponed it is blocked until the wave runs the triangle phase

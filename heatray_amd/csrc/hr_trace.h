@@ -65,6 +65,85 @@ HRD void cswap(uint32_t &a, uint32_t &b)
     a = lo, b = hi;
 }
 
+#if HR_NODE32
+// Per-scene constants of the 32-byte node frames (wave-uniform: scalar registers)
+struct GridK {
+    float cellX, cellY, cellZ;
+    int32_t expX, expY, expZ; // biased exponent of cell * 2^-7
+};
+HRD GridK gridOf(const SceneDev &S) { return GridK{S.gridCell[0], S.gridCell[1], S.gridCell[2], S.gridExpM7[0], S.gridExpM7[1], S.gridExpM7[2]}; }
+// RayK for 32-byte nodes: oix/oiy/oiz hold (o - gridLo) / d (rayFrame below)
+
+HRD uint32_t q7(uint32_t x, int c) { return (x >> (7 * c)) & 127u; } // -> v_bfe_u32
+
+// One step at the 4-wide node `cur` (32-byte format, hr_types.h): TWO dwordx4 loads, slab test of the four 7-bit child boxes,
+// continue with the nearest child that is hit and push the others farthest first; pop when nothing is hit.
+HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, const GridK &gk, float tmin, float tlim)
+{
+    const Node4 &n = nodes[cur];
+    const uint4 P = n.p, Q = n.q;
+    const uint32_t nInner = (Q.y >> 28) & 7u;
+    const int innerBase = (int)(Q.w & 0x0FFFFFFFu), leafKey = ~(4 * cur + 3);
+    const uint32_t gx = Q.z & 0x3FFFu, gy = (Q.z >> 14) & 0x3FFFu;
+    const uint32_t gz = (P.x >> 28) | ((P.y >> 28) << 4) | ((P.z >> 28) << 8) | (((P.w >> 28) & 3u) << 12);
+    // t = (gridLo + g * cell + q * scale - o) / d = q * (scale / d) + (g * cell) / d - (o - gridLo) / d
+    const float bx = __uint_as_float((uint32_t)(gk.expX + (int32_t)(Q.z >> 28)) << 23) * rk.idx;
+    const float by = __uint_as_float((uint32_t)(gk.expY + (int32_t)(Q.w >> 28)) << 23) * rk.idy;
+    const float bz = __uint_as_float((uint32_t)(gk.expZ + (int32_t)(Q.x >> 28)) << 23) * rk.idz;
+    const float ax = __builtin_fmaf((float)gx * gk.cellX, rk.idx, -rk.oix), ay = __builtin_fmaf((float)gy * gk.cellY, rk.idy, -rk.oiy),
+                az = __builtin_fmaf((float)gz * gk.cellZ, rk.idz, -rk.oiz);
+    // the sign of the direction decides which plane dword is the entry and which the exit plane of each slab
+    const uint32_t nX = rk.idx < 0.0f ? P.w : P.x, fX = rk.idx < 0.0f ? P.x : P.w;
+    const uint32_t nY = rk.idy < 0.0f ? Q.x : P.y, fY = rk.idy < 0.0f ? P.y : Q.x;
+    const uint32_t nZ = rk.idz < 0.0f ? Q.y : P.z, fZ = rk.idz < 0.0f ? P.z : Q.y;
+    uint32_t key[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float tnx = __builtin_fmaf((float)q7(nX, c), bx, ax), tfx = __builtin_fmaf((float)q7(fX, c), bx, ax);
+        const float tny = __builtin_fmaf((float)q7(nY, c), by, ay), tfy = __builtin_fmaf((float)q7(fY, c), by, ay);
+        const float tnz = __builtin_fmaf((float)q7(nZ, c), bz, az), tfz = __builtin_fmaf((float)q7(fZ, c), bz, az);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
+        // entry distance (>= tmin >= 0, so its bits order like the value) with the child slot in the two low bits; a slot without
+        // a child holds an inverted box (entry plane beyond the exit plane on every axis): tn > tf
+        key[c] = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+    }
+    // sorting network: ascending entry distance, misses (0xFFFFFFFF) last
+    cswap(key[0], key[1]), cswap(key[2], key[3]), cswap(key[0], key[2]), cswap(key[1], key[3]), cswap(key[1], key[2]);
+    int ref[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int sl = (int)(key[j] & 3u);
+        ref[j] = (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl; // (a miss computes a value nobody uses)
+    }
+    if (sp <= kStackLDS - 3) {
+        // common case, branch-free: store the three farther children farthest first and advance the stack pointer only
+        // past the ones that were hit (hits are a prefix of the sorted order, so a skipped slot is simply overwritten)
+        stackLane[sp * 64] = ref[3];
+        sp += (key[3] != 0xFFFFFFFFu) ? 1 : 0;
+        stackLane[sp * 64] = ref[2];
+        sp += (key[2] != 0xFFFFFFFFu) ? 1 : 0;
+        stackLane[sp * 64] = ref[1];
+        sp += (key[1] != 0xFFFFFFFFu) ? 1 : 0;
+        const bool any = key[0] != 0xFFFFFFFFu;
+        const bool empty = !any && sp == 0;
+        sp -= (!any && sp > 0) ? 1 : 0;
+        const int popped = stackLane[(sp < kStackLDS - 1 ? sp : kStackLDS - 1) * 64]; // stays inside the LDS part (value unused when sp == kStackLDS)
+        cur = any ? ref[0] : (empty ? kSentinel : popped);
+    } else {
+        // deep stack: entries beyond kStackLDS live in the private overflow area
+#pragma unroll
+        for (int j = 3; j >= 1; --j)
+            if (key[j] != 0xFFFFFFFFu) HR_PUSH(ref[j]);
+        if (key[0] != 0xFFFFFFFFu) {
+            cur = ref[0];
+        } else {
+            HR_POP();
+        }
+    }
+}
+
+#else
 // One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that
 // is hit and push the others farthest first (so the nearer one pops first); pop when nothing is hit.
 HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim,
@@ -133,6 +212,19 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
     }
 }
 
+#endif
+
+// Per-ray constants of the slab test: 1 / d and the ray origin over d (relative to the frame grid's origin for 32-byte nodes)
+HRD RayK rayFrame(const SceneDev &S, v3 o, float idx, float idy, float idz)
+{
+#if HR_NODE32
+    return RayK{idx, idy, idz, (o.x - S.gridLo[0]) * idx, (o.y - S.gridLo[1]) * idy, (o.z - S.gridLo[2]) * idz};
+#else
+    (void)S;
+    return RayK{idx, idy, idz, o.x * idx, o.y * idy, o.z * idz};
+#endif
+}
+
 // Reciprocal for the slab test only (never for the hit): no infinities / NaNs enter the box test.
 HRD float safeInv(float d)
 {
@@ -176,15 +268,20 @@ HRD void traverse(const SceneDev &S, v3 o, v3 d, float tmin, float tmax, uint32_
     else
         cur = 0;
     const float idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
-    const float oix = o.x * idx, oiy = o.y * idy, oiz = o.z * idz;
     float tlim = tmax; // shrinks to the closest hit so far (closest-hit rays only)
-
-    const RayK rk{idx, idy, idz, oix, oiy, oiz};
+    const RayK rk = rayFrame(S, o, idx, idy, idz);
+#if HR_NODE32
+    const GridK gk = gridOf(S);
+#endif
     while (cur != kSentinel) {
         // ---- inner nodes: descend until this lane holds a leaf (cur < 0) or runs out of work
         while (cur >= 0 && cur != kSentinel) {
             if (STATS) ++nodeVisits;
+#if HR_NODE32
+            nodeStep4(S.nodes, cur, sp, stackLane, ovf, rk, gk, tmin, tlim);
+#else
             nodeStep4(S.nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
+#endif
         }
         // ---- leaf: 1..4 triangles
         if (cur < 0) {

@@ -7,6 +7,29 @@
 namespace hr {
 
 // ---- acceleration structure -------------------------------------------------------------------
+#ifndef HR_NODE32
+#define HR_NODE32 0 // the 64-byte node below is the default; 1 selects the 32-byte experiment (DESIGN.md §2 "32-byte nodes")
+#endif
+#if HR_NODE32
+// EXPERIMENT (kept buildable, parity-green, not the default): a 4-wide BVH node in 32 bytes = TWO dwordx4 loads instead of three.
+// A CU's texture addresser accepts per-lane loads at about one lane per cycle per instruction whatever the width
+// (tools/calib_tcp.hip), and k_trace keeps it 87 % busy, so fewer load instructions per node do unload it (-21 % TA busy cycles)
+// — but unpacking 7-bit planes and the grid frame costs 23 % more VALU instructions, which were at 73 % busy already: the kernel
+// becomes VALU-bound and ends 1.5 % slower (profiles/r2f_node32_vs_node64.txt).
+//   p = (lo.x, lo.y, lo.z, hi.x)  q = (hi.y, hi.z, w6, w7): six plane dwords; bits 7c..7c+6 of a plane dword = child c's plane,
+//   quantised to 7 bits (lo rounded down, hi rounded up: conservative); a child slot without a child holds lo = 127, hi = 0 and can
+//   never be hit.  The node's frame is origin + q * scale with
+//     origin_k = gridLo_k + g_k * cell_k   g_k: 14-bit coordinate on a scene-wide power-of-two grid (SceneDev::grid*)
+//     scale_k  = cell_k * 2^(r_k - 7)      r_k: 4 bits
+//   w6 = g.x | g.y << 14 | r.x << 28;  w7 = childBase | r.y << 28;  the top nibbles of the plane dwords hold g.z (lo.x, lo.y, lo.z:
+//   4 bits each, hi.x: 2 bits, above them the number of children - 1), r.z (hi.y) and the number of inner children (hi.z).
+// Children 0 .. nInner-1 are the nodes childBase + j (allocated together); the others are single triangles stored at
+// tris[4 * node + 3 - j]: the reference of child j is `base + j` for both kinds (base = childBase or ~(4 * node + 3)).
+struct alignas(32) Node4 {
+    uint4 p, q;
+};
+static const int kGridBits = 14;
+#else
 // 4-wide BVH node, child boxes quantised to 8 bits per plane against the node's own box: one 64-byte,
 // 64-byte-aligned record (never straddles a cache line) of which THREE dwordx4 loads are used.
 //   a = (origin.x, origin.y, origin.z, meta)    meta = ex | ey << 8 | ez << 16 | nInner << 24 | nValid << 27,
@@ -23,6 +46,8 @@ struct alignas(64) Node4 {
     float4 a;
     uint4 b, c, d;
 };
+
+#endif
 
 // World-space triangle in BVH leaf order, 48 bytes = three dwordx4 loads:
 //   p = (v0.x v0.y v0.z e1.x)  q = (e1.y e1.z e2.x e2.y)  r = (e2.z, prim id, flags, -)
@@ -87,6 +112,9 @@ struct SceneDev {
     // sample tables
     const float2 *seq, *aperture, *seqOffsets;
     int32_t nSeq, seqLen, nSeqOffsets;
+    // frame grid of the 32-byte nodes: origin of the grid, cell size (a power of two per axis), biased exponent of cell * 2^-7
+    float gridLo[3], gridCell[3];
+    int32_t gridExpM7[3];
     // interactive-mode block table (hr_interactive_blocks_set); blockNx == 0: the unshuffled list
     int32_t blockNx, blockNy;
     int32_t blockCoords[32];
