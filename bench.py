@@ -128,7 +128,9 @@ def _short_kernel(name):
     return n.split("<")[0]
 
 
-PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]))
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]),
+              # busy cycles of the two units that bind k_trace: the texture addresser of a CU, and the VALUs
+              ("units", ["TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "TA_FLAT_READ_WAVEFRONTS_sum"]))
 
 
 def pmc_legs(args, keep_dir=None):
@@ -144,7 +146,7 @@ def pmc_legs(args, keep_dir=None):
     os.makedirs(out_root, exist_ok=True)
     child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.join(ROOT, "bench.py"),
              "--pmc-child", "--workload", args.workload, "--steps", str(args.steps), "--warmup", "0", "--cpu-seconds", "0", "--no-stats-pass",
-             "--no-wakeup", "--no-pmc", "--no-converge", "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
+             "--no-wakeup", "--no-pmc", "--no-converge", "--estimator", args.estimator, "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
     env = dict(os.environ, TMPDIR="/tmp")
     res = {"kernels": {}, "passes": {}, "dir": out_root if keep_dir else None}
     t0 = time.perf_counter()
@@ -153,7 +155,7 @@ def pmc_legs(args, keep_dir=None):
         shutil.rmtree(d, ignore_errors=True)
         cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "-d", d, "-o", name, "--output-format", "csv", "--", *child]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
         except (OSError, subprocess.TimeoutExpired) as e:
             res["passes"][name] = {"error": str(e)[:200]}
             continue
@@ -253,7 +255,10 @@ def main():
                     "sharded frame (no collective); the JSON line is marked emulated and is not a benchmark result")
     ap.add_argument("--converge", action="store_true", help="passes-to-converge p50 (BASELINE metric 2) over all 16 runs (default: 3 of them): an "
                     "8192-pass reference render + the runs; N = 1 only")
+    ap.add_argument("--estimator", default="reference", choices=["reference", "env_mis"], help="estimator of the timed region and of the convergence "
+                    "leg: the reference's (BASELINE metric), or importance-sampled environment + one-sample MIS (include/hrcore.h)")
     ap.add_argument("--no-converge", action="store_true", help="skip the live passes-to-converge leg (the committed measurement is quoted, marked as such)")
+    ap.add_argument("--converge-mis", action="store_true", help="also run the convergence leg with the env-MIS estimator")
     ap.add_argument("--converge-cap", type=int, default=4096, help="give up a convergence run after this many passes")
     ap.add_argument("--converge-runs", type=int, default=16, help="number of runs (Sobol sequence indices 0..n-1 of the offsets table)")
     ap.add_argument("--shard-rank", type=int, default=0, help="with --shard-of: which rank's shard to render")
@@ -311,6 +316,7 @@ def main():
     sc = build_scene(args.workload, args.width, args.height, max(32, passes_total))
     if args.depth >= 0:
         sc.options.max_ray_depth = args.depth
+    sc.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS if args.estimator == "env_mis" else ffi.HR_ESTIMATOR_REFERENCE
     stream = torch.cuda.current_stream().cuda_stream
     eng_rank = args.shard_rank if emulated else rank
     eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, time_kernels=True)
@@ -475,7 +481,24 @@ def main():
                     peak = n_cus * 4 * per_simd  # G wave-instructions / s
                     ach = valu_per_ray["all_kernels"] * run_rays / wall_s / 1e9
                     roofline["valu"] = {"bound": "valu_issue", "achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
-                                        "peak_source": peak_src, "wave_instructions_per_ray": valu_per_ray}
+                                        "peak_source": peak_src, "wave_instructions_per_ray": valu_per_ray,
+                                        "note": "issue-rate ceiling of plain FMAs at the calibrated clock; the instruction mix of k_trace occupies a SIMD "
+                                                "for ~4 cycles per instruction and the chip holds ~1.5 GHz under this load: see `units` for busy fractions"}
+                if pmc and not pmc.get("failed") and "rays" in pmc["passes"].get("units", {}):
+                    ku = pmc["kernels"].get("k_trace", {})
+                    if ku.get("GRBM_GUI_ACTIVE") and ku.get("TA_TA_BUSY_sum") is not None:
+                        n_xcd = 8.0   # GRBM_GUI_ACTIVE is reported summed over the XCDs; TA counters over the CUs; SQ_ACTIVE_* in quad-cycles
+                        n_cus = float(getattr(torch.cuda.get_device_properties(dev), "multi_processor_count", 256))
+                        cyc = ku["GRBM_GUI_ACTIVE"] / n_xcd
+                        roofline["units"] = {
+                            "kernel": "k_trace", "kernel_cycles": cyc,
+                            "ta_busy": ku["TA_TA_BUSY_sum"] / n_cus / cyc,
+                            "valu_busy": ku.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_cus * 4.0) / cyc,
+                            "ta_wave_loads_per_ray": ku.get("TA_FLAT_READ_WAVEFRONTS_sum", 0.0) / pmc["passes"]["units"]["rays"],
+                            "definition": "busy cycles of the CU's texture addresser (TA_TA_BUSY_sum / CUs) and of the VALUs (SQ_ACTIVE_INST_VALU x 4 / SIMDs) "
+                                          "over the cycles k_trace ran (GRBM_GUI_ACTIVE / 8 XCDs), summed over every launch of a counter pass of this command: "
+                                          "the two units that bind the kernel (scattered 16-B-per-lane loads cost one TA cycle per lane and instruction, "
+                                          "tools/calib_tcp.hip)"}
             vt = cpu
             if vt is None:
                 vpath = os.path.join(ROOT, "profiles", "vt_spec.json")
@@ -524,6 +547,13 @@ def main():
             conv = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
             conv["measured_live"] = True
             conv["runs_of_16"] = n_runs
+            conv["estimator"] = args.estimator
+            if args.estimator == "reference" and args.converge_mis:
+                # the same leg with the importance-sampled environment + MIS estimator (its own 8192-pass reference image)
+                sc.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS
+                conv_mis = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
+                sc.options.estimator = ffi.HR_ESTIMATOR_REFERENCE
+                conv["env_mis"] = {k: conv_mis[k] for k in ("p50", "runs", "median_err_at_pass", "reference_render_s", "runs_s")}
         else:
             cpath = os.path.join(ROOT, "profiles", "converge.json")
             if os.path.exists(cpath):

@@ -38,6 +38,7 @@ HR_MF_VERTEX_COLORS = 1 << 9
 HR_SAMPLE_RANDOM, HR_SAMPLE_HALTON, HR_SAMPLE_HAMMERSLEY, HR_SAMPLE_BLUE_NOISE, HR_SAMPLE_SOBOL = range(5)
 HR_BOKEH_CIRCULAR, HR_BOKEH_PENTAGON, HR_BOKEH_HEXAGON, HR_BOKEH_OCTAGON = range(4)
 
+HR_ESTIMATOR_REFERENCE, HR_ESTIMATOR_ENV_MIS = 0, 1
 (HR_VIS_NONE, HR_VIS_GEOMETRIC_NORMALS, HR_VIS_UVS, HR_VIS_TANGENTS, HR_VIS_BITANGENTS, HR_VIS_NORMALMAP,
  HR_VIS_FINAL_NORMALS, HR_VIS_BASE_COLOR, HR_VIS_ROUGHNESS, HR_VIS_METALLIC, HR_VIS_EMISSIVE, HR_VIS_CLEARCOAT,
  HR_VIS_CLEARCOAT_ROUGHNESS, HR_VIS_CLEARCOAT_NORMALMAP, HR_VIS_SHADER) = range(15)
@@ -101,7 +102,8 @@ class PassParams(C.Structure):
                 ("aperture_radius", C.c_float), ("view_matrix", C.c_float * 16), ("interactive_mode", C.c_int32),
                 ("block_size", C.c_int32 * 2), ("current_block_pixel", C.c_int32 * 2), ("max_sample_index", C.c_float),
                 ("enable_visualizer", C.c_int32), ("visualizer_mode", C.c_int32),
-                ("enable_accumulator_visualizer", C.c_int32), ("show_nans", C.c_int32), ("show_inf", C.c_int32)]
+                ("enable_accumulator_visualizer", C.c_int32), ("show_nans", C.c_int32), ("show_inf", C.c_int32),
+                ("estimator", C.c_int32)]
 
 
 class PassStats(C.Structure):

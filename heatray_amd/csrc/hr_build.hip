@@ -12,6 +12,7 @@
 //              so no reliance on cross-XCD visibility)
 //   emit     : subtrees of <= 4 triangles collapse into leaves; 64-byte two-box nodes
 #include "hr_kernels.h"
+#include "hr_texture.h"
 
 #include <vector>
 
@@ -764,6 +765,138 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     if (finalTris) hipFree(sorted);
     if (hipGetLastError() != hipSuccess) return 1;
     return rc;
+}
+
+// ------------------------------------------------------------------ environment importance table (HR_ESTIMATOR_ENV_MIS)
+// The distribution the one-sample MIS estimator draws environment directions from (include/hrcore.h): texel weight =
+// (luminosity of the brightest texel of its 3 x 3 neighbourhood + maxLuminosity / 65536) x cos(elevation of the row), quantised to
+// integers so that the sums do not depend on their order — the tables are bit-identical to oracle/oracle_scene.cpp::buildEnvTable.
+__global__ __launch_bounds__(256) void k_env_lum(TexDesc t, float *__restrict__ lum, uint32_t *__restrict__ maxBits)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float l = 0.0f;
+    if (i < (uint32_t)(t.w * t.h)) {
+        const v4 c = texel(t, (int)(i % (uint32_t)t.w), (int)(i / (uint32_t)t.w));
+        l = (c.x * 0.33f + c.y * 0.59f) + c.z * 0.11f; // utility.rlsl:163-166 luminosity
+        l = l > 0.0f ? l : 0.0f;
+        lum[i] = l;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l = fmax_(l, __shfl_xor(l, o));
+    if ((threadIdx.x & 63) == 0 && l > 0.0f) atomicMax(maxBits, __float_as_uint(l)); // non-negative floats order like their bits
+}
+__global__ __launch_bounds__(256) void k_env_dilate(const float *__restrict__ lum, float *__restrict__ dil, int w, int h)
+{
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (uint32_t)(w * h)) return;
+    const int i = (int)(idx % (uint32_t)w), j = (int)(idx / (uint32_t)w);
+    float m = 0.0f;
+    for (int dj = -1; dj <= 1; ++dj) {
+        const int jj = j + dj < 0 ? 0 : (j + dj >= h ? h - 1 : j + dj);
+        for (int di = -1; di <= 1; ++di) {
+            const int ii = (i + di + w) % w;
+            const float l = lum[(size_t)jj * w + ii];
+            m = l > m ? l : m;
+        }
+    }
+    dil[idx] = m;
+}
+HRD uint32_t envWeight(float lum, float floorLum, float norm, float c)
+{
+    const float wt = (lum + floorLum) * c;
+    const float q = norm > 0.0f ? (wt / norm) * 1048576.0f : 0.0f;
+    return (uint32_t)q + 1u;
+}
+// one workgroup per row: quantised weights and their sum
+__global__ __launch_bounds__(256) void k_env_rows(const float *__restrict__ dil, int w, int h, const uint32_t *__restrict__ maxBits,
+                                                  uint32_t *__restrict__ wq, unsigned long long *__restrict__ rowSum)
+{
+    __shared__ unsigned long long part[4];
+    const int j = blockIdx.x;
+    const float maxLum = __uint_as_float(*maxBits);
+    const float floorLum = maxLum * (1.0f / 65536.0f), norm = maxLum + floorLum;
+    const float elevation = (((float)j + 0.5f) / (float)h - 0.5f) * HR_KPI;
+    const float c = cos_(elevation);
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < w; i += 256) {
+        const uint32_t v = envWeight(dil[(size_t)j * w + i], floorLum, norm, c);
+        wq[(size_t)j * w + i] = v;
+        s += v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) rowSum[j] = part[0] + part[1] + part[2] + part[3];
+}
+// marginal over the rows (h is at most a few thousand: one thread)
+__global__ void k_env_marginal(const unsigned long long *__restrict__ rowSum, int w, int h, const uint32_t *__restrict__ maxBits,
+                               float *__restrict__ rowCdf, unsigned long long *__restrict__ total, float *__restrict__ meanLum)
+{
+    unsigned long long t = 0;
+    for (int j = 0; j < h; ++j) t += rowSum[j];
+    unsigned long long acc = 0;
+    for (int j = 0; j < h; ++j) {
+        rowCdf[j] = (float)acc / (float)t;
+        acc += rowSum[j];
+    }
+    rowCdf[h] = 1.0f;
+    *total = t;
+    // mean luminosity over the sphere from the same integers: sum(weight) / sum(cos), rows in order
+    const float maxLum = __uint_as_float(*maxBits);
+    const float norm = maxLum + maxLum * (1.0f / 65536.0f);
+    float sumC = 0.0f;
+    for (int j = 0; j < h; ++j) sumC = sumC + cos_((((float)j + 0.5f) / (float)h - 0.5f) * HR_KPI);
+    *meanLum = (((float)t / 1048576.0f) * norm) / ((float)w * sumC);
+}
+// one workgroup per row: conditional CDF over the columns (chunked scan with a carry) and the texel probabilities
+__global__ __launch_bounds__(256) void k_env_cols(const uint32_t *__restrict__ wq, const unsigned long long *__restrict__ rowSum,
+                                                  const unsigned long long *__restrict__ total, int w, float *__restrict__ colCdf,
+                                                  float *__restrict__ prob)
+{
+    __shared__ unsigned long long waveSum[4];
+    __shared__ unsigned long long carry;
+    const int j = blockIdx.x;
+    const float fr = (float)rowSum[j], ft = (float)*total;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < w; base += 256) {
+        const int i = base + (int)threadIdx.x;
+        const unsigned long long v = i < w ? (unsigned long long)wq[(size_t)j * w + i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long up = __shfl_up(inc, o);
+            if ((int)lane >= o) inc += up;
+        }
+        if (lane == 63) waveSum[wave] = inc;
+        __syncthreads();
+        unsigned long long before = carry;
+        for (uint32_t k = 0; k < wave; ++k) before += waveSum[k];
+        if (i < w) {
+            colCdf[(size_t)j * (w + 1) + i] = (float)(before + inc - v) / fr;
+            prob[(size_t)j * w + i] = (float)v / ft;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) colCdf[(size_t)j * (w + 1) + w] = 1.0f;
+}
+
+// scratch: lum, dil (w*h floats each), wq (w*h uint32), rowSum (h uint64), total (uint64), maxBits (uint32) — caller-owned
+void launchEnvTable(hipStream_t st, const TexDesc &tex, float *lum, float *dil, uint32_t *wq, unsigned long long *rowSum, unsigned long long *total,
+                    uint32_t *maxBits, float *rowCdf, float *colCdf, float *prob, float *meanLum)
+{
+    const int w = tex.w, h = tex.h;
+    const uint32_t n = (uint32_t)(w * h), g = (n + 255) / 256;
+    hipMemsetAsync(maxBits, 0, 4, st);
+    hipLaunchKernelGGL(k_env_lum, dim3(g), dim3(256), 0, st, tex, lum, maxBits);
+    hipLaunchKernelGGL(k_env_dilate, dim3(g), dim3(256), 0, st, lum, dil, w, h);
+    hipLaunchKernelGGL(k_env_rows, dim3(h), dim3(256), 0, st, dil, w, h, maxBits, wq, rowSum);
+    hipLaunchKernelGGL(k_env_marginal, dim3(1), dim3(1), 0, st, rowSum, w, h, maxBits, rowCdf, total, meanLum);
+    hipLaunchKernelGGL(k_env_cols, dim3(h), dim3(256), 0, st, wq, rowSum, total, w, colCdf, prob);
 }
 
 // ---------------------------------------------------------------------------------------- QMC

@@ -145,6 +145,10 @@ struct hr_ctx {
     std::vector<hr_material> materials;
     hr_lights lights{};
     int32_t blockNx = 0, blockNy = 0, blockCoords[32] = {0};
+    // importance table of the environment map (HR_ESTIMATOR_ENV_MIS), built on the device when a pass first asks for it
+    float *dEnvRowCdf = nullptr, *dEnvColCdf = nullptr, *dEnvProb = nullptr;
+    int envW = 0, envH = 0, envTex = -2;
+    float envMeanLum = 0.0f;
     bool committed = false, sceneDirty = true, hasPassthrough = false;
     // What changed since the last commit decides what a commit does: a change of the set of geometries rebuilds the tree, a
     // change of transforms only (Scene::applyTransform while the user drags a slider) REFITS it — same topology, every box
@@ -454,6 +458,7 @@ int hr_ctx_destroy(hr_ctx *c)
         if (c->stageEv[k]) hipEventDestroy(c->stageEv[k]);
     }
     hipFree(c->dConsts);
+    hipFree(c->dEnvRowCdf), hipFree(c->dEnvColCdf), hipFree(c->dEnvProb);
     if (c->hConsts) hipHostFree(c->hConsts);
     if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
@@ -952,6 +957,7 @@ int hr_texture_destroy(hr_ctx *c, hr_tex_id id)
     QUIESCE(c);
     hipFree(c->textures[id].dpx);
     c->textures[id] = Texture();
+    if (c->envTex == id) c->envTex = -2, c->envW = c->envH = 0;
     c->sceneDirty = true;
     return HR_OK;
 }
@@ -1172,6 +1178,8 @@ static int uploadScene(hr_ctx *c)
     s.lights = c->lights;
     s.seq = c->dSeq, s.aperture = c->dAperture, s.seqOffsets = c->dSeqOffsets;
     s.nSeq = c->nSeq, s.seqLen = c->seqLen, s.nSeqOffsets = c->nSeqOffsets;
+    s.envRowCdf = c->dEnvRowCdf, s.envColCdf = c->dEnvColCdf, s.envProb = c->dEnvProb;
+    s.envW = c->envW, s.envH = c->envH, s.envMeanLum = c->envMeanLum;
     s.blockNx = c->blockNx, s.blockNy = c->blockNy;
     std::memcpy(s.blockCoords, c->blockCoords, sizeof(s.blockCoords));
     HIP_TRY(c, hipMemcpy(c->dScene, &s, sizeof(SceneDev), hipMemcpyHostToDevice));
@@ -1180,6 +1188,49 @@ static int uploadScene(hr_ctx *c)
     for (const hr_material &m : c->materials)
         if (m.type == HR_MAT_PBR && (!(m.flags & HR_MF_DOUBLE_SIDED) || (m.flags & HR_MF_ALPHA_MASK))) c->hasPassthrough = true;
     c->sceneDirty = false;
+    return HR_OK;
+}
+
+// HR_ESTIMATOR_ENV_MIS: (re)build the importance table of the current environment map on the device
+static int ensureEnvTable(hr_ctx *c)
+{
+    const int id = c->lights.env_texture;
+    const bool have = c->lights.env_enabled && id >= 0 && id < (int)c->textures.size() && c->textures[id].alive;
+    if (!have) {
+        if (c->envW != 0) {
+            QUIESCE(c);
+            c->envW = c->envH = 0, c->envTex = -2;
+            c->sceneDirty = true;
+        }
+        return HR_OK;
+    }
+    const TexDesc &t = c->textures[id].desc;
+    if (c->envTex == id && c->envW == t.w && c->envH == t.h) return HR_OK;
+    QUIESCE(c);
+    hipFree(c->dEnvRowCdf), hipFree(c->dEnvColCdf), hipFree(c->dEnvProb);
+    c->dEnvRowCdf = c->dEnvColCdf = c->dEnvProb = nullptr, c->envW = c->envH = 0, c->envTex = -2;
+    const size_t n = (size_t)t.w * t.h;
+    float *lum = nullptr, *dil = nullptr;
+    uint32_t *wq = nullptr, *maxBits = nullptr;
+    unsigned long long *rowSum = nullptr;
+    hipError_t e = hipMalloc(&c->dEnvRowCdf, sizeof(float) * ((size_t)t.h + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->dEnvColCdf, sizeof(float) * (size_t)t.h * ((size_t)t.w + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->dEnvProb, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&lum, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&dil, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&wq, sizeof(uint32_t) * n);
+    if (e == hipSuccess) e = hipMalloc(&rowSum, sizeof(unsigned long long) * ((size_t)t.h + 1));
+    if (e == hipSuccess) e = hipMalloc(&maxBits, 16);
+    if (e == hipSuccess) {
+        float *dMean = reinterpret_cast<float *>(maxBits) + 1;
+        launchEnvTable(c->stream, t, lum, dil, wq, rowSum, rowSum + t.h, maxBits, c->dEnvRowCdf, c->dEnvColCdf, c->dEnvProb, dMean);
+        e = hipMemcpyAsync(&c->envMeanLum, dMean, sizeof(float), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    hipFree(lum), hipFree(dil), hipFree(wq), hipFree(rowSum), hipFree(maxBits);
+    HIP_TRY(c, e);
+    c->envW = t.w, c->envH = t.h, c->envTex = id;
+    c->sceneDirty = true;
     return HR_OK;
 }
 
@@ -1490,7 +1541,14 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     if (c->nSeq <= 0 || c->nSeqOffsets <= 0) FAIL(c, HR_ERR_INVALID, "sample tables not set");
     if (pp->max_ray_depth < 0 || pp->max_ray_depth + 2 >= kMaxBounceSlots - 8) FAIL(c, HR_ERR_INVALID, "max_ray_depth out of range");
     if (pp->interactive_mode && (pp->block_size[0] <= 0 || pp->block_size[1] <= 0)) FAIL(c, HR_ERR_INVALID, "bad block size");
-    int rc = uploadScene(c); // drains the pipeline first when the scene constants changed
+    int rc = HR_OK;
+    if (pp->estimator == HR_ESTIMATOR_ENV_MIS) {
+        rc = ensureEnvTable(c);
+        if (rc) return rc;
+    } else if (pp->estimator != HR_ESTIMATOR_REFERENCE) {
+        FAIL(c, HR_ERR_INVALID, "unknown estimator");
+    }
+    rc = uploadScene(c); // drains the pipeline first when the scene constants changed
     if (rc) return rc;
     if (c->frame.nOwnedTiles == 0) return HR_OK;
     // only passes of equal depth overlap (keeps the groups in lockstep; order is enforced by resolveReady regardless)

@@ -138,6 +138,10 @@ int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const fl
 void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts);
 void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts);
 
+// environment importance table (HR_ESTIMATOR_ENV_MIS): scratch and outputs are caller-owned device arrays
+void launchEnvTable(hipStream_t st, const TexDesc &tex, float *lum, float *dil, uint32_t *wq, unsigned long long *rowSum, unsigned long long *total,
+                    uint32_t *maxBits, float *rowCdf, float *colCdf, float *prob, float *meanLum);
+
 void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, float2 *out);
 void launchMultiscatterLUT(hipStream_t st, const float2 *sobol4096, float *out128x128);
 

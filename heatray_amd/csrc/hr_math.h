@@ -144,6 +144,12 @@ HRD float sin_(float x)
     sincos_(x, &s, &c);
     return s;
 }
+HRD float cos_(float x)
+{
+    float s, c;
+    sincos_(x, &s, &c);
+    return c;
+}
 
 HRD float atan_(float xx)
 {

@@ -272,7 +272,8 @@ struct Shader {
         }
         float environment = 0.0f;
         if (L.env_enabled) {
-            environment = 50.0f * L.env_exposure;
+            // lightSampling.rlsl:74-79's constant 50, or for HR_ESTIMATOR_ENV_MIS the irradiance the map can deliver (pi x mean luminosity)
+            environment = (pp.estimator == HR_ESTIMATOR_ENV_MIS && S.envW > 0) ? (S.envMeanLum * HR_KPI) * L.env_exposure : 50.0f * L.env_exposure;
             probabilitySum += environment;
         }
         float norm = 1.0f / greaterThanZero(probabilitySum);
@@ -381,6 +382,120 @@ struct Shader {
             }
         }
     }
+    // ---- HR_ESTIMATOR_ENV_MIS (include/hrcore.h): importance sampling of the environment map + one-sample MIS.  Not in the
+    // reference; the arithmetic is the oracle's (oracle/oracle_shade.cpp, same operations in the same order).
+    HRD bool envMis() const { return pp.estimator == HR_ESTIMATOR_ENV_MIS && S.envW > 0; }
+    HRD void envTexelOf(v3 dir, int &i, int &j) const
+    {
+        float theta = atan2_(dir.x, -dir.z) + S.lights.env_theta_rotation;
+        if (theta > HR_KTWOPI) theta = theta - HR_KTWOPI;
+        float phi = atan2_(dir.y, sqrt_(dir.x * dir.x + dir.z * dir.z));
+        float u = (theta / HR_KTWOPI) + 0.5f;
+        float t = 1.0f - ((-phi * HR_KONEOVERPI) + 0.5f);
+        const int w = S.envW, h = S.envH;
+        int ii = (int)floor_(u * (float)w) % w;
+        i = ii < 0 ? ii + w : ii;
+        int jj = (int)floor_(t * (float)h);
+        j = jj < 0 ? 0 : (jj >= h ? h - 1 : jj);
+    }
+    HRD float envPdf(v3 dir) const
+    {
+        int i, j;
+        envTexelOf(dir, i, j);
+        const float cosEl = sqrt_(dir.x * dir.x + dir.z * dir.z);
+        const float K = ((float)S.envW * (float)S.envH) / (HR_KTWOPI * HR_KPI);
+        return (S.envProb[(size_t)j * S.envW + i] * K) / fmax_(cosEl, 1e-6f);
+    }
+    static HRD int cdfFind(const float *cdf, int n, float x)
+    {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cdf[mid] <= x)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        return lo;
+    }
+    HRD v3 sampleEnv(float u1, float u2) const
+    {
+        const int w = S.envW, h = S.envH;
+        const float *rc = S.envRowCdf;
+        const int j = cdfFind(rc, h, u1);
+        const float fy = (u1 - rc[j]) / fmax_(rc[j + 1] - rc[j], 1e-20f);
+        const float *cc = S.envColCdf + (size_t)j * (w + 1);
+        const int i = cdfFind(cc, w, u2);
+        const float fx = (u2 - cc[i]) / fmax_(cc[i + 1] - cc[i], 1e-20f);
+        const float t = ((float)j + saturate(fy)) / (float)h, u = ((float)i + saturate(fx)) / (float)w;
+        const float elevation = (t - 0.5f) * HR_KPI;
+        const float azimuth = (u - 0.5f) * HR_KTWOPI - S.lights.env_theta_rotation;
+        float se, ce, sa, ca;
+        sincos_(elevation, &se, &ce);
+        sincos_(azimuth, &sa, &ca);
+        return v3(ce * sa, se, -(ce * ca));
+    }
+    HRD void envMisDiffuse(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee,
+                           Ray &next) const
+    {
+        const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        v3 O = (sel.x < 0.5f) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv(rand.x, rand.y);
+        float NdotO = dot(N, O);
+        if (!(NdotO > 0.0f)) return;
+        NdotO = saturate(NdotO);
+        const float pLobe = NdotO / HR_KPI, pMap = envPdf(O);
+        v3 reflectance = (Cdiff / HR_KPI) * NdotO;
+        reflectance = reflectance * in.weight;
+        reflectance = reflectance / (0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / sampleProbability;
+        reflectance = reflectance / envProbability;
+        if (dot(reflectance, reflectance) > 0.0f) {
+            Ray r = createRay(in, P);
+            r.d = O;
+            r.weight = reflectance;
+            r.occlusionTest = true;
+            r.missKind = MISS_ENV, r.missIdx = 0;
+            r.extraT = 0.0f;
+            emit(r, nee, next);
+        }
+    }
+    HRD void envMisSpecular(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
+                            float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next) const
+    {
+        const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        v3 O, H;
+        if (sel.x < 0.5f) {
+            H = mul(frame, sampleVisibleGGX(mulT(frame, I), rand.x, rand.y, roughnessAlpha));
+            O = normalize(2.0f * saturate(dot(I, H)) * H - I);
+        } else {
+            O = sampleEnv(rand.x, rand.y);
+            H = normalize(I + O);
+        }
+        float NdotO = dot(N, O);
+        if (!(NdotO > 0.0f)) return;
+        NdotO = saturate(NdotO);
+        const float NdotH = saturate(dot(N, H)), IdotH = saturate(dot(I, H));
+        const float D = D_GGX(NdotH, roughnessAlpha);
+        const v3 F = F_Schlick(Cspec, IdotH);
+        const float G2 = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha), G1 = G1_Smith_GGX(NdotI, roughnessAlpha);
+        v3 specular = (D * F * G2) / greaterThanZero(4.0f * NdotI);
+        specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+        const float pLobe = (D * G1) / greaterThanZero(4.0f * NdotI), pMap = envPdf(O);
+        v3 reflectance = specular * in.weight;
+        reflectance = reflectance / greaterThanZero(0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / sampleProbability;
+        reflectance = reflectance / envProbability;
+        if (dot(reflectance, reflectance) > 0.0f) {
+            Ray r = createRay(in, P);
+            r.d = O;
+            r.weight = reflectance;
+            r.occlusionTest = true;
+            r.missKind = MISS_ENV, r.missIdx = 0;
+            r.extraT = 0.0f;
+            emit(r, nee, next);
+        }
+    }
+
     HRD void directDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float lightProbability, v2 rand, const m3 &frame,
                                  Ray &nee, Ray &next) const // :52-98
     {
@@ -406,7 +521,10 @@ struct Shader {
                 }
             }
         } else if (ls.probability > 0.0f) {
-            indirectDiffuseSample(in, P, N, Cdiff, sampleProbability, ls.probability, rand, frame, MISS_ENV, nee, next);
+            if (envMis())
+                envMisDiffuse(in, P, N, Cdiff, sampleProbability, ls.probability, rand, frame, nee, next);
+            else
+                indirectDiffuseSample(in, P, N, Cdiff, sampleProbability, ls.probability, rand, frame, MISS_ENV, nee, next);
         }
     }
     HRD void indirectSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
@@ -473,8 +591,11 @@ struct Shader {
                 }
             }
         } else if (ls.probability > 0.0f) {
-            indirectSpecularSample(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame,
-                                   MISS_ENV, nee, next);
+            if (envMis())
+                envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame, nee, next);
+            else
+                indirectSpecularSample(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame,
+                                       MISS_ENV, nee, next);
         }
     }
 

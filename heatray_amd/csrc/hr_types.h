@@ -115,6 +115,10 @@ struct SceneDev {
     // frame grid of the 32-byte nodes: origin of the grid, cell size (a power of two per axis), biased exponent of cell * 2^-7
     float gridLo[3], gridCell[3];
     int32_t gridExpM7[3];
+    // importance table of the environment map (HR_ESTIMATOR_ENV_MIS): P(row < j), P(col < i | row j), P(texel); envW == 0: none
+    const float *envRowCdf, *envColCdf, *envProb;
+    int32_t envW, envH;
+    float envMeanLum; // solid-angle-weighted mean luminosity of the map (light-pick weight of the MIS estimator)
     // interactive-mode block table (hr_interactive_blocks_set); blockNx == 0: the unshuffled list
     int32_t blockNx, blockNy;
     int32_t blockCoords[32];

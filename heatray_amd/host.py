@@ -225,6 +225,7 @@ class RenderOptions:
     visualizer_mode: int = ffi.HR_VIS_NONE
     show_nans: bool = False
     show_inf: bool = False
+    estimator: int = ffi.HR_ESTIMATOR_REFERENCE
 
     def pass_params(self, sample_index, current_block_pixel=(0, 0)):
         """Uniforms of one pass: PassGenerator::runRenderFrameJob (PassGenerator.cpp:341-369)."""
@@ -246,6 +247,7 @@ class RenderOptions:
         p.visualizer_mode = self.visualizer_mode
         p.enable_accumulator_visualizer = int(self.show_nans or self.show_inf)
         p.show_nans, p.show_inf = int(self.show_nans), int(self.show_inf)
+        p.estimator = int(self.estimator)
         return p
 
 

@@ -19,6 +19,7 @@
 #include <random>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 PassGenerator::~PassGenerator()
@@ -155,6 +156,10 @@ bool PassGenerator::runInitJob(const RLint renderWidth, const RLint renderHeight
         return false;
     }
     openrl::currentContext() = m_context;
+    {
+        const char* est = getenv("HEATRAY_ESTIMATOR");
+        m_envMis = est && std::string(est) == "env_mis";
+    }
     m_width = renderWidth;
     m_height = renderHeight;
     if (!HRFunc(hr_frame_resize(m_context, renderWidth, renderHeight))) return false;
@@ -279,6 +284,9 @@ void PassGenerator::runRenderFrameJob(const RenderOptions& newOptions, const Pas
         params.show_nans = m_globalDebugMode == M::kNANs ? 1 : 0;
         params.show_inf = m_globalDebugMode == M::kInf ? 1 : 0;
         params.enable_accumulator_visualizer = (params.show_nans || params.show_inf) ? 1 : 0;
+        // RenderOptions is the reference's struct, unchanged, so the estimator is chosen out of band: HEATRAY_ESTIMATOR=env_mis selects
+        // the importance-sampled environment + MIS estimator of include/hrcore.h (default: the reference's estimator)
+        params.estimator = m_envMis ? HR_ESTIMATOR_ENV_MIS : HR_ESTIMATOR_REFERENCE;
 
         // Interactive mode walks the 3x3 block; the sample index advances once per full block (:372-384).
         if (m_renderOptions.enableInteractiveMode) {

@@ -193,6 +193,7 @@ private:
     bool m_running = false;
 
     hr_ctx* m_context = nullptr;
+    bool m_envMis = false; // HEATRAY_ESTIMATOR=env_mis
     RLint m_width = 0, m_height = 0;
 
     std::shared_ptr<openrl::PixelPackBuffer> m_resultPixels = nullptr;

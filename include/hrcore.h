@@ -294,7 +294,18 @@ typedef struct hr_pass_params {
     int32_t enable_accumulator_visualizer;
     int32_t show_nans;
     int32_t show_inf;
+    int32_t estimator;         /* HR_ESTIMATOR_*: how next-event rays towards the environment are sampled */
 } hr_pass_params;
+
+/* HR_ESTIMATOR_REFERENCE: the reference's estimator, bit for bit: when the light pick falls on the environment, the occlusion ray
+ * is BRDF-sampled (microfacet.rlsl:25-50,100-151) — the shaders leave importance sampling of the IBL and MIS as TODOs
+ * (lightSampling.rlsl:75-77, microfacet.rlsl:94-96).
+ * HR_ESTIMATOR_ENV_MIS: that one ray is drawn either from the BRDF lobe or from a luminance x solid-angle
+ * distribution over the environment map's texels (half the time each) and weighted with the balance heuristic (the one-sample
+ * MIS estimator): same expectation, far less variance under small bright sources.  PBR materials only; everything else —
+ * ray budget, light pick, lobe pick, analytic lights, glass — is the reference's. */
+#define HR_ESTIMATOR_REFERENCE 0
+#define HR_ESTIMATOR_ENV_MIS 1
 
 /* one-hot show* flags of GlobalData (PassGenerator.h:275-289) as an enum */
 #define HR_VIS_NONE 0

@@ -58,6 +58,19 @@ struct TriAttr {
     uint32_t flags;
 };
 
+// Importance table of the environment map for HR_ESTIMATOR_ENV_MIS (include/hrcore.h): a piecewise-constant distribution over the
+// texels, weight = (luminosity + maxLuminosity / 65536) x cos(elevation of the row), quantised to integers so that sums — hence the
+// tables — do not depend on the order of summation (the HIP build is a parallel scan and must produce the same bits).
+struct EnvTable {
+    int w = 0, h = 0;
+    int tex = -2;                 // texture id the table was built from (-2: none)
+    std::vector<float> rowCdf;    // h + 1: P(row < j)
+    std::vector<float> colCdf;    // h x (w + 1): P(col < i | row j)
+    std::vector<float> prob;      // h x w: probability of texel (i, j)
+    float meanLum = 0.0f;         // solid-angle-weighted mean of the (dilated) luminosity: the light pick's estimate of the map's power
+};
+vec4 texelOf(const Texture &t, int x, int y);
+
 // ---- BVH (oracle_bvh.cpp) ----
 struct BvhNode { // binary node holding both child boxes
     float lo[2][3], hi[2][3];
@@ -97,6 +110,7 @@ struct Context {
     std::vector<vec2> seq, aperture;
     std::vector<vec2> seqOffsets;
     int blockNx = 0, blockNy = 0, blockCoords[32] = {0}; // interactive-mode block table (0: the unshuffled list)
+    EnvTable env;
     // committed scene
     bool committed = false;
     std::vector<Tri> tris;       // submission order (prim id)
@@ -110,6 +124,7 @@ struct Context {
 };
 
 void commitScene(Context &ctx);
+void buildEnvTable(Context &ctx); // (re)builds ctx.env when the environment texture changed
 bool alphaPasses(const Context &ctx, int prim, float u, float v); // alpha-mask test for occlusion rays
 
 // ---- shading (oracle_shade.cpp) ----

@@ -30,6 +30,89 @@ static inline vec4 texel(const Texture &t, int x, int y)
 }
 
 // texture2D at LOD 0.  GL texel addressing: texel centres at (i + 0.5) / size.
+vec4 texelOf(const Texture &t, int x, int y) { return texel(t, x, y); }
+
+// HR_ESTIMATOR_ENV_MIS: the importance table of the environment map (EnvTable, oracle_internal.h)
+void buildEnvTable(Context &ctx)
+{
+    EnvTable &E = ctx.env;
+    const int id = ctx.lights.env_texture;
+    if (!ctx.lights.env_enabled || id < 0 || id >= (int)ctx.textures.size() || !ctx.textures[id].alive) {
+        E = EnvTable();
+        return;
+    }
+    if (E.tex == id && E.w == ctx.textures[id].w && E.h == ctx.textures[id].h) return;
+    const Texture &T = ctx.textures[id];
+    const int w = T.w, h = T.h;
+    E.w = w, E.h = h, E.tex = id;
+    std::vector<float> lum((size_t)w * h);
+    float maxLum = 0.0f;
+    for (int j = 0; j < h; ++j)
+        for (int i = 0; i < w; ++i) {
+            const vec4 c = texel(T, i, j);
+            float l = (c.x * 0.33f + c.y * 0.59f) + c.z * 0.11f; // utility.rlsl:163-166 luminosity
+            l = l > 0.0f ? l : 0.0f;
+            lum[(size_t)j * w + i] = l;
+            maxLum = l > maxLum ? l : maxLum;
+        }
+    // the light shader filters the map bilinearly, which smears a bright texel over its neighbours: weight every texel with the
+    // brightest of its 3 x 3 neighbourhood (wrapping in azimuth), so that the halo is importance-sampled too
+    {
+        std::vector<float> dil((size_t)w * h);
+        for (int j = 0; j < h; ++j)
+            for (int i = 0; i < w; ++i) {
+                float m = 0.0f;
+                for (int dj = -1; dj <= 1; ++dj) {
+                    const int jj = j + dj < 0 ? 0 : (j + dj >= h ? h - 1 : j + dj);
+                    for (int di = -1; di <= 1; ++di) {
+                        const int ii = (i + di + w) % w;
+                        const float l = lum[(size_t)jj * w + ii];
+                        m = l > m ? l : m;
+                    }
+                }
+                dil[(size_t)j * w + i] = m;
+            }
+        lum.swap(dil);
+    }
+    const float floorLum = maxLum * (1.0f / 65536.0f); // keeps every texel reachable without taking the samples away from the bright ones
+    const float norm = maxLum + floorLum; // >= every weight (cos <= 1)
+    std::vector<uint32_t> wq((size_t)w * h);
+    std::vector<unsigned long long> rowSum(h);
+    unsigned long long total = 0;
+    for (int j = 0; j < h; ++j) {
+        const float elevation = (((float)j + 0.5f) / (float)h - 0.5f) * kPI; // row 0 = bottom of the map = looking down
+        const float c = cos_(elevation);
+        unsigned long long r = 0;
+        for (int i = 0; i < w; ++i) {
+            const float wt = (lum[(size_t)j * w + i] + floorLum) * c;
+            const float q = norm > 0.0f ? (wt / norm) * 1048576.0f : 0.0f;
+            const uint32_t v = (uint32_t)q + 1u;
+            wq[(size_t)j * w + i] = v;
+            r += v;
+        }
+        rowSum[j] = r;
+        total += r;
+    }
+    E.rowCdf.assign((size_t)h + 1, 0.0f), E.colCdf.assign((size_t)h * (w + 1), 0.0f), E.prob.assign((size_t)w * h, 0.0f);
+    unsigned long long acc = 0;
+    for (int j = 0; j < h; ++j) {
+        E.rowCdf[j] = (float)acc / (float)total;
+        acc += rowSum[j];
+        unsigned long long a = 0;
+        for (int i = 0; i < w; ++i) {
+            E.colCdf[(size_t)j * (w + 1) + i] = (float)a / (float)rowSum[j];
+            a += wq[(size_t)j * w + i];
+            E.prob[(size_t)j * w + i] = (float)wq[(size_t)j * w + i] / (float)total;
+        }
+        E.colCdf[(size_t)j * (w + 1) + w] = 1.0f;
+    }
+    E.rowCdf[h] = 1.0f;
+    // mean luminosity over the sphere from the same integers: sum(weight) / sum(cos) — rows in order, one float addition per row
+    float sumC = 0.0f;
+    for (int j = 0; j < h; ++j) sumC = sumC + cos_((((float)j + 0.5f) / (float)h - 0.5f) * kPI);
+    E.meanLum = (((float)total / 1048576.0f) * norm) / ((float)w * sumC);
+}
+
 vec4 sampleTexture(const Texture &t, float u, float v)
 {
     if (t.filter == HR_FILTER_NEAREST) {

@@ -277,7 +277,10 @@ struct Shader {
         }
         float environment = 0.0f;
         if (L.env_enabled) {
-            environment = 50.0f * L.env_exposure;
+            // :74-79 "TODO: Add IBL importance sampling. Right now this is just a hack" — the constant 50 starves analytic lights
+            // (a sun-like directional light is picked a few per cent of the time).  HR_ESTIMATOR_ENV_MIS weighs the map like the
+            // other lights, by the irradiance it can deliver: pi x its mean luminosity.
+            environment = envMis() ? (ctx.env.meanLum * kPI) * L.env_exposure : 50.0f * L.env_exposure;
             probabilitySum += environment;
         }
         float norm = 1.0f / greaterThanZero(probabilitySum);
@@ -355,6 +358,128 @@ struct Shader {
             next = r;
     }
 
+    // ---- HR_ESTIMATOR_ENV_MIS (include/hrcore.h): importance sampling of the environment map + one-sample MIS ----
+    // Not in the reference (its shaders mark it TODO: lightSampling.rlsl:75-77, microfacet.rlsl:94-96); this is the contract the
+    // HIP kernels reproduce bit for bit, with its own known-answer tests (tests/test_oracle_kat.py).
+    bool envMis() const { return pp.estimator == HR_ESTIMATOR_ENV_MIS && ctx.env.w > 0; }
+    // the texel a direction falls into, with environmentLight.rlsl:19-34's mapping (u to the right, t upwards)
+    void envTexelOf(vec3 dir, int &i, int &j) const
+    {
+        float theta = atan2_(dir.x, -dir.z) + ctx.lights.env_theta_rotation;
+        if (theta > kTwoPI) theta = theta - kTwoPI;
+        float phi = atan2_(dir.y, sqrtf(dir.x * dir.x + dir.z * dir.z));
+        float u = (theta / kTwoPI) + 0.5f;
+        float t = 1.0f - ((-phi * kOneOverPI) + 0.5f);
+        const int w = ctx.env.w, h = ctx.env.h;
+        int ii = (int)floorf(u * (float)w) % w;
+        i = ii < 0 ? ii + w : ii;
+        int jj = (int)floorf(t * (float)h);
+        j = jj < 0 ? 0 : (jj >= h ? h - 1 : jj);
+    }
+    // density per solid angle of the table's distribution at `dir`: P(texel) / (texel area in (azimuth, elevation)) / cos(elevation)
+    float envPdf(vec3 dir) const
+    {
+        int i, j;
+        envTexelOf(dir, i, j);
+        const float cosEl = sqrtf(dir.x * dir.x + dir.z * dir.z);
+        const float K = ((float)ctx.env.w * (float)ctx.env.h) / (kTwoPI * kPI);
+        return (ctx.env.prob[(size_t)j * ctx.env.w + i] * K) / fmax_(cosEl, 1e-6f);
+    }
+    static int cdfFind(const float *cdf, int n, float x) // largest k in [0, n) with cdf[k] <= x (cdf[0] = 0)
+    {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (cdf[mid] <= x)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        return lo;
+    }
+    vec3 sampleEnv(float u1, float u2) const
+    {
+        const int w = ctx.env.w, h = ctx.env.h;
+        const float *rc = ctx.env.rowCdf.data();
+        const int j = cdfFind(rc, h, u1);
+        const float fy = (u1 - rc[j]) / fmax_(rc[j + 1] - rc[j], 1e-20f);
+        const float *cc = ctx.env.colCdf.data() + (size_t)j * (w + 1);
+        const int i = cdfFind(cc, w, u2);
+        const float fx = (u2 - cc[i]) / fmax_(cc[i + 1] - cc[i], 1e-20f);
+        const float t = ((float)j + saturate(fy)) / (float)h, u = ((float)i + saturate(fx)) / (float)w;
+        const float elevation = (t - 0.5f) * kPI;
+        const float azimuth = (u - 0.5f) * kTwoPI - ctx.lights.env_theta_rotation;
+        float se, ce, sa, ca;
+        sincos_(elevation, &se, &ce);
+        sincos_(azimuth, &sa, &ca);
+        return vec3(ce * sa, se, -(ce * ca));
+    }
+    // The next-event ray towards the environment of a diffuse lobe: drawn from the lobe (cosine) or from the map, half the time
+    // each; weight f cos / (p_lobe / 2 + p_map / 2) — the balance heuristic of the one-sample model.
+    void envMisDiffuse(const Ray &in, vec3 P, int prim, vec3 N, vec3 Cdiff, float sampleProbability, float envProbability, vec2 rand,
+                       const mat3 &frame, Ray &nee, Ray &next)
+    {
+        const vec2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        vec3 O = (sel.x < 0.5f) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv(rand.x, rand.y);
+        float NdotO = dot(N, O);
+        if (!(NdotO > 0.0f)) return;
+        NdotO = saturate(NdotO);
+        const float pLobe = NdotO / kPI, pMap = envPdf(O);
+        vec3 reflectance = (Cdiff / kPI) * NdotO;
+        reflectance = reflectance * in.weight;
+        reflectance = reflectance / (0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / sampleProbability;
+        reflectance = reflectance / envProbability;
+        // (no 1e-5 cut-off on the weight here: an importance-sampled ray towards a bright texel carries a small weight and a large radiance)
+        if (dot(reflectance, reflectance) > 0.0f) {
+            Ray r = createRay(in, P, prim);
+            r.d = O;
+            r.weight = reflectance;
+            r.occlusionTest = true;
+            r.missKind = MISS_ENV, r.missIdx = 0;
+            r.extraT = 0.0f;
+            emit(r, nee, next);
+        }
+    }
+    void envMisSpecular(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut, float roughness,
+                        float sampleProbability, float envProbability, vec2 rand, const mat3 &frame, Ray &nee, Ray &next)
+    {
+        const vec2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        vec3 O, H;
+        if (sel.x < 0.5f) { // the lobe's own sampler (microfacet.rlsl:100-151)
+            H = mul(frame, sampleVisibleGGX(mulT(frame, I), rand.x, rand.y, roughnessAlpha));
+            O = normalize(2.0f * saturate(dot(I, H)) * H - I);
+        } else {
+            O = sampleEnv(rand.x, rand.y);
+            H = normalize(I + O);
+        }
+        float NdotO = dot(N, O);
+        if (!(NdotO > 0.0f)) return;
+        NdotO = saturate(NdotO);
+        const float NdotH = saturate(dot(N, H)), IdotH = saturate(dot(I, H));
+        const float D = D_GGX(NdotH, roughnessAlpha);
+        const vec3 F = F_Schlick(Cspec, IdotH);
+        const float G2 = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha), G1 = G1_Smith_GGX(NdotI, roughnessAlpha);
+        // BRDF x cos as in directSpecularSample (microfacet.rlsl:153-220); density of the visible-normal sampler: D G1 / (4 N.I)
+        vec3 specular = (D * F * G2) / greaterThanZero(4.0f * NdotI);
+        specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+        const float pLobe = (D * G1) / greaterThanZero(4.0f * NdotI), pMap = envPdf(O);
+        vec3 reflectance = specular * in.weight;
+        reflectance = reflectance / greaterThanZero(0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / sampleProbability;
+        reflectance = reflectance / envProbability;
+        // (no 1e-5 cut-off on the weight here: an importance-sampled ray towards a bright texel carries a small weight and a large radiance)
+        if (dot(reflectance, reflectance) > 0.0f) {
+            Ray r = createRay(in, P, prim);
+            r.d = O;
+            r.weight = reflectance;
+            r.occlusionTest = true;
+            r.missKind = MISS_ENV, r.missIdx = 0;
+            r.extraT = 0.0f;
+            emit(r, nee, next);
+        }
+    }
+
     // ---- microfacet.rlsl ----
     vec3 computeMultiscattering(int lut, vec3 Cspec, float NdotI, float roughness) const // :17-23
     {
@@ -410,7 +535,10 @@ struct Shader {
                 }
             }
         } else if (ls.probability > 0.0f) {
-            indirectDiffuseSample(in, P, prim, N, Cdiff, sampleProbability, ls.probability, rand, frame, MISS_ENV, nee, next);
+            if (envMis())
+                envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, ls.probability, rand, frame, nee, next);
+            else
+                indirectDiffuseSample(in, P, prim, N, Cdiff, sampleProbability, ls.probability, rand, frame, MISS_ENV, nee, next);
         }
     }
     void indirectSpecularSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut,
@@ -478,8 +606,11 @@ struct Shader {
                 }
             }
         } else if (ls.probability > 0.0f) {
-            indirectSpecularSample(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame,
-                                   MISS_ENV, nee, next);
+            if (envMis())
+                envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame, nee, next);
+            else
+                indirectSpecularSample(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand,
+                                       frame, MISS_ENV, nee, next);
         }
     }
 
@@ -938,6 +1069,7 @@ struct Shader {
 
 void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
 {
+    if (pp.estimator == HR_ESTIMATOR_ENV_MIS) buildEnvTable(ctx);
     const int W = ctx.W, H = ctx.H, tile = ctx.tile > 0 ? ctx.tile : 32;
     const int tilesX = (W + tile - 1) / tile;
     if (nThreads <= 0) nThreads = omp_get_max_threads();
@@ -1044,6 +1176,50 @@ void ora_kat_light_sample(hr_ctx *ctx, const float N[3], const float P[3], float
     Shader::LightSample ls = sh.computeLightSample(vec3(N[0], N[1], N[2]), xi, vec3(P[0], P[1], P[2]));
     outI[0] = ls.type, outI[1] = ls.missKind, outI[2] = ls.missIdx;
     outF[0] = ls.probability, outF[1] = ls.maxDistance, outF[2] = ls.dir.x, outF[3] = ls.dir.y, outF[4] = ls.dir.z;
+}
+// HR_ESTIMATOR_ENV_MIS: light pick with the map weighed by its mean luminosity; mean luminosity of the table; density and a sample
+void ora_kat_light_sample_mis(hr_ctx *ctx, const float N[3], const float P[3], float xi, int outI[3], float outF[5])
+{
+    Context &c = contextOf(ctx);
+    buildEnvTable(c);
+    hr_pass_params pp{};
+    pp.estimator = HR_ESTIMATOR_ENV_MIS;
+    hr_pass_stats st{};
+    float px[4] = {0, 0, 0, 0};
+    Shader sh(c, pp, px, st);
+    Shader::LightSample ls = sh.computeLightSample(vec3(N[0], N[1], N[2]), xi, vec3(P[0], P[1], P[2]));
+    outI[0] = ls.type, outI[1] = ls.missKind, outI[2] = ls.missIdx;
+    outF[0] = ls.probability, outF[1] = ls.maxDistance, outF[2] = ls.dir.x, outF[3] = ls.dir.y, outF[4] = ls.dir.z;
+}
+float ora_kat_env_mean_luminosity(hr_ctx *ctx)
+{
+    Context &c = contextOf(ctx);
+    buildEnvTable(c);
+    return c.env.meanLum;
+}
+float ora_kat_env_pdf(hr_ctx *ctx, const float dir[3])
+{
+    Context &c = contextOf(ctx);
+    buildEnvTable(c);
+    hr_pass_params pp{};
+    pp.estimator = HR_ESTIMATOR_ENV_MIS;
+    hr_pass_stats st{};
+    float px[4] = {0, 0, 0, 0};
+    Shader sh(c, pp, px, st);
+    return sh.envPdf(vec3(dir[0], dir[1], dir[2]));
+}
+// out: direction[3], density per solid angle at that direction
+void ora_kat_env_sample(hr_ctx *ctx, float u1, float u2, float out[4])
+{
+    Context &c = contextOf(ctx);
+    buildEnvTable(c);
+    hr_pass_params pp{};
+    pp.estimator = HR_ESTIMATOR_ENV_MIS;
+    hr_pass_stats st{};
+    float px[4] = {0, 0, 0, 0};
+    Shader sh(c, pp, px, st);
+    vec3 d = sh.sampleEnv(u1, u2);
+    out[0] = d.x, out[1] = d.y, out[2] = d.z, out[3] = sh.envPdf(d);
 }
 // the light / miss shaders (environmentLight / directionalLight / pointLight / spotLight.rlsl) for a ray that reached its light:
 // missKind 1 env 2 directional 3 point 4 spot; out = the value performAccumulate added (clamped by maxChannelValue)

@@ -367,6 +367,33 @@ def test_passthrough_scene_full_size_pipelined(golden):
     e.close()
 
 
+@pytest.mark.parametrize("u8_env", [False, True])
+def test_env_mis_estimator_bit_exact(golden, u8_env):
+    # HR_ESTIMATOR_ENV_MIS (include/hrcore.h): the importance table of the environment map is built on the device (integer sums:
+    # order-independent) and the one-sample MIS estimator reproduces the oracle's arithmetic — bit-exact HDR buffers again
+    sc = scenes.multi_material(96, 54, bounces=4, passes=16, textured=True)
+    env = scenes.synthetic_hdri(256, 128)
+    sc.env_pixels = (np.clip(env / 50.0, 0, 1) * 255).astype(np.uint8) if u8_env else env
+    sc.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS
+    sc.lights.env_theta_rotation = 0.7
+    g, o, ge, oe = render_both(sc, 6, lut=golden["multiscatter_lut"])
+    assert_parity(g, o, "env MIS estimator, multi-material")
+    assert ge.stats().rays_any == oe.stats().rays_any
+    sc.options.estimator = ffi.HR_ESTIMATOR_REFERENCE               # switching back and forth on live engines
+    for eng in (ge, oe):
+        eng.clear()
+        for s_ in range(3):
+            eng.render_pass(sc.options.pass_params(s_))
+    ref_g, ref_o = ge.readback(), oe.readback()
+    assert_parity(ref_g, ref_o, "reference estimator after the MIS one")
+    assert ref_g.tobytes() != g.tobytes()
+    soup = scenes.triangle_soup(20000, width=64, height=36, bounces=6, passes=16, env=True)
+    soup.env_pixels = env
+    soup.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS
+    g2, o2, _, _ = render_both(soup, 5, lut=golden["multiscatter_lut"])
+    assert_parity(g2, o2, "env MIS estimator, soup with HDRI")
+
+
 def test_debug_visualizers(golden):
     sc = scenes.multi_material(64, 36, bounces=2, textured=True)
     for mode in (ffi.HR_VIS_GEOMETRIC_NORMALS, ffi.HR_VIS_UVS, ffi.HR_VIS_FINAL_NORMALS, ffi.HR_VIS_BASE_COLOR,

@@ -565,3 +565,149 @@ def test_clearcoat_lobe_is_sampled_about_the_base_normal():
         totals[name] = float(img[..., :3].sum())
     assert totals["base"] > 0.0
     assert totals["coat"] == 0.0, totals
+
+
+# ------------------------------------------------------------------------------------------------ HR_ESTIMATOR_ENV_MIS
+# The importance-sampled environment + one-sample MIS estimator (include/hrcore.h) is NOT in the reference (its shaders leave it as
+# TODOs: lightSampling.rlsl:75-77, microfacet.rlsl:94-96), so it has no text to be checked against: its contract is (1) the same
+# expectation as the reference estimator — checked against a float64 quadrature of the rendering integral written here, and (2) less
+# variance under small bright sources.
+def sun_map(w=256, h=128):
+    env = np.full((h, w, 3), 0.05, dtype=F)
+    env[100:103, 40:44] = 2000.0         # a 4 x 3 texel sun at ~52 degrees elevation, 40000 x the sky
+    return env
+
+
+def mis_plane(estimator, env, roughness, metallic, passes, size=8):
+    sc = scenes.Scene("mis_plane", width=size, height=size, use_multiscatter_lut=False)
+    p, n, uv, i = scenes.plane_strip(2000, 2000)
+    sc.materials[0] = host.bake_pbr(base_color=(0.8, 0.8, 0.8), roughness=roughness, metallic=metallic, specular_f0=0.0 if metallic == 0 else 0.5)
+    sc.meshes.append(scenes.MeshData(p, n, i, uvs=uv, mode=ffi.HR_TRIANGLE_STRIP, material_id=0))
+    sc.env_pixels = env
+    o = sc.options
+    o.max_ray_depth, o.aspect_ratio, o.fstop, o.focal_length = 1, 1.0, host.FSTOP_DISABLED, 4000.0
+    o.max_channel_value = 1e9
+    o.view_matrix = host.orbit_view_matrix(10.0, 0.3, 0.9)
+    o.max_render_passes = passes
+    o.estimator = estimator
+    return sc
+
+
+def radiance_by_quadrature(env, view, roughness, metallic, base=0.8):
+    """Outgoing radiance of the plane towards the camera: integral of BRDF x cos x (bilinearly filtered lat/long map) over the
+    hemisphere, midpoint rule in (elevation, azimuth), float64.  Lambert, or the single-scatter GGX lobe with separable Smith G."""
+    h, w = env.shape[:2]
+    e = env[..., 0].astype(np.float64)
+    V = view[:3, 2] / np.linalg.norm(view[:3, 2])
+    n_el, n_az = 2048, 4096
+    el = (np.arange(n_el) + 0.5) / n_el * math.pi / 2
+    az = (np.arange(n_az) + 0.5) / n_az * 2 * math.pi - math.pi
+    EL, AZ = np.meshgrid(el, az, indexing="ij")
+    O = np.stack([np.cos(EL) * np.sin(AZ), np.sin(EL), -np.cos(EL) * np.cos(AZ)], -1)
+    x, y = (AZ / (2 * math.pi) + 0.5) * w - 0.5, (EL / math.pi + 0.5) * h - 0.5
+    x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+    fx, fy = x - x0, y - y0
+    tx = lambda ix, iy: e[np.mod(iy, h), np.mod(ix, w)]
+    L = (tx(x0, y0) * (1 - fx) + tx(x0 + 1, y0) * fx) * (1 - fy) + (tx(x0, y0 + 1) * (1 - fx) + tx(x0 + 1, y0 + 1) * fx) * fy
+    d_omega = (math.pi / 2 / n_el) * (2 * math.pi / n_az) * np.cos(EL)
+    n_o = O[..., 1]
+    if metallic == 0:
+        f_cos = base / math.pi * n_o
+    else:
+        a = max(roughness, 0.01) ** 2
+        n_i = V[1]
+        H = O + V
+        H /= np.linalg.norm(H, axis=-1, keepdims=True)
+        n_h, i_h = H[..., 1], (H * V).sum(-1)
+        D = a * a / (np.pi * (n_h ** 2 * (a * a - 1) + 1) ** 2)
+        g1 = lambda c: 2 * c / (np.sqrt(a * a + (1 - a * a) * c * c) + c)
+        f_cos = D * (base + (1 - base) * (1 - i_h) ** 5) * g1(n_o) * g1(n_i) / (4 * n_i)
+    return float((f_cos * L * d_omega).sum())
+
+
+@pytest.mark.parametrize("roughness,metallic", [(1.0, 0.0), (0.6, 1.0)])
+def test_env_mis_estimator_is_unbiased_and_quieter(roughness, metallic):
+    env = sun_map()
+    passes = 4096
+    truth = radiance_by_quadrature(env, np.asarray(host.orbit_view_matrix(10.0, 0.3, 0.9), dtype=np.float64), roughness, metallic)
+    out = {}
+    for est in (ffi.HR_ESTIMATOR_REFERENCE, ffi.HR_ESTIMATOR_ENV_MIS):
+        img, _ = render(mis_plane(est, env, roughness, metallic, passes), passes)
+        rgb = img[..., 0] / img[..., 3]
+        out[est] = (float(rgb.mean()), float(rgb.std() / rgb.mean()))
+    ref_mean, ref_noise = out[ffi.HR_ESTIMATOR_REFERENCE]
+    mis_mean, mis_noise = out[ffi.HR_ESTIMATOR_ENV_MIS]
+    assert mis_mean == pytest.approx(truth, rel=0.01), (mis_mean, truth)        # same expectation as the rendering integral
+    assert ref_mean == pytest.approx(truth, rel=0.12), (ref_mean, truth)        # ... and so is the reference's, within ITS noise
+    assert mis_noise < 0.25 * ref_noise, (mis_noise, ref_noise)                 # pixel-to-pixel noise after 4096 passes: >= 4 x lower
+    # a short render: the reference estimator has hardly seen the sun yet, the MIS one is already within a few per cent
+    img, _ = render(mis_plane(ffi.HR_ESTIMATOR_ENV_MIS, env, roughness, metallic, 64), 64)
+    assert float((img[..., 0] / img[..., 3]).mean()) == pytest.approx(truth, rel=0.05)
+
+
+def test_env_mis_estimator_white_furnace_and_fallbacks():
+    # uniform environment: expectation E x albedo for both estimators (the reference one is exact per sample here, the MIS one in the mean)
+    env = np.full((8, 16, 3), 0.8, dtype=F)
+    img, _ = render(mis_plane(ffi.HR_ESTIMATOR_ENV_MIS, env, 1.0, 0.0, 1024), 1024)
+    assert float((img[..., :3] / img[..., 3:4]).mean()) == pytest.approx(0.8 * 0.8, rel=3e-3)
+    # without an environment light the flag changes nothing (analytic lights are sampled as in the reference)
+    sc0, sc1 = scenes.cornell_box(24, 24, bounces=3), scenes.cornell_box(24, 24, bounces=3)
+    sc1.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS
+    assert render(sc0, 2)[0].tobytes() == render(sc1, 2)[0].tobytes()
+
+
+def test_env_mis_table_density_and_light_pick():
+    # the importance table is a probability density over directions: its samples' densities integrate to 1 in the Monte-Carlo sense
+    # (E[1 / pdf] = 4 pi), bright texels are drawn in proportion to luminosity x solid angle, and the light pick weighs the map by
+    # pi x its mean luminosity next to saturate(N.L) luminosity(colour) of the analytic lights (instead of lightSampling.rlsl:74-79's 50)
+    L = lib()
+    L.ora_kat_env_mean_luminosity.restype = C.c_float
+    env = sun_map()
+    rig = host.LightRig()
+    rig.add_directional(color=(1, 1, 1), illuminance=683.0 * 2.0, phi=0.0, theta=math.pi / 2)   # straight up, colour 2
+    eng = oracle_lib.engine()
+    eng.resize(8, 8)
+    tid = eng.create_texture(env, wrap=ffi.HR_WRAP_REPEAT)
+    rig.set_environment(tid, 0.0, 0.3)
+    eng.set_lights(rig.bake())
+    out = (C.c_float * 4)()
+    n = 128
+    u = (np.arange(n) + 0.5) / n
+    inv_pdf, in_sun = [], 0
+    h, w = env.shape[:2]
+    for a in u:
+        for b in u:
+            L.ora_kat_env_sample(eng._ctx, C.c_float(a), C.c_float(b), out)
+            d = np.array(out[:3])
+            assert np.linalg.norm(d) == pytest.approx(1.0, abs=1e-5)
+            inv_pdf.append(1.0 / out[3])
+            uu, tt = latlong_uv(d, 0.3)
+            i, j = int((uu % 1.0) * w), int(tt * h)
+            in_sun += 39 <= i <= 44 and 99 <= j <= 103          # the sun block and its bilinear halo
+    # the density integrates to one over the sphere (midpoint rule on the map's own grid, through the direction -> texel lookup)
+    L.ora_kat_env_pdf.restype = C.c_float
+    total = 0.0
+    for j in range(0, h):
+        el = ((j + 0.5) / h - 0.5) * math.pi
+        for i in range(0, w, 1):
+            az = ((i + 0.5) / w - 0.5) * 2 * math.pi - 0.3
+            d = (math.cos(el) * math.sin(az), math.sin(el), -math.cos(el) * math.cos(az))
+            total += float(L.ora_kat_env_pdf(eng._ctx, f3(*d))) * (2 * math.pi / w) * (math.pi / h) * math.cos(el)
+    assert total == pytest.approx(1.0, rel=2e-3)
+    # expected share of the (dilated) sun: its weight over the total, from the map itself
+    lum = env[..., 0].astype(np.float64) * 1.03
+    dil = np.maximum.reduce([np.roll(np.roll(np.pad(lum, ((1, 1), (0, 0)), mode="edge"), dx, 1), dy, 0)[1:-1] for dx in (-1, 0, 1) for dy in (-1, 0, 1)])
+    cos_row = np.cos(((np.arange(h) + 0.5) / h - 0.5) * math.pi)[:, None]
+    wt = (dil + lum.max() / 65536.0) * cos_row
+    share = wt[99:104, 39:45].sum() / wt.sum()
+    assert in_sun / (n * n) == pytest.approx(share, abs=0.02)
+    mean_lum = float(L.ora_kat_env_mean_luminosity(eng._ctx))
+    assert mean_lum == pytest.approx(float(wt.sum() / (w * cos_row.sum())), rel=2e-3)
+    oi, of = (C.c_int * 3)(), (C.c_float * 5)()
+    L.ora_kat_light_sample_mis(eng._ctx, f3(0, 1, 0), f3(0, 0, 0), C.c_float(0.999), oi, of)
+    w_dir, w_env = 1.0 * (0.33 + 0.59 + 0.11) * 2.0, mean_lum * math.pi
+    assert oi[0] == 4 and of[0] == pytest.approx(w_env / (w_dir + w_env), rel=1e-4)      # the environment, with its power-based probability
+    L.ora_kat_light_sample_mis(eng._ctx, f3(0, 1, 0), f3(0, 0, 0), C.c_float(0.001), oi, of)
+    assert oi[0] == 1 and of[0] == pytest.approx(w_dir / (w_dir + w_env), rel=1e-4)
+    s = light_sample(eng, (0, 1, 0), (0, 0, 0), 0.999)                                   # the reference estimator keeps the constant 50
+    assert s["type"] == 4 and s["prob"] == pytest.approx(50.0 / (50.0 + w_dir), rel=1e-4)
