@@ -12,11 +12,11 @@ cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
 python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 echo "[profile] plain bench done"
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
 echo "[profile] kernel trace done"
 for pass in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum" "sq:SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
   name="${pass%%:*}"; ctrs="${pass#*:}"
-  rocprofv3 --kernel-trace --pmc $ctrs -d "$OUT/$name" -o "$name" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.err" || { echo "[profile] pass $name failed"; tail -5 "$OUT/$name.err"; }
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $ctrs -d "$OUT/$name" -o "$name" --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_$name.json" 2> "$OUT/$name.err" || { echo "[profile] pass $name failed"; tail -5 "$OUT/$name.err"; }
   echo "[profile] pmc pass $name done"
 done
 # keep the merge small: only the csv summaries travel back

@@ -72,6 +72,7 @@ def main():
                                  "WRITE_SIZE, streamed_queue_bytes = 48 B x rays per launch" % tag,
             "streamed_queue_read_bytes_per_launch": streamed,
             "k_trace_hbm_bytes_per_launch": (fetch_kb + write_kb) * 1024.0 + 0.5 * streamed,
+            "k_trace_hbm_bytes_per_ray": ((fetch_kb + write_kb) * 1024.0 + 0.5 * streamed) / rays_per_launch if rays_per_launch else None,
             "k_trace_hbm_bytes_fullest_launch": (tr["FETCH_SIZE"]["max"] + tr["WRITE_SIZE"]["max"]) * 1024.0 + 0.5 * streamed,
             "note": "FETCH_SIZE counts L2 -> fabric requests; lines served by the 256 MiB Infinity Cache are included (the guide: 'hits appear to be "
                     "counted, not excluded'), so this is an upper bound of what reaches HBM (scene + BVH = ~120 MB stay cache-resident)",
