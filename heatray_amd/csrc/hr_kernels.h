@@ -47,7 +47,7 @@ struct SegDev {
 #ifndef HR_MAX_SEGS
 #define HR_MAX_SEGS 120
 #endif
-static const int kMaxSegs = HR_MAX_SEGS; // in-flight passes of one group: (passes injected per macro step) x (stages per pass); <= 127 (buildSegStarts)
+static const int kMaxSegs = HR_MAX_SEGS; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
 struct StepTable {
     uint32_t traceHead; // work cursor of the persistent trace kernel (reset with every table upload)
     int32_t nSeg;

@@ -211,11 +211,15 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
     __syncthreads();
     if (threadIdx.x < 64) {
         const int m = 2 * n; // entries to scan; entry m receives the total
-        const int first = (int)threadIdx.x * 4;
-        uint32_t v[4];
+        constexpr int kPer = (2 * kMaxSegs + 1 + 63) / 64; // entries per lane of the first wave
+        const int first = (int)threadIdx.x * kPer;
+        uint32_t v[kPer];
+        uint32_t sum = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (first + j < m) ? segStart[first + j] : 0u;
-        const uint32_t sum = v[0] + v[1] + v[2] + v[3];
+        for (int j = 0; j < kPer; ++j) {
+            v[j] = (first + j < m) ? segStart[first + j] : 0u;
+            sum += v[j];
+        }
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -224,7 +228,7 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
         }
         uint32_t acc = incl - sum;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < kPer; ++j) {
             if (first + j <= m) segStart[first + j] = acc;
             acc += v[j];
         }
