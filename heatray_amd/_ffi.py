@@ -153,7 +153,7 @@ ABI_SYMBOLS = [
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
     "display", "display_readback", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
-    "frame_pass_batch", "interactive_blocks_set",
+    "frame_pass_batch", "interactive_blocks_set", "scene_cache",
 ]
 
 
@@ -275,6 +275,9 @@ class Engine:
 
     def clear_scene(self):
         self._call("scene_clear")
+
+    def set_scene_cache(self, path):
+        self._call("scene_cache", None if not path else str(path).encode())
 
     def commit(self):
         self._call("scene_commit")

@@ -767,6 +767,30 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     return rc;
 }
 
+// ------------------------------------------------------------------------------------ content hash
+// Order-independent 64-bit digest of a device buffer (words mixed with their index, then summed): the key of the tree cache.
+__global__ __launch_bounds__(256) void k_hash_words(const uint32_t *__restrict__ words, size_t n, unsigned long long seed,
+                                                    unsigned long long *__restrict__ out)
+{
+    unsigned long long acc = 0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        unsigned long long z = ((unsigned long long)words[i] << 32 | (unsigned long long)(i & 0xFFFFFFFFull)) + seed + (i >> 32) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; // splitmix64 finaliser
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        acc += z ^ (z >> 31);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+void launchHashWords(hipStream_t st, const void *words, size_t nWords, unsigned long long seed, unsigned long long *out)
+{
+    if (!nWords) return;
+    size_t blocks = (nWords + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_hash_words, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<const uint32_t *>(words), nWords, seed, out);
+}
+
 // ------------------------------------------------------------------ environment importance table (HR_ESTIMATOR_ENV_MIS)
 // The distribution the one-sample MIS estimator draws environment directions from (include/hrcore.h): texel weight =
 // (luminosity of the brightest texel of its 3 x 3 neighbourhood + maxLuminosity / 65536) x cos(elevation of the row), quantised to

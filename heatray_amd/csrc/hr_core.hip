@@ -7,6 +7,7 @@
 #include "hr_trace.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -166,6 +167,7 @@ struct hr_ctx {
     SceneConsts *dConsts = nullptr;
     SceneConsts *hConsts = nullptr; // pinned
     float builtAreaPerDiag2 = 0.0f; // areaSum / diag^2 right after the last full build (refit quality reference)
+    std::string cachePath;          // hr_scene_cache
     // pinned staging ring for mesh uploads
     char *stage[2] = {nullptr, nullptr};
     hipEvent_t stageEv[2] = {nullptr, nullptr};
@@ -800,6 +802,103 @@ int hr_scene_clear(hr_ctx *c)
     return HR_OK;
 }
 
+// ---- tree cache file (hr_scene_cache): header + nodes + node boxes + prim -> slot map
+namespace {
+struct CacheHeader {
+    char magic[8];
+    uint32_t version, nodeBytes;
+    unsigned long long key;
+    uint32_t nTris, nNodes, levels, rootLeafCount, triSlots, pad;
+    uint32_t levelStart[kMaxLevels + 1];
+};
+const uint32_t kCacheVersion = 2;
+} // namespace
+
+// digest of everything the tree depends on: geometry bytes (hashed on the device), transforms, modes, strides
+static int sceneKey(hr_ctx *c, unsigned long long *key)
+{
+    unsigned long long *dKey = nullptr;
+    HIP_TRY(c, hipMalloc(&dKey, 8));
+    hipError_t e = hipMemsetAsync(dKey, 0, 8, c->stream);
+    unsigned long long host = 0xC0FFEE1234ull;
+    auto mix = [&](const void *p, size_t bytes) {
+        const unsigned char *b = (const unsigned char *)p;
+        for (size_t i = 0; i < bytes; ++i) host = (host ^ b[i]) * 0x100000001B3ull; // FNV-1a over the small host-side fields
+    };
+    unsigned long long seed = 1;
+    for (const Geom &g : c->geoms) {
+        if (!g.alive || g.nTris() == 0) continue;
+        mix(&g.nVerts, sizeof(g.nVerts)), mix(&g.nIdx, sizeof(g.nIdx)), mix(&g.mode, sizeof(g.mode)), mix(g.world, sizeof(g.world));
+        mix(g.stride, sizeof(g.stride)), mix(g.off, sizeof(g.off)), mix(g.has, sizeof(g.has));
+        if (e == hipSuccess) launchHashWords(c->stream, g.dBlock, g.blockBytes / 4, seed++, dKey);
+    }
+    unsigned long long dev = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&dev, dKey, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dKey);
+    HIP_TRY(c, e);
+    *key = host ^ (dev * 0x9E3779B97F4A7C15ull);
+    return HR_OK;
+}
+
+// read the tree of this scene from the cache file; false: no usable file (the caller builds)
+static bool loadTree(hr_ctx *c, unsigned long long key, uint32_t nTris, BuildResult *out)
+{
+    FILE *f = fopen(c->cachePath.c_str(), "rb");
+    if (!f) return false;
+    CacheHeader h;
+    bool ok = fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "HRBVHTR", 8) == 0 && h.version == kCacheVersion &&
+              h.nodeBytes == sizeof(Node4) && h.key == key && h.nTris == nTris && h.nNodes > 0 && h.levels <= (uint32_t)kMaxLevels;
+    std::vector<char> buf;
+    BuildResult br{};
+    if (ok) {
+        const size_t nb = (size_t)h.nNodes * sizeof(Node4), bb = (size_t)h.nNodes * sizeof(Box6), sb = (size_t)nTris * 4;
+        buf.resize(nb + bb + sb);
+        ok = fread(buf.data(), 1, buf.size(), f) == buf.size();
+        if (ok) {
+            ok = hipMalloc(&br.nodes, nb) == hipSuccess && hipMalloc(&br.nodeBox, bb) == hipSuccess && hipMalloc(&br.slotOfPrim, sb) == hipSuccess &&
+                 hipMalloc(&br.tris, sizeof(Tri) * (size_t)h.triSlots) == hipSuccess;
+            ok = ok && hipMemcpy(br.nodes, buf.data(), nb, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(br.nodeBox, buf.data() + nb, bb, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(br.slotOfPrim, buf.data() + nb + bb, sb, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemset(br.tris, 0xFF, sizeof(Tri) * (size_t)h.triSlots) == hipSuccess;
+        }
+    }
+    fclose(f);
+    if (!ok) {
+        hipFree(br.nodes), hipFree(br.nodeBox), hipFree(br.slotOfPrim), hipFree(br.tris);
+        return false;
+    }
+    br.nNodes = (int32_t)h.nNodes, br.levels = (int32_t)h.levels, br.rootLeafCount = (int32_t)h.rootLeafCount, br.triSlots = h.triSlots;
+    std::memcpy(br.levelStart, h.levelStart, sizeof(br.levelStart));
+    *out = br;
+    return true;
+}
+
+static void saveTree(hr_ctx *c, unsigned long long key, uint32_t nTris, const BuildResult &br)
+{
+    if (br.nNodes <= 0) return;
+    const size_t nb = (size_t)br.nNodes * sizeof(Node4), bb = (size_t)br.nNodes * sizeof(Box6), sb = (size_t)nTris * 4;
+    std::vector<char> buf(nb + bb + sb);
+    if (hipMemcpy(buf.data(), br.nodes, nb, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(buf.data() + nb, br.nodeBox, bb, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(buf.data() + nb + bb, br.slotOfPrim, sb, hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    CacheHeader h{};
+    std::memcpy(h.magic, "HRBVHTR", 8);
+    h.version = kCacheVersion, h.nodeBytes = sizeof(Node4), h.key = key, h.nTris = nTris, h.nNodes = (uint32_t)br.nNodes, h.levels = (uint32_t)br.levels;
+    h.rootLeafCount = (uint32_t)br.rootLeafCount, h.triSlots = br.triSlots;
+    std::memcpy(h.levelStart, br.levelStart, sizeof(h.levelStart));
+    const std::string tmp = c->cachePath + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;
+    const bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+    fclose(f);
+    if (ok)
+        rename(tmp.c_str(), c->cachePath.c_str());
+    else
+        remove(tmp.c_str());
+}
+
 // Device temporaries and timing events of one commit: released on every exit path.
 namespace {
 struct CommitScratch {
@@ -865,6 +964,7 @@ int hr_scene_commit(hr_ctx *c)
         HIP_TRY(c, hipMemcpyAsync(c->dG, gd.data(), gd.size() * sizeof(GeomDev), hipMemcpyHostToDevice, c->stream));
         // A commit after transform edits only keeps the tree's topology: triangles are re-assembled straight into their leaf
         // slots and every level is refitted bottom-up.  No allocation, no host round trip before the last kernel.
+        bool cacheHit = false;
         bool refit = c->tuneRefit && !c->topologyDirty && c->tree.nodes && c->treeTris == nTris && c->tree.rootLeafCount == 0;
         if (refit) {
             launchAssemble(c->stream, c->dG, (int)gd.size(), nTris, c->tree.tris, c->tree.slotOfPrim, c->attrs, ext, c->dScratch);
@@ -887,11 +987,25 @@ int hr_scene_commit(hr_ctx *c)
             HIP_TRY(c, hipMemcpyAsync(c->hConsts, c->dConsts, sizeof(SceneConsts), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             const SceneConsts k = *c->hConsts;
-            const int brc = buildLBVH(c->stream, c->trisPrim, nTris, k.lo, k.hi, k.pad, c->dConsts, &cs.br);
-            if (brc != 0) FAIL(c, HR_ERR_DEVICE, brc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
+            unsigned long long key = 0;
+            bool fromCache = false;
+            if (!c->cachePath.empty()) {
+                rc = sceneKey(c, &key);
+                if (rc != HR_OK) return rc;
+                fromCache = loadTree(c, key, nTris, &cs.br);
+            }
+            if (fromCache) { // the tree is this scene's: only the triangles have to be put into their leaf slots
+                launchAssemble(c->stream, c->dG, (int)gd.size(), nTris, cs.br.tris, cs.br.slotOfPrim, c->attrs, ext, c->dScratch);
+                launchSceneConsts(c->stream, c->dScratch, c->dConsts, nullptr);
+                cacheHit = true;
+            } else {
+                const int brc = buildLBVH(c->stream, c->trisPrim, nTris, k.lo, k.hi, k.pad, c->dConsts, &cs.br);
+                if (brc != 0) FAIL(c, HR_ERR_DEVICE, brc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
+                if (!c->cachePath.empty()) saveTree(c, key, nTris, cs.br);
+            }
             // the traversal stack holds at most 3 entries per level of inner nodes (hr_trace.h)
             if (3 * cs.br.levels > kStackLDS + kStackOvf) FAIL(c, HR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
-        if (cs.br.triSlots >= (1u << 28)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: triangle slots do not fit a 28-bit leaf reference");
+            if (cs.br.triSlots >= (1u << 28)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: triangle slots do not fit a 28-bit leaf reference");
             freeTree(c);
             c->tree = cs.br, cs.keepBuild = true;
             c->treeTris = nTris;
@@ -909,7 +1023,7 @@ int hr_scene_commit(hr_ctx *c)
         for (int q = 0; q < 3; ++q) c->info.aabb_min[q] = k.lo[q], c->info.aabb_max[q] = k.hi[q];
         c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)c->tree.nNodes, c->info.ray_epsilon = k.eps;
         c->info.bvh_levels = (uint32_t)c->tree.levels;
-        c->info.refitted = refit ? 1u : 0u;
+        c->info.refitted = refit ? 1u : (cacheHit ? 2u : 0u);
     }
     HIP_TRY(c, hipEventRecord(cs.e1, c->stream));
     HIP_TRY(c, hipEventSynchronize(cs.e1));
@@ -917,6 +1031,13 @@ int hr_scene_commit(hr_ctx *c)
     c->committed = true;
     c->sceneDirty = true;
     c->topologyDirty = false, c->transformDirty = false;
+    return HR_OK;
+}
+
+int hr_scene_cache(hr_ctx *c, const char *path)
+{
+    ENTER(c);
+    c->cachePath = path ? path : "";
     return HR_OK;
 }
 
@@ -1253,17 +1374,27 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
 {
     const size_t cap = c->queueCapacity ? c->queueCapacity : 1;
     const size_t n16 = cap * 16;
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(c, hipMalloc(&ps.q[i].A, n16));
-        HIP_TRY(c, hipMalloc(&ps.q[i].B, n16));
-        HIP_TRY(c, hipMalloc(&ps.q[i].C, n16));
-        HIP_TRY(c, hipMalloc(&ps.q[i].D, n16));
+    const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc(&ps.q[i].A, n16);
+        if (e == hipSuccess) e = hipMalloc(&ps.q[i].B, n16);
+        if (e == hipSuccess) e = hipMalloc(&ps.q[i].C, n16);
+        if (e == hipSuccess) e = hipMalloc(&ps.q[i].D, n16);
     }
-    HIP_TRY(c, hipMalloc(&ps.sq.A, n16));
-    HIP_TRY(c, hipMalloc(&ps.sq.B, n16));
-    HIP_TRY(c, hipMalloc(&ps.sq.C, n16));
-    HIP_TRY(c, hipMalloc(&ps.hits, cap * hitRecordSize()));
-    HIP_TRY(c, hipMalloc(&ps.passbuf, (size_t)c->W * c->H * 4 * sizeof(float)));
+    if (e == hipSuccess) e = hipMalloc(&ps.sq.A, n16);
+    if (e == hipSuccess) e = hipMalloc(&ps.sq.B, n16);
+    if (e == hipSuccess) e = hipMalloc(&ps.sq.C, n16);
+    if (e == hipSuccess) e = hipMalloc(&ps.hits, cap * hitRecordSize());
+    if (e == hipSuccess) e = hipMalloc(&ps.passbuf, fbBytes);
+    if (e != hipSuccess) { // say what ran out: a pass slot is the unit the pipeline's memory grows in
+        size_t freeB = 0, totalB = 0;
+        hipMemGetInfo(&freeB, &totalB);
+        c->err = "pass slot " + std::to_string(c->nSlotsAllocated + 1) + " (" + std::to_string((11 * n16 + cap * hitRecordSize() + fbBytes) >> 20) +
+                 " MiB of ray queues and pass buffer at " + std::to_string(c->W) + "x" + std::to_string(c->H) + "): " + hipGetErrorString(e) + "; " +
+                 std::to_string(freeB >> 20) + " MiB of device memory free";
+        return HR_ERR_DEVICE;
+    }
     ps.ctr = c->dCounters + (&ps - c->slots);
     HIP_TRY(c, hipEventCreateWithFlags(&ps.evFinal, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&ps.evResolved, hipEventDisableTiming));

@@ -136,6 +136,8 @@ int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const fl
 // Refit: the tree keeps its topology; every node's child boxes are recomputed bottom-up from the triangles in `tree.tris`
 // (already moved by launchAssemble) and re-quantised.  Level by level, no host synchronisation.
 void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts);
+// order-independent 64-bit digest of a device buffer, added to *out (device)
+void launchHashWords(hipStream_t st, const void *words, size_t nWords, unsigned long long seed, unsigned long long *out);
 void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts);
 
 // environment importance table (HR_ESTIMATOR_ENV_MIS): scratch and outputs are caller-owned device arrays

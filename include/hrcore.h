@@ -124,6 +124,13 @@ int hr_scene_clear(hr_ctx *ctx);
  * vertex (vertex.rlsl:25-43), Morton codes, radix sort, LBVH, refit. */
 int hr_scene_commit(hr_ctx *ctx);
 
+/* Acceleration-structure cache.  With a path set, a commit that would build the tree first looks for the file: if
+ * it holds the tree of exactly this scene (a content hash of every mesh block — computed on the device — the transforms, modes and the
+ * node format), the tree is read and uploaded instead of built, and only the triangles are re-assembled; otherwise the tree is built and
+ * the file (re)written.  NULL or "" switches the cache off.  Worth it for large scenes (a 30 M-triangle build takes about a second); for
+ * a million triangles the 5 ms device build is as fast as reading the file. */
+int hr_scene_cache(hr_ctx *ctx, const char *path);
+
 typedef struct hr_scene_info {
     uint64_t n_triangles;
     uint64_t n_nodes;
@@ -132,7 +139,8 @@ typedef struct hr_scene_info {
     float ray_epsilon; /* self-intersection t_min, 1e-4 * |aabb diagonal| */
     float build_ms;
     uint32_t bvh_levels; /* levels of inner nodes of the acceleration structure (0 for the oracle's brute force / a leaf root) */
-    uint32_t refitted;   /* 1: the last commit kept the tree's topology and refitted its boxes (transform-only edits) */
+    uint32_t refitted;   /* 1: the last commit kept the tree's topology and refitted its boxes (transform-only edits);
+                          * 2: the tree came from the cache file (hr_scene_cache) */
 } hr_scene_info;
 int hr_scene_get_info(hr_ctx *ctx, hr_scene_info *out);
 

@@ -151,6 +151,8 @@ int ora_scene_commit(hr_ctx *ctx)
     (void)t0;
     return HR_OK;
 }
+int ora_scene_cache(hr_ctx *, const char *) { return HR_OK; } // the oracle always builds
+
 int ora_scene_get_info(hr_ctx *ctx, hr_scene_info *out)
 {
     if (!ctx->c.committed) ORA_FAIL(ctx, HR_ERR_INVALID, "scene not committed");

@@ -28,6 +28,7 @@ int hr_geom_remove(hr_ctx *, hr_geom_id) { return HR_OK; }
 int hr_geom_set_transform(hr_ctx *, hr_geom_id, const float[16]) { return HR_OK; }
 int hr_scene_clear(hr_ctx *) { return HR_OK; }
 int hr_scene_commit(hr_ctx *) { return HR_OK; }
+int hr_scene_cache(hr_ctx *, const char *) { return HR_OK; }
 int hr_scene_get_info(hr_ctx *, hr_scene_info *o) { std::memset(o, 0, sizeof(*o)); return HR_OK; }
 int hr_texture_create(hr_ctx *c, const hr_texture_desc *, const void *, hr_tex_id *out) { if (out) *out = c->nTextures; c->nTextures++; return HR_OK; }
 int hr_texture_destroy(hr_ctx *, hr_tex_id) { return HR_OK; }

@@ -405,6 +405,29 @@ def test_debug_visualizers(golden):
     sc.options.show_nans = True
     g, o, _, _ = render_both(sc, 1, lut=golden["multiscatter_lut"])
     assert_parity(g, o, "nan visualizer")
+    sc.options.show_nans, sc.options.show_inf = False, True          # accumulator.rlsl:16-21, the Inf detector
+    g, o, _, _ = render_both(sc, 1, lut=golden["multiscatter_lut"])
+    assert_parity(g, o, "inf visualizer")
+    sc.options.show_inf = False
+    # the remaining modes need tangent space / a normal map / clearcoat maps: a mesh with tangents and every texture slot filled
+    rng = np.random.default_rng(17)
+    tex = lambda c: ((rng.uniform(0.2, 1.0, (16, 16, c)) * 255).astype(np.uint8), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_LINEAR)
+    sc2 = scenes.multi_material(64, 36, bounces=2)
+    sc2.textures = [tex(4), tex(3), tex(3), tex(3), tex(1), tex(1), tex(3)]
+    sc2.materials[3] = host.bake_pbr(base_color=(0.7, 0.6, 0.5), roughness=0.5, metallic=0.2, clear_coat=1.0, clear_coat_roughness=0.3,
+                                     base_color_texture=0, metallic_roughness_texture=1, emissive_texture=2, normalmap=3,
+                                     clear_coat_texture=4, clear_coat_roughness_texture=5, clear_coat_normalmap=6)
+    for me in sc2.meshes:
+        n = me.positions.shape[0]
+        me.tangents = np.tile(np.array([1, 0, 0], np.float32), (n, 1))
+        me.bitangents = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+        me.material_id = 3
+    for mode in (ffi.HR_VIS_TANGENTS, ffi.HR_VIS_BITANGENTS, ffi.HR_VIS_NORMALMAP, ffi.HR_VIS_EMISSIVE, ffi.HR_VIS_CLEARCOAT,
+                 ffi.HR_VIS_CLEARCOAT_ROUGHNESS, ffi.HR_VIS_CLEARCOAT_NORMALMAP):
+        sc2.options.visualizer_mode = mode
+        g, o, _, _ = render_both(sc2, 1, lut=golden["multiscatter_lut"])
+        assert_parity(g, o, f"visualizer {mode}")
+        assert g[..., :3].max() > 0.0, mode                            # the mode really drew something
 
 
 def test_interactive_block_mode(golden):
@@ -849,6 +872,51 @@ def test_hundred_random_edit_steps_refit_and_rebuild(golden):
                     eng.render_pass(sc.options.pass_params(s_))
             assert_parity(g.readback(), o.readback(), f"render after edit step {step} ({kind})")
     assert refits >= 40 and rebuilds >= 5, (refits, rebuilds)
+
+
+def test_tree_cache_round_trip(tmp_path):
+    # hr_scene_cache: the tree of a scene is written on the first commit and read back — after a device-side content hash of the
+    # meshes matched — by the next context; a changed scene misses; hits never depend on where the tree came from
+    sc = scenes.triangle_soup(30000, width=32, height=32, n_materials=4)
+    path = tmp_path / "scene.hrbvh"
+    rng = np.random.default_rng(8)
+    org = rng.uniform(-1.2, 1.2, (8000, 3)).astype(np.float32)
+    d = rng.normal(size=(8000, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = oracle_lib.engine()
+    sc.apply(o)
+    want = o.debug_trace(org, d)
+    a = core.create_engine()
+    a.set_scene_cache(path)
+    sc.apply(a)
+    assert a.scene_info().refitted == 0 and path.exists() and path.stat().st_size > 30000 * 4
+    assert a.debug_trace(org, d).tobytes() == want.tobytes()
+    b = core.create_engine()
+    b.set_scene_cache(path)
+    sc.apply(b)
+    assert b.scene_info().refitted == 2                                   # read, not built
+    assert b.scene_info().n_nodes == a.scene_info().n_nodes
+    assert b.debug_trace(org, d).tobytes() == want.tobytes()
+    b.set_transform(0, scenes._translate(0.01, 0.0, 0.0))                 # a cached tree refits like a built one
+    b.commit()
+    o.set_transform(0, scenes._translate(0.01, 0.0, 0.0))
+    o.commit()
+    assert b.scene_info().refitted == 1
+    assert b.debug_trace(org, d).tobytes() == o.debug_trace(org, d).tobytes()
+    sc2 = scenes.triangle_soup(30000, width=32, height=32, n_materials=4, seed=scenes.SEED + 1)   # other geometry, same counts
+    c2 = core.create_engine()
+    c2.set_scene_cache(path)
+    sc2.apply(c2)
+    assert c2.scene_info().refitted == 0                                  # key mismatch: built (and the file replaced)
+    o2 = oracle_lib.engine()
+    sc2.apply(o2)
+    assert c2.debug_trace(org, d).tobytes() == o2.debug_trace(org, d).tobytes()
+    path.write_bytes(path.read_bytes()[:1000])                            # a truncated file is ignored
+    c3 = core.create_engine()
+    c3.set_scene_cache(path)
+    sc2.apply(c3)
+    assert c3.scene_info().refitted == 0
+    assert c3.debug_trace(org, d).tobytes() == o2.debug_trace(org, d).tobytes()
 
 
 def test_strided_and_interleaved_vertex_buffers(golden):

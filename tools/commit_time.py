@@ -42,5 +42,22 @@ for label, tune in (("refit", ""), ("rebuild", "refit=0")):
     out[f"{label}_recommit_wall_ms"] = walls
     out[f"{label}_recommit_device_ms"] = devs
     eng.close()
+# tree cache (hr_scene_cache): first commit writes the file, a second context reads it
+import tempfile
+path = os.path.join(tempfile.mkdtemp(dir="/tmp"), "scene.hrbvh")
+os.environ["HR_TUNE"] = ""
+for label in ("cache_miss_and_write", "cache_hit"):
+    eng = core.create_engine()
+    eng.resize(sc.width, sc.height)
+    eng.set_scene_cache(path)
+    for me in sc.meshes:
+        eng.add_mesh(me.positions, me.normals, me.indices, material_id=me.material_id)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    eng.commit()
+    out[f"{label}_commit_wall_ms"] = (time.perf_counter() - t0) * 1e3
+    out[f"{label}_refitted_flag"] = int(eng.scene_info().refitted)
+    eng.close()
+out["cache_file_mb"] = os.path.getsize(path) / 1e6
 import json
 print(json.dumps(out))
