@@ -97,6 +97,8 @@ def random_scene(seed):
     r = rng.random()
     if r < 0.4:
         sc.env_pixels = scenes.synthetic_hdri(64, 32)
+        if rng.random() < 0.3:                                   # an 8-bit map (stays 8-bit on the device)
+            sc.env_pixels = (np.clip(sc.env_pixels / 50.0, 0, 1) * 255).astype(np.uint8)
         sc.lights.env_theta_rotation = float(rng.uniform(0, 6))
         sc.env_exposure_compensation = float(rng.uniform(-2, 2))
     elif r < 0.7:
@@ -113,6 +115,8 @@ def random_scene(seed):
     o.fstop = float(rng.choice([host.FSTOP_DISABLED, 1.4, 2.8, 8.0]))
     o.sample_mode = int(rng.choice([ffi.HR_SAMPLE_SOBOL, ffi.HR_SAMPLE_HALTON, ffi.HR_SAMPLE_HAMMERSLEY]))
     o.max_channel_value = float(F(rng.choice([math.pi, 1.0, 50.0])))
+    # the importance-sampled environment + MIS estimator (include/hrcore.h) on a part of the scenes (a no-op without a map)
+    o.estimator = ffi.HR_ESTIMATOR_ENV_MIS if rng.random() < 0.4 else ffi.HR_ESTIMATOR_REFERENCE
     return sc
 
 
@@ -146,6 +150,35 @@ def test_random_scene_parity(golden, seed):
     # and what the viewer would show of it
     P = ffi.display_params(tonemapping_enabled=bool(seed & 1), exposure=0.5 * (seed % 5 - 2), saturation=1.0 + 0.1 * (seed % 3))
     assert g.display(P, ffi.HR_DISPLAY_RGBA8).tobytes() == o.display(P, ffi.HR_DISPLAY_RGBA8).tobytes()
+
+
+@pytest.mark.parametrize("seed", range(max(8, int(os.environ.get("HR_FUZZ_SEEDS", "40")) // 4)))
+def test_random_scene_edit_sequences(golden, seed):
+    # transform edits between passes: the HIP core refits (or, when the boxes degenerate, rebuilds) its tree, the oracle rebuilds;
+    # every state must render bit-identically
+    rng = np.random.default_rng(9000 + seed)
+    sc = random_scene(3000 + seed)
+    g, o = core.create_engine(), oracle_lib.engine()
+    for eng in (g, o):
+        sc.apply(eng, lut=golden["multiscatter_lut"])
+    n_pass = 0
+    for round_ in range(4):
+        for eng in (g, o):
+            for s in range(2):
+                eng.render_pass(sc.options.pass_params(n_pass + s))
+        n_pass += 2
+        a, b = g.readback(), o.readback()
+        assert a.tobytes() == b.tobytes(), f"seed {seed} round {round_}: {int((a != b).any(axis=-1).sum())} pixels differ"
+        for gid in rng.choice(len(sc.meshes), size=int(rng.integers(1, len(sc.meshes) + 1)), replace=False):
+            m = np.eye(4, dtype=F)
+            m[:3, :3] = (np.diag(rng.uniform(0.8, 1.25, 3)) @ _rot(rng)).astype(F) if rng.random() < 0.5 else np.eye(3, dtype=F)
+            m[:3, 3] = rng.uniform(-0.4, 0.4, 3)
+            base = sc.meshes[int(gid)].world if sc.meshes[int(gid)].world is not None else np.eye(4, dtype=F)
+            w = (m @ base).astype(F)
+            g.set_transform(int(gid), w), o.set_transform(int(gid), w)
+        g.commit(), o.commit()
+        assert list(g.scene_info().aabb_min) == list(o.scene_info().aabb_min) and g.scene_info().ray_epsilon == o.scene_info().ray_epsilon
+        g.clear(), o.clear()
 
 
 def _clustered_soup(rng, n_tris):
