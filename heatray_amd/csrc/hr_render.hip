@@ -237,9 +237,17 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
 }
 
 
+#ifndef HR_TAIL_SHARE
+#define HR_TAIL_SHARE 1 // idle lanes take over subtrees of their wave's remaining rays once the work queue is empty
+#endif
+#ifndef HR_TAIL_ROUNDS
+#define HR_TAIL_ROUNDS 3
+#endif
+static const unsigned long long kNoHitKey = ~0ull;
+
 #ifdef HR_TAILPROF
 // Experiment builds only: when does the work queue run dry, when does the launch end, how long is the longest ray?
-__device__ unsigned long long g_tailprof[8]; // [0] min start clock, [1] min exhaustion clock, [2] max end clock, [3] max steps of a ray, [4] sum steps, [5] rays
+__device__ unsigned long long g_tailprof[24]; // [0] min start clock, [1] min exhaustion clock, [2] max end clock, [3] max steps of a ray, [4] sum steps, [5] rays
 #endif
 
 template <bool STATS>
@@ -248,6 +256,13 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
 {
     __shared__ int stack[kWavesPerBlock][kStackLDS][64];
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
+#if HR_TAIL_SHARE
+    // merge slots of the drain phase (below): one per ray a wave held when the work queue ran dry
+    __shared__ unsigned long long mKey[kWavesPerBlock][64]; // min over the ray's fragments of (t bits, prim, face bit); kNoHitKey: none
+    __shared__ uint32_t mCount[kWavesPerBlock][64];         // fragments still traversing
+    __shared__ float2 mUV[kWavesPerBlock][64];              // barycentrics that belong to mKey
+    __shared__ uint32_t mDonor[kWavesPerBlock][64];         // k-th donating lane of this round
+#endif
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
     buildSegStarts(tbl, segStart, false);
@@ -283,11 +298,15 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     uint32_t nvC = 0, ntC = 0, nvA = 0, ntA = 0, nacc = 0;
 
     int pend = 0; // postponed leaf (a negative leaf reference) or 0: the lane keeps descending while a leaf waits
+#if HR_TAIL_SHARE
+    uint32_t slot = lane;  // merge slot of the ray (fragment) this lane holds during the drain phase
+    bool draining = false; // wave-uniform: the merge slots are initialised
+#endif
 #ifdef HR_TAILPROF
     const unsigned long long tStart = wall_clock64();
     unsigned long long tExh = 0;
     uint32_t mySteps = 0, maxSteps = 0;
-    unsigned long long sumSteps = 0, nRays = 0;
+    unsigned long long sumSteps = 0, nRays = 0, nGiven = 0;
 #endif
     for (;;) {
         // ---------------- refill idle lanes (persistent threads with dynamic fetch)
@@ -357,6 +376,75 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                 nIdle = __popcll(idleMask);
             }
         }
+#if HR_TAIL_SHARE
+        // ---------------- drain phase: the queue is empty, so a launch now lasts as long as its longest ray (0.5 ms for a ray of
+        // ~400 node steps, against ~70 on average).  Idle lanes therefore take over pending subtrees of the rays still in
+        // flight in their wave: the closest hit is the lexicographic minimum of (t, prim) over ALL triangles, so it does not
+        // matter which lane visits which subtree; the fragments of a ray meet in its merge slot.
+        if (exhausted) {
+            if (!draining) {
+                draining = true;
+                slot = lane;
+                mKey[wave][lane] = kNoHitKey;
+                mCount[wave][lane] = (item != 0xFFFFFFFFu) ? 1u : 0u;
+            }
+            if (item != 0xFFFFFFFFu) { // what the other fragments of this ray have found so far bounds this one too
+                const unsigned long long k = mKey[wave][slot];
+                if (k != kNoHitKey) {
+                    if (segIdx & 1) {
+                        cur = kSentinel, sp = 0, pend = 0; // occluded: nothing left to find
+                    } else {
+                        const float ts = __uint_as_float((uint32_t)(k >> 32));
+                        tlim = ts < tlim ? ts : tlim;
+                    }
+                }
+            }
+            for (int round = 0; round < HR_TAIL_ROUNDS; ++round) { // a lane gives one subtree per round
+            const bool canGive = item != 0xFFFFFFFFu && sp >= 1 && sp <= kStackLDS; // (entries beyond kStackLDS are private)
+            const unsigned long long giveMask = __ballot(canGive);
+            if (nIdle == 0 || giveMask == 0ull) break;
+            {
+                const uint32_t nGive = (uint32_t)__popcll(giveMask);
+                const uint32_t nMove = nGive < (uint32_t)nIdle ? nGive : (uint32_t)nIdle;
+                const uint32_t giveRank = (uint32_t)__popcll(giveMask & ltMask), idleRank = (uint32_t)__popcll(idleMask & ltMask);
+                if (canGive && giveRank < nMove) mDonor[wave][giveRank] = lane;
+                const bool takes = idle && idleRank < nMove;
+                const uint32_t src = takes ? mDonor[wave][idleRank] : lane;
+                // the ray travels by cross-lane reads (every lane executes them), the subtree through the donor's stack column
+                const float sox = __shfl(o.x, (int)src), soy = __shfl(o.y, (int)src), soz = __shfl(o.z, (int)src);
+                const float sdx = __shfl(d.x, (int)src), sdy = __shfl(d.y, (int)src), sdz = __shfl(d.z, (int)src);
+                const float sTmax = __shfl(tmax, (int)src), sTlim = __shfl(tlim, (int)src);
+                const uint32_t sSkip = (uint32_t)__shfl((int)skipPrim, (int)src), sItem = (uint32_t)__shfl((int)item, (int)src);
+                const uint32_t sLocal = (uint32_t)__shfl((int)local, (int)src), sSlot = (uint32_t)__shfl((int)slot, (int)src);
+                const int sSeg = __shfl(segIdx, (int)src);
+                const int given = stack[wave][0][src]; // the donor's OLDEST entry: the farthest subtree, usually the largest
+                if (canGive && giveRank < nMove) {
+                    sp -= 1;
+                    if (sp > 0) stackLane[0] = stackLane[sp * 64];
+                }
+                if (takes) {
+                    item = sItem, segIdx = sSeg, local = sLocal, slot = sSlot, skipPrim = sSkip;
+                    o = v3(sox, soy, soz), d = v3(sdx, sdy, sdz);
+                    tmax = sTmax, tlim = sTlim;
+                    idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
+                    {
+                        const RayK f = rayFrame(S, o, idx, idy, idz);
+                        oix = f.oix, oiy = f.oiy, oiz = f.oiz;
+                    }
+                    best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
+                    sp = 0, pend = 0, cur = given;
+                    atomicAdd(&mCount[wave][slot], 1u);
+                    idle = false;
+#ifdef HR_TAILPROF
+                    nGiven += 1;
+#endif
+                }
+                nIdle -= (int)nMove;
+                idleMask = __ballot(idle);
+            }
+            }
+        }
+#endif
         if (nIdle == 64) { // nothing in flight (finished rays were retired at the end of the previous round)
             if (exhausted) break;
             continue;
@@ -393,7 +481,8 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         // ---------------- triangle phase: run it once enough lanes wait for it, or when nobody can descend any more
         const unsigned long long blockedMask = __ballot(pend != 0 && (cur < 0 || cur == kSentinel));
         const unsigned long long nodeMask = __ballot(cur >= 0 && cur != kSentinel);
-        if (blockedMask != 0ull && (__popcll(blockedMask) >= kTriPhase || nodeMask == 0ull)) {
+        // (while draining, lane utilisation no longer matters: a waiting leaf is tested at once)
+        if (blockedMask != 0ull && (__popcll(blockedMask) >= (exhausted ? 1 : kTriPhase) || nodeMask == 0ull)) {
             if (pend != 0) {
                 const int enc = ~pend;
                 const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
@@ -440,6 +529,47 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
             }
         }
         // ---------------- retire finished rays
+#if HR_TAIL_SHARE
+        if (draining && cur == kSentinel && pend == 0 && item != 0xFFFFFFFFu) {
+            // a fragment is done: fold its result into the ray's slot; the last fragment writes the ray's result
+            const bool hit = best.prim != kMissPrim;
+            const unsigned long long myKey =
+                !hit ? kNoHitKey
+                     : (isAny ? 0ull
+                              : (((unsigned long long)__float_as_uint(best.t) << 32) | ((unsigned long long)(best.prim & 0x7FFFFFFFu) << 1) |
+                                 (unsigned long long)(best.prim >> 31)));
+            if (hit) atomicMin(&mKey[wave][slot], myKey);
+            if (hit && !isAny && mKey[wave][slot] == myKey) mUV[wave][slot] = make_float2(best.u, best.v);
+            const uint32_t before = atomicSub(&mCount[wave][slot], 1u);
+            if (before == 1u) {
+                const unsigned long long k = mKey[wave][slot];
+                const SegDev &sg = tbl->seg[segIdx >> 1];
+                if (isAny) {
+                    if (k == kNoHitKey) {
+                        const float4 c = sg.sq.C[local];
+                        float *px = sg.passbuf + (size_t)__float_as_uint(c.w) * 4;
+                        px[0] = px[0] + c.x;
+                        px[1] = px[1] + c.y;
+                        px[2] = px[2] + c.z;
+                        ++nacc;
+                    }
+                } else {
+                    HitRec h;
+                    h.prim = kMissPrim, h.t = tmax, h.u = 0.0f, h.v = 0.0f;
+                    if (k != kNoHitKey) {
+                        const uint32_t lo = (uint32_t)k;
+                        const float2 uv = mUV[wave][slot];
+                        h.prim = (lo >> 1) | (lo << 31), h.t = __uint_as_float((uint32_t)(k >> 32)), h.u = uv.x, h.v = uv.y;
+                    }
+                    sg.hits[local] = h;
+                }
+            }
+#ifdef HR_TAILPROF
+            maxSteps = mySteps > maxSteps ? mySteps : maxSteps, sumSteps += mySteps, nRays += (before == 1u), mySteps = 0;
+#endif
+            item = 0xFFFFFFFFu;
+        }
+#endif
         if (cur == kSentinel && pend == 0 && item != 0xFFFFFFFFu) {
             const SegDev &sg = tbl->seg[segIdx >> 1];
             if (isAny) {
@@ -469,6 +599,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         atomicMax(&g_tailprof[3], (unsigned long long)maxSteps);
         atomicAdd(&g_tailprof[4], sumSteps);
         atomicAdd(&g_tailprof[5], nRays);
+        atomicAdd(&g_tailprof[6], nGiven);
+        if (tExh && lane == 0) { // per-wave drain time in 0.05 ms buckets
+            unsigned long long b = (tEnd - tExh) / 5000ull;
+            atomicAdd(&g_tailprof[8 + (b > 15ull ? 15ull : b)], 1ull);
+        }
     }
 #endif
 
@@ -718,9 +853,9 @@ size_t hitRecordSize() { return sizeof(HitRec); }
 extern "C" int hr_debug_tailprof(unsigned long long *out8, int reset)
 {
     hipDeviceSynchronize();
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hr::g_tailprof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(hr::g_tailprof), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[8] = {~0ull, ~0ull, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[24] = {~0ull, ~0ull, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(hr::g_tailprof), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

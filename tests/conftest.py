@@ -30,3 +30,16 @@ def hrcore_lib():
     """The product library.  GPU tests fail loudly (not skip) when it is missing."""
     from heatray_amd import core
     return core.load_library()
+
+
+def pytest_collection_finish(session):
+    # Tests that hand torch device buffers to the library initialise torch's HIP context; do that before the first engine
+    # exists, whatever subset of the GPU tests was selected (a late torch initialisation has failed with "No HIP GPUs are
+    # available" on a box where the library had been using the card for a while).
+    if any(item.get_closest_marker("gpu") for item in session.items):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass

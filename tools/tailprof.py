@@ -16,7 +16,7 @@ sc = bench.build_scene(sys.argv[1] if len(sys.argv) > 1 else "c3", 0, 0, 32)
 eng = core.create_engine()
 sc.apply(eng)
 lib = core.load_library()
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 24)()
 for i in range(12):                      # fill the pipeline
     eng.render_pass(sc.options.pass_params(i))
 eng.synchronize()
@@ -31,3 +31,4 @@ for i in range(12, 20):                  # steady state: one trace launch per pa
         # wall_clock64 ticks at 100 MHz
         print("launch: %8d rays  total %.3f ms  queue dry after %.3f ms  tail %.3f ms   steps/ray mean %.1f max %d" % (
             v[5], (v[2] - v[0]) / 1e5, (v[1] - v[0]) / 1e5, (v[2] - v[1]) / 1e5, v[4] / v[5], v[3]))
+        print("        subtrees handed over %d; waves by drain time (0.05 ms buckets): %s" % (v[6], " ".join(str(x) for x in v[8:24])))
