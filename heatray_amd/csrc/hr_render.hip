@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     const unsigned long long tStart = wall_clock64();
     unsigned long long tExh = 0;
     uint32_t mySteps = 0, maxSteps = 0;
-    unsigned long long sumSteps = 0, nRays = 0, nGiven = 0;
+    unsigned long long sumSteps = 0, nRays = 0, nGiven = 0, drainIters = 0, drainLanes = 0;
 #endif
     for (;;) {
         // ---------------- refill idle lanes (persistent threads with dynamic fetch)
@@ -449,6 +449,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
             if (exhausted) break;
             continue;
         }
+#ifdef HR_TAILPROF
+        if (exhausted) drainIters += 1, drainLanes += (unsigned long long)(64 - nIdle);
+#endif
 
         const bool isAny = (segIdx & 1) != 0;
         // ---------------- inner-node steps for every lane that holds an inner node
@@ -517,6 +520,9 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                         best.prim = 0u; // occluded (anything but kMissPrim)
                         cur = kSentinel;
                         sp = 0;
+#if HR_TAIL_SHARE
+                        if (draining) atomicMin(&mKey[wave][slot], 0ull); // the ray's other fragments stop at their next round
+#endif
                         break;
                     }
                     const uint32_t bp = best.prim & 0x7FFFFFFFu;
@@ -524,6 +530,14 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
                         best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
                         best.t = t, best.u = u, best.v = v;
                         tlim = t;
+#if HR_TAIL_SHARE
+                        if (draining) { // publish at once: subtrees handed to other lanes are speculative until a hit bounds them
+                            const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)prim << 1) |
+                                                          (unsigned long long)(det > 0.0f ? 1u : 0u);
+                            atomicMin(&mKey[wave][slot], kk);
+                            if (mKey[wave][slot] == kk) mUV[wave][slot] = make_float2(u, v);
+                        }
+#endif
                     }
                 }
             }
@@ -600,6 +614,11 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
         atomicAdd(&g_tailprof[4], sumSteps);
         atomicAdd(&g_tailprof[5], nRays);
         atomicAdd(&g_tailprof[6], nGiven);
+        if (lane == 0) {
+            atomicMax(&g_tailprof[7], drainIters);
+            atomicAdd(&g_tailprof[16], drainLanes);
+            atomicAdd(&g_tailprof[17], drainIters);
+        }
         if (tExh && lane == 0) { // per-wave drain time in 0.05 ms buckets
             unsigned long long b = (tEnd - tExh) / 5000ull;
             atomicAdd(&g_tailprof[8 + (b > 15ull ? 15ull : b)], 1ull);

@@ -31,4 +31,5 @@ for i in range(12, 20):                  # steady state: one trace launch per pa
         # wall_clock64 ticks at 100 MHz
         print("launch: %8d rays  total %.3f ms  queue dry after %.3f ms  tail %.3f ms   steps/ray mean %.1f max %d" % (
             v[5], (v[2] - v[0]) / 1e5, (v[1] - v[0]) / 1e5, (v[2] - v[1]) / 1e5, v[4] / v[5], v[3]))
-        print("        subtrees handed over %d; waves by drain time (0.05 ms buckets): %s" % (v[6], " ".join(str(x) for x in v[8:24])))
+        print("        subtrees handed over %d; waves by drain time (0.05 ms buckets, first 8): %s" % (v[6], " ".join(str(x) for x in v[8:16])))
+        print("        drain rounds of a wave: max %d, mean %.1f; lanes busy in a drain round: %.1f of 64" % (v[7], v[17] / 5120.0, v[16] / max(v[17], 1)))
