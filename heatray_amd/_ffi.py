@@ -39,6 +39,7 @@ HR_SAMPLE_RANDOM, HR_SAMPLE_HALTON, HR_SAMPLE_HAMMERSLEY, HR_SAMPLE_BLUE_NOISE, 
 HR_BOKEH_CIRCULAR, HR_BOKEH_PENTAGON, HR_BOKEH_HEXAGON, HR_BOKEH_OCTAGON = range(4)
 
 HR_ESTIMATOR_REFERENCE, HR_ESTIMATOR_ENV_MIS = 0, 1
+HR_TEXTURE_LOD_BASE, HR_TEXTURE_LOD_CONE = 0, 1
 (HR_VIS_NONE, HR_VIS_GEOMETRIC_NORMALS, HR_VIS_UVS, HR_VIS_TANGENTS, HR_VIS_BITANGENTS, HR_VIS_NORMALMAP,
  HR_VIS_FINAL_NORMALS, HR_VIS_BASE_COLOR, HR_VIS_ROUGHNESS, HR_VIS_METALLIC, HR_VIS_EMISSIVE, HR_VIS_CLEARCOAT,
  HR_VIS_CLEARCOAT_ROUGHNESS, HR_VIS_CLEARCOAT_NORMALMAP, HR_VIS_SHADER) = range(15)
@@ -103,7 +104,7 @@ class PassParams(C.Structure):
                 ("block_size", C.c_int32 * 2), ("current_block_pixel", C.c_int32 * 2), ("max_sample_index", C.c_float),
                 ("enable_visualizer", C.c_int32), ("visualizer_mode", C.c_int32),
                 ("enable_accumulator_visualizer", C.c_int32), ("show_nans", C.c_int32), ("show_inf", C.c_int32),
-                ("estimator", C.c_int32)]
+                ("estimator", C.c_int32), ("texture_lod", C.c_int32)]
 
 
 class PassStats(C.Structure):

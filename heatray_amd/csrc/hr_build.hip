@@ -923,6 +923,78 @@ void launchEnvTable(hipStream_t st, const TexDesc &tex, float *lum, float *dil, 
     hipLaunchKernelGGL(k_env_cols, dim3(h), dim3(256), 0, st, wq, rowSum, total, w, colCdf, prob);
 }
 
+// ---------------------------------------------------------------------------- mip chain, texel density (HR_TEXTURE_LOD_CONE)
+// One level of the chain: dst(x, y) = ((s(2x, 2y) + s(2x+1, 2y)) + (s(2x, 2y+1) + s(2x+1, 2y+1))) * 0.25 per channel, source
+// coordinates clamped to the source level (odd sizes); u8 data enters as float(byte) / 255.0f, levels >= 1 are f32.
+__global__ __launch_bounds__(256) void k_mip_down(const void *__restrict__ src, int srcIsU8, int sw, int sh, int c, float *__restrict__ dst, int dw, int dh)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint32_t)(dw * dh)) return;
+    const int x = (int)(i % (uint32_t)dw), y = (int)(i / (uint32_t)dw);
+    const int x0 = 2 * x < sw ? 2 * x : sw - 1, x1 = 2 * x + 1 < sw ? 2 * x + 1 : sw - 1;
+    const int y0 = 2 * y < sh ? 2 * y : sh - 1, y1 = 2 * y + 1 < sh ? 2 * y + 1 : sh - 1;
+    for (int k = 0; k < c; ++k) {
+        float a, b, cc, d;
+        if (srcIsU8) {
+            const uint8_t *p = reinterpret_cast<const uint8_t *>(src);
+            a = (float)p[((size_t)y0 * sw + x0) * c + k] / 255.0f, b = (float)p[((size_t)y0 * sw + x1) * c + k] / 255.0f;
+            cc = (float)p[((size_t)y1 * sw + x0) * c + k] / 255.0f, d = (float)p[((size_t)y1 * sw + x1) * c + k] / 255.0f;
+        } else {
+            const float *p = reinterpret_cast<const float *>(src);
+            a = p[((size_t)y0 * sw + x0) * c + k], b = p[((size_t)y0 * sw + x1) * c + k];
+            cc = p[((size_t)y1 * sw + x0) * c + k], d = p[((size_t)y1 * sw + x1) * c + k];
+        }
+        dst[((size_t)y * dw + x) * c + k] = ((a + b) + (cc + d)) * 0.25f;
+    }
+}
+
+// levels 1 .. nLevels-1 of `t` into `mips` (laid out as hr_texture.h's mipOffset expects)
+void launchMipChain(hipStream_t st, const TexDesc &t, int nLevels, float *mips)
+{
+    const void *src = t.px;
+    int srcU8 = t.dtype == HR_TEX_U8 ? 1 : 0, sw = t.w, sh = t.h;
+    size_t off = 0;
+    for (int l = 1; l < nLevels; ++l) {
+        const int dw = sw / 2 < 1 ? 1 : sw / 2, dh = sh / 2 < 1 ? 1 : sh / 2;
+        float *dst = mips + off;
+        hipLaunchKernelGGL(k_mip_down, dim3(((uint32_t)(dw * dh) + 255) / 256), dim3(256), 0, st, src, srcU8, sw, sh, t.c, dst, dw, dh);
+        off += (size_t)dw * dh * t.c;
+        src = dst, srcU8 = 0, sw = dw, sh = dh;
+    }
+}
+
+__global__ void k_tex_lod_scale(TexDesc *table, int n)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) table[i].lodScale = 0.5f * (log_((float)table[i].w * (float)table[i].h) * 1.4426950408889634f);
+}
+void launchTexLodScale(hipStream_t st, TexDesc *table, int n)
+{
+    if (n > 0) hipLaunchKernelGGL(k_tex_lod_scale, dim3((n + 63) / 64), dim3(64), 0, st, table, n);
+}
+
+// texDensity[prim] = 0.5 * log2(uv area / world area) of every triangle (twice-areas cancel); -1e30 where either area is zero
+// (no uvs, degenerate triangle): such a triangle is textured at level 0
+__global__ __launch_bounds__(256) void k_tex_density(const Tri *__restrict__ leafTris, uint32_t nSlots, const TriAttr *__restrict__ attrs,
+                                                     float *__restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nSlots) return;
+    const Tri tr = leafTris[i];
+    const uint32_t prim = __float_as_uint(tr.r.y);
+    if (prim == 0xFFFFFFFFu) return;
+    const v3 e1(tr.p.w, tr.q.x, tr.q.y), e2(tr.q.z, tr.q.w, tr.r.x);
+    const float world2 = length(cross(e1, e2));
+    const TriAttr &a = attrs[prim];
+    const float du1 = a.uv[2] - a.uv[0], dv1 = a.uv[3] - a.uv[1], du2 = a.uv[4] - a.uv[0], dv2 = a.uv[5] - a.uv[1];
+    const float uv2 = abs_(du1 * dv2 - dv1 * du2);
+    out[prim] = (world2 > 0.0f && uv2 > 0.0f) ? 0.5f * (log_(uv2 / world2) * 1.4426950408889634f) : -1e30f;
+}
+void launchTexDensity(hipStream_t st, const Tri *leafTris, uint32_t nSlots, const TriAttr *attrs, float *out)
+{
+    if (nSlots) hipLaunchKernelGGL(k_tex_density, dim3((nSlots + 255) / 256), dim3(256), 0, st, leafTris, nSlots, attrs, out);
+}
+
 // ---------------------------------------------------------------------------------------- QMC
 // Random.h:26-34 (see oracle/oracle_qmc.cpp for the x86 conversion note)
 HRD uint32_t toUint32(float f) { return (uint32_t)(unsigned long long)(long long)(f * 4294967296.0f); }

@@ -20,6 +20,7 @@ namespace {
 
 struct Texture {
     void *dpx = nullptr;
+    float *dmips = nullptr; // levels >= 1 (HR_TEXTURE_LOD_CONE), built on first use
     TexDesc desc{};
     bool alive = false;
 };
@@ -50,6 +51,7 @@ struct hr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool collectStats = false;
+    bool textureLodUsed = false; // a pass has asked for HR_TEXTURE_LOD_CONE (kernel variant, see LaunchCfg)
     int rank = 0, world = 1, tile = 32;
     int numCUs = 256;
     std::string err;
@@ -184,6 +186,9 @@ struct hr_ctx {
     size_t dMaterialsCap = 0;
     TexDesc *dTextures = nullptr;
     size_t dTexturesCap = 0;
+    float *dTexDensity = nullptr; // HR_TEXTURE_LOD_CONE: per-triangle level offset, rebuilt after every commit once the mode was used
+    size_t texDensityCap = 0;
+    bool texDensityStale = true;
     float2 *dSeq = nullptr, *dAperture = nullptr, *dSeqOffsets = nullptr;
     int nSeq = 0, seqLen = 0, nSeqOffsets = 0;
     SceneDev hScene{};
@@ -244,7 +249,7 @@ struct hr_ctx {
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
     int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64;
-    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats}; }
+    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed}; }
 };
 
 #define FAIL(ctx, code, msg)  \
@@ -464,6 +469,8 @@ int hr_ctx_destroy(hr_ctx *c)
     if (c->hConsts) hipHostFree(c->hConsts);
     if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
+    hipFree(c->dTexDensity);
+    for (Texture &t : c->textures) hipFree(t.dmips);
     hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dCounters);
     for (hr_ctx::Group &G : c->groups) {
         if (G.hQCount) hipHostFree(G.hQCount);
@@ -1030,6 +1037,7 @@ int hr_scene_commit(hr_ctx *c)
     hipEventElapsedTime(&c->info.build_ms, cs.e0, cs.e1);
     c->committed = true;
     c->sceneDirty = true;
+    c->texDensityStale = true;
     c->topologyDirty = false, c->transformDirty = false;
     return HR_OK;
 }
@@ -1063,7 +1071,7 @@ int hr_texture_create(hr_ctx *c, const hr_texture_desc *d, const void *pixels, h
     Texture t;
     HIP_TRY(c, hipMalloc(&t.dpx, bytes));
     HIP_TRY(c, hipMemcpy(t.dpx, pixels, bytes, hipMemcpyHostToDevice));
-    t.desc = TexDesc{t.dpx, d->width, d->height, d->channels, d->wrap_s, d->wrap_t, d->filter, d->dtype, 0};
+    t.desc = TexDesc{t.dpx, d->width, d->height, d->channels, d->wrap_s, d->wrap_t, d->filter, d->dtype, 0, nullptr, 0.0f, 0};
     t.alive = true;
     c->textures.push_back(t);
     c->sceneDirty = true;
@@ -1076,7 +1084,7 @@ int hr_texture_destroy(hr_ctx *c, hr_tex_id id)
     ENTER(c);
     if (id < 0 || id >= (int)c->textures.size() || !c->textures[id].alive) FAIL(c, HR_ERR_INVALID, "bad texture id");
     QUIESCE(c);
-    hipFree(c->textures[id].dpx);
+    hipFree(c->textures[id].dpx), hipFree(c->textures[id].dmips);
     c->textures[id] = Texture();
     if (c->envTex == id) c->envTex = -2, c->envW = c->envH = 0;
     c->sceneDirty = true;
@@ -1259,7 +1267,7 @@ int hr_multiscatter_lut_generate(hr_ctx *c, float *out, hr_tex_id *outTex)
     if (outTex) { // loadMultiscatterTexture: LINEAR + CLAMP_TO_EDGE sampler (TextureLoader.cpp:36-41)
         Texture t;
         t.dpx = lut;
-        t.desc = TexDesc{lut, 128, 128, 1, HR_WRAP_CLAMP_TO_EDGE, HR_WRAP_CLAMP_TO_EDGE, HR_FILTER_LINEAR, HR_TEX_F32, 0};
+        t.desc = TexDesc{lut, 128, 128, 1, HR_WRAP_CLAMP_TO_EDGE, HR_WRAP_CLAMP_TO_EDGE, HR_FILTER_LINEAR, HR_TEX_F32, 0, nullptr, 0.0f, 0};
         t.alive = true;
         c->textures.push_back(t);
         c->sceneDirty = true;
@@ -1292,7 +1300,10 @@ static int uploadScene(hr_ctx *c)
         td[i] = c->textures[i].desc;
         if (!c->textures[i].alive) td[i].px = nullptr;
     }
-    if (!td.empty()) HIP_TRY(c, hipMemcpy(c->dTextures, td.data(), td.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+    if (!td.empty()) {
+        HIP_TRY(c, hipMemcpy(c->dTextures, td.data(), td.size() * sizeof(TexDesc), hipMemcpyHostToDevice));
+        launchTexLodScale(c->stream, c->dTextures, (int)td.size()); // TexDesc::lodScale, in the device's (= the oracle's) arithmetic
+    }
     SceneDev &s = c->hScene;
     s.materials = c->dMaterials, s.nMaterials = (int)c->materials.size();
     s.textures = c->dTextures, s.nTextures = (int)c->textures.size();
@@ -1303,6 +1314,7 @@ static int uploadScene(hr_ctx *c)
     s.envW = c->envW, s.envH = c->envH, s.envMeanLum = c->envMeanLum;
     s.blockNx = c->blockNx, s.blockNy = c->blockNy;
     std::memcpy(s.blockCoords, c->blockCoords, sizeof(s.blockCoords));
+    s.texDensity = c->texDensityStale ? nullptr : c->dTexDensity;
     HIP_TRY(c, hipMemcpy(c->dScene, &s, sizeof(SceneDev), hipMemcpyHostToDevice));
     // rays can outlive maxRayDepth only by passing through single-sided / alpha-masked surfaces
     c->hasPassthrough = false;
@@ -1352,6 +1364,51 @@ static int ensureEnvTable(hr_ctx *c)
     HIP_TRY(c, e);
     c->envW = t.w, c->envH = t.h, c->envTex = id;
     c->sceneDirty = true;
+    return HR_OK;
+}
+
+// HR_TEXTURE_LOD_CONE: build what the mode needs and is missing — the mip chains of the textures and the per-triangle level offset
+static int ensureTextureLod(hr_ctx *c)
+{
+    bool quiesced = false;
+    for (Texture &t : c->textures) {
+        if (!t.alive || t.desc.nLevels != 0) continue;
+        if (!quiesced) {
+            QUIESCE(c);
+            quiesced = true;
+        }
+        TexDesc &d = t.desc;
+        int levels = 1;
+        size_t elems = 0;
+        for (int w = d.w, h = d.h; (w > 1 || h > 1) && d.filter != HR_FILTER_NEAREST; ++levels) {
+            w = w / 2 < 1 ? 1 : w / 2, h = h / 2 < 1 ? 1 : h / 2;
+            elems += (size_t)w * h * d.c;
+        }
+        if (levels > 1) {
+            HIP_TRY(c, hipMalloc(&t.dmips, elems * sizeof(float)));
+            launchMipChain(c->stream, d, levels, t.dmips);
+        }
+        d.nLevels = levels, d.mips = t.dmips;
+        c->sceneDirty = true;
+    }
+    if (c->texDensityStale && c->tree.tris) {
+        if (!quiesced) {
+            QUIESCE(c);
+            quiesced = true;
+        }
+        const size_t nTris = c->treeTris;
+        if (c->texDensityCap < nTris || !c->dTexDensity) {
+            hipFree(c->dTexDensity);
+            c->dTexDensity = nullptr, c->texDensityCap = 0;
+            HIP_TRY(c, hipMalloc(&c->dTexDensity, sizeof(float) * (nTris ? nTris : 1)));
+            c->texDensityCap = nTris;
+        }
+        const uint32_t slots = c->tree.triSlots ? c->tree.triSlots : (uint32_t)nTris;
+        launchTexDensity(c->stream, c->tree.tris, slots, c->attrs, c->dTexDensity);
+        c->texDensityStale = false;
+        c->sceneDirty = true;
+    }
+    if (quiesced) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HR_OK;
 }
 
@@ -1678,6 +1735,13 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
         if (rc) return rc;
     } else if (pp->estimator != HR_ESTIMATOR_REFERENCE) {
         FAIL(c, HR_ERR_INVALID, "unknown estimator");
+    }
+    if (pp->texture_lod == HR_TEXTURE_LOD_CONE) {
+        rc = ensureTextureLod(c);
+        if (rc) return rc;
+        c->textureLodUsed = true;
+    } else if (pp->texture_lod != HR_TEXTURE_LOD_BASE) {
+        FAIL(c, HR_ERR_INVALID, "unknown texture_lod mode");
     }
     rc = uploadScene(c); // drains the pipeline first when the scene constants changed
     if (rc) return rc;

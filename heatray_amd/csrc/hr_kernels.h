@@ -26,6 +26,7 @@ struct LaunchCfg {
     int traceBlocksPerCU;
     int shadeBlocksPerCU;
     bool collectStats;
+    bool textureLod; // some pass has asked for HR_TEXTURE_LOD_CONE: launch the shading kernel that carries the trilinear sampler
 };
 
 // One in-flight pass as seen by the kernels of one macro step.
@@ -137,6 +138,9 @@ int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const fl
 // (already moved by launchAssemble) and re-quantised.  Level by level, no host synchronisation.
 void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts);
 // order-independent 64-bit digest of a device buffer, added to *out (device)
+void launchMipChain(hipStream_t st, const TexDesc &t, int nLevels, float *mips);
+void launchTexLodScale(hipStream_t st, TexDesc *table, int n);
+void launchTexDensity(hipStream_t st, const Tri *leafTris, uint32_t nSlots, const TriAttr *attrs, float *out);
 void launchHashWords(hipStream_t st, const void *words, size_t nWords, unsigned long long seed, unsigned long long *out);
 void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts);
 

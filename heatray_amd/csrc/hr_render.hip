@@ -86,7 +86,7 @@ HRD void storeRay(const RayQueue &q, uint32_t slot, const Ray &r, uint32_t pixel
     q.A[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.maxT);
     q.B[slot] = make_float4(r.d.x, r.d.y, r.d.z, r.extraT);
     q.C[slot] = make_float4(r.weight.x, r.weight.y, r.weight.z, __uint_as_float(pixel));
-    q.D[slot] = make_int4((int)packMeta(r), r.sequenceIndexOffset, (int)srcPrim, 0);
+    q.D[slot] = make_int4((int)packMeta(r), r.sequenceIndexOffset, (int)srcPrim, (int)packCone(r.coneW, r.coneG));
 }
 
 // pixel of thread `gid` in this context's tile shard: tiles in round-robin order, 8x8-pixel blocks inside
@@ -656,6 +656,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
 #define HR_SHADE_MINBLOCKS 4 // <= 128 VGPRs: four 256-thread workgroups per CU (measured best on MI355X; 5+ spills)
 #endif
 static const int kShadeBlock = HR_SHADE_BLOCK; // queue slots are reserved once per workgroup and pass (fewer same-address atomics)
+template <bool LOD>
 __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
@@ -742,14 +743,17 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
             in.missKind = (int)((meta >> 24) & 7u), in.missIdx = (int)((meta >> 27) & 7u);
             in.sequenceIndexOffset = dm.y;
             in.occlusionTest = false, in.valid = true;
-            Shader sh(S, sg.pp, sg.passbuf + (size_t)pixel * 4);
+            in.coneW = in.coneG = 0.0f; // (the variant without the mode carries no cone: nothing to keep in registers)
+            if (LOD) unpackCone((uint32_t)dm.w, in.coneW, in.coneG);
+            ShaderT<LOD> sh(S, sg.pp, sg.passbuf + (size_t)pixel * 4);
             if (h.prim == kMissPrim) {
                 // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
                 if (in.missKind == MISS_ENV) sh.performAccumulate(sh.environmentRadiance(in.d, in.weight));
             } else {
                 prim = h.prim & 0x7FFFFFFFu;
                 uint32_t mid;
-                const Shader::Surface sf = sh.surface(in, prim, (h.prim >> 31) != 0u, h.t, h.u, h.v, mid);
+                const typename ShaderT<LOD>::Surface sf = sh.surface(in, prim, (h.prim >> 31) != 0u, h.t, h.u, h.v, mid);
+                sh.setFootprint(in, sf.normal, h.t, prim);
                 if (mid < (uint32_t)S.nMaterials) {
                     const hr_material &M = S.materials[mid];
                     if (M.type == HR_MAT_GLASS) {
@@ -847,7 +851,10 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, co
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats)
 {
     const int grid = cfg.numCUs * cfg.shadeBlocksPerCU;
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
+    if (cfg.textureLod)
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
+    else
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
 }
 
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out)

@@ -23,15 +23,36 @@ struct Ray {
     bool occlusionTest;
     int missKind, missIdx;
     bool valid;
+    float coneW, coneG; // ray cone (HR_TEXTURE_LOD_CONE): width at the origin and spread angle; travels as two bf16-truncated floats
 };
 
-struct Shader {
+// The cone rides in one dword of the ray record: the upper halves of the two floats (truncation is part of the contract)
+HRD uint32_t packCone(float w, float g) { return (__float_as_uint(w) & 0xFFFF0000u) | (__float_as_uint(g) >> 16); }
+HRD void unpackCone(uint32_t bits, float &w, float &g) { w = __uint_as_float(bits & 0xFFFF0000u), g = __uint_as_float(bits << 16); }
+HRD float widenCone(float g, float roughness) { return fmin_(g + 0.25f * roughness, 1.0f); }
+
+// LOD: compiled with the ray-cone texture lookups of HR_TEXTURE_LOD_CONE.  The shading kernel exists in both variants; the one
+// without is what runs until a pass asks for the mode (its code and register allocation are those of the level-0 sampler alone).
+template <bool LOD> struct ShaderT {
     const SceneDev &S;
     const hr_pass_params &pp;
     float *px; // RGBA of the pixel this path belongs to (single owner: plain read-modify-write)
     uint32_t nAccum;
+    float lodBase; // HR_TEXTURE_LOD_CONE: log2(texels of a unit-uv-square texture under the cone's footprint); level 0 when <= 0
 
-    HRD Shader(const SceneDev &s, const hr_pass_params &p, float *pixel) : S(s), pp(p), px(pixel), nAccum(0) {}
+    HRD ShaderT(const SceneDev &s, const hr_pass_params &p, float *pixel) : S(s), pp(p), px(pixel), nAccum(0), lodBase(-1e30f) {}
+
+    // Advance the ray's cone to the hit and derive the footprint's level offset on this triangle (HR_TEXTURE_LOD_CONE)
+    HRD void setFootprint(Ray &in, v3 normal, float t, uint32_t prim)
+    {
+        lodBase = -1e30f;
+        if (!LOD) return;
+        const float hitW = in.coneW + in.coneG * t;
+        in.coneW = hitW;
+        if (pp.texture_lod != HR_TEXTURE_LOD_CONE || !S.texDensity || !(hitW > 0.0f)) return;
+        const float cosT = fmax_(abs_(dot(in.d, normal)), 0.1f);
+        lodBase = S.texDensity[prim] + log_(hitW / cosT) * 1.4426950408889634f;
+    }
 
     // sequence.rlsl:18-28
     HRD v2 getSequenceValue(int sequenceIndex, int sampleIndex) const
@@ -76,6 +97,7 @@ struct Shader {
     HRD v4 tex(int id, v2 uv) const
     {
         if (id < 0 || id >= S.nTextures || !S.textures[id].px) return v4{1.0f, 1.0f, 1.0f, 1.0f}; // dummy white texel (Texture.h:188-203)
+        if (LOD && pp.texture_lod == HR_TEXTURE_LOD_CONE) return sampleTextureLod(S.textures[id], uv.x, uv.y, lodBase + S.textures[id].lodScale);
         return sampleTexture(S.textures[id], uv.x, uv.y);
     }
 
@@ -377,6 +399,7 @@ struct Shader {
                 r.occlusionTest = (missKind != MISS_NONE);
                 r.missKind = missKind, r.missIdx = 0;
                 r.extraT = 0.0f;
+                if (LOD) r.coneG = widenCone(in.coneG, 1.0f);
                 if (missKind == MISS_ENV && !S.lights.env_enabled) return;
                 emit(r, nee, next);
             }
@@ -554,6 +577,7 @@ struct Shader {
                 r.occlusionTest = (missKind != MISS_NONE);
                 r.missKind = missKind, r.missIdx = 0;
                 r.extraT = 0.0f;
+                if (LOD) r.coneG = widenCone(in.coneG, roughness);
                 if (missKind == MISS_ENV && !S.lights.env_enabled) return;
                 emit(r, nee, next);
             }
@@ -801,6 +825,7 @@ struct Shader {
                 r.occlusionTest = (missKind != MISS_NONE);
                 r.missKind = missKind, r.missIdx = 0;
                 r.extraT = 0.0f;
+                if (LOD) r.coneG = widenCone(in.coneG, roughnessAlpha);
                 if (missKind == MISS_ENV && !S.lights.env_enabled) return;
                 emit(r, nee, next);
             }
@@ -921,6 +946,7 @@ struct Shader {
                 r.extraT = 0.0f;
                 r.missKind = S.lights.env_enabled ? MISS_ENV : MISS_NONE;
                 r.missIdx = 0;
+                if (LOD) r.coneG = widenCone(in.coneG, roughnessAlpha);
                 next = r;
             }
         } else { // :257-279
@@ -945,6 +971,7 @@ struct Shader {
         }
     }
 };
+using Shader = ShaderT<false>;
 
 // ---- perspective.rlsl:39-93 (frame shader) ----
 HRD float randomRL(float sx, float sy) { return fract(sin_(sx * 12.9898f + sy * 78.233f) * 43758.5453123f); } // utility.rlsl:15-18
@@ -997,6 +1024,8 @@ HRD bool generatePrimary(const SceneDev &S, const hr_pass_params &pp, int W, int
     out.depth = 0;
     out.occlusionTest = false;
     out.valid = true;
+    out.coneW = 0.0f;                     // ray cone of HR_TEXTURE_LOD_CONE: a pinhole pixel (the aperture is ignored)
+    out.coneG = 2.0f * pp.fov_tan / Hf;   // one pixel's angle at the image centre
     return true;
 }
 

@@ -77,6 +77,9 @@ struct TexDesc {
     int32_t w, h, c;
     int32_t wrapS, wrapT, filter;
     int32_t dtype;  // HR_TEX_F32, or HR_TEX_U8: bytes stay bytes in HBM and are normalised on fetch as float(byte) / 255.0f
+    int32_t nLevels; // 0: no mip chain built; otherwise levels 0 .. nLevels-1 exist (HR_TEXTURE_LOD_CONE, hr_texture.h)
+    const float *mips; // levels 1 .. nLevels-1, always f32, c channels, level l is max(1, w >> l) x max(1, h >> l), stored one after the other
+    float lodScale;  // 0.5 * log2(w * h): texels per unit uv length, as a level offset
     int32_t pad;
 };
 
@@ -122,6 +125,8 @@ struct SceneDev {
     // interactive-mode block table (hr_interactive_blocks_set); blockNx == 0: the unshuffled list
     int32_t blockNx, blockNy;
     int32_t blockCoords[32];
+    // HR_TEXTURE_LOD_CONE: per triangle (prim id) 0.5 * log2(uv area / world area), or null
+    const float *texDensity;
 };
 
 // ---- counters ---------------------------------------------------------------------------------

@@ -226,6 +226,7 @@ class RenderOptions:
     show_nans: bool = False
     show_inf: bool = False
     estimator: int = ffi.HR_ESTIMATOR_REFERENCE
+    texture_lod: int = ffi.HR_TEXTURE_LOD_BASE
 
     def pass_params(self, sample_index, current_block_pixel=(0, 0)):
         """Uniforms of one pass: PassGenerator::runRenderFrameJob (PassGenerator.cpp:341-369)."""
@@ -248,6 +249,7 @@ class RenderOptions:
         p.enable_accumulator_visualizer = int(self.show_nans or self.show_inf)
         p.show_nans, p.show_inf = int(self.show_nans), int(self.show_inf)
         p.estimator = int(self.estimator)
+        p.texture_lod = int(self.texture_lod)
         return p
 
 

@@ -159,6 +159,8 @@ bool PassGenerator::runInitJob(const RLint renderWidth, const RLint renderHeight
     {
         const char* est = getenv("HEATRAY_ESTIMATOR");
         m_envMis = est && std::string(est) == "env_mis";
+        const char* lod = getenv("HEATRAY_TEXTURE_LOD");
+        m_textureLodCone = lod && std::string(lod) == "cone";
     }
     m_width = renderWidth;
     m_height = renderHeight;
@@ -287,6 +289,7 @@ void PassGenerator::runRenderFrameJob(const RenderOptions& newOptions, const Pas
         // RenderOptions is the reference's struct, unchanged, so the estimator is chosen out of band: HEATRAY_ESTIMATOR=env_mis selects
         // the importance-sampled environment + MIS estimator of include/hrcore.h (default: the reference's estimator)
         params.estimator = m_envMis ? HR_ESTIMATOR_ENV_MIS : HR_ESTIMATOR_REFERENCE;
+        params.texture_lod = m_textureLodCone ? HR_TEXTURE_LOD_CONE : HR_TEXTURE_LOD_BASE; // HEATRAY_TEXTURE_LOD=cone: mip chain + ray cones
 
         // Interactive mode walks the 3x3 block; the sample index advances once per full block (:372-384).
         if (m_renderOptions.enableInteractiveMode) {

@@ -303,6 +303,7 @@ typedef struct hr_pass_params {
     int32_t show_nans;
     int32_t show_inf;
     int32_t estimator;         /* HR_ESTIMATOR_*: how next-event rays towards the environment are sampled */
+    int32_t texture_lod;       /* HR_TEXTURE_LOD_*: which mip level material textures are read at        */
 } hr_pass_params;
 
 /* HR_ESTIMATOR_REFERENCE: the reference's estimator, bit for bit: when the light pick falls on the environment, the occlusion ray
@@ -314,6 +315,18 @@ typedef struct hr_pass_params {
  * ray budget, light pick, lobe pick, analytic lights, glass — is the reference's. */
 #define HR_ESTIMATOR_REFERENCE 0
 #define HR_ESTIMATOR_ENV_MIS 1
+
+/* HR_TEXTURE_LOD_BASE: every lookup reads level 0 (bilinear), as in rounds 1-2: OpenRL's level selection inside ray shaders (no
+ * screen-space derivatives) is closed, so the reference-faithful path does not guess one.
+ * HR_TEXTURE_LOD_CONE: the reference creates its textures with RL_LINEAR_MIPMAP_LINEAR and generated mips
+ * (RLWrapper/Texture.h:51,68,85-87).  With this mode the core builds the mip chain on the device (2x2 box filter, levels >= 1 kept
+ * as f32) the first time it is asked for, carries a ray cone along every path (width at the ray origin + spread angle: the pixel's
+ * angle for camera rays, widened by 0.25 x roughness at every scattering event) and reads MATERIAL textures trilinearly at the
+ * level whose texel matches the cone's footprint on the triangle (its world-to-uv area ratio, over |cos| of the incidence).
+ * Environment, LUT and occlusion-ray alpha lookups stay at level 0.  Not the reference's estimator: it has its own oracle
+ * contract (oracle/oracle_shade.cpp, bit-exact) and known-answer tests. */
+#define HR_TEXTURE_LOD_BASE 0
+#define HR_TEXTURE_LOD_CONE 1
 
 /* one-hot show* flags of GlobalData (PassGenerator.h:275-289) as an enum */
 #define HR_VIS_NONE 0

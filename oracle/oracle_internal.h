@@ -28,12 +28,17 @@ struct Texture {
     int wrapS = HR_WRAP_REPEAT, wrapT = HR_WRAP_REPEAT, filter = HR_FILTER_LINEAR;
     bool alive = false;
     std::vector<float> px; // w*h*c, u8 data converted as float(byte)/255.0f
+    // HR_TEXTURE_LOD_CONE: levels 1 .. nLevels-1 one after the other (2x2 box filter of the level below), nLevels == 0: not built yet
+    int nLevels = 0;
+    std::vector<float> mips;
+    float lodScale = 0.0f; // 0.5 * log2(w * h)
 };
 
 struct vec4 {
     float x, y, z, w;
 };
 vec4 sampleTexture(const Texture &t, float u, float v);
+vec4 sampleTextureLod(const Texture &t, float u, float v, float lambda); // trilinear over the mip chain (HR_TEXTURE_LOD_CONE)
 
 struct Geom {
     bool alive = false;
@@ -111,6 +116,7 @@ struct Context {
     std::vector<vec2> seqOffsets;
     int blockNx = 0, blockNy = 0, blockCoords[32] = {0}; // interactive-mode block table (0: the unshuffled list)
     EnvTable env;
+    std::vector<float> texDensity; // HR_TEXTURE_LOD_CONE: 0.5 * log2(uv area / world area) per triangle (prim id)
     // committed scene
     bool committed = false;
     std::vector<Tri> tris;       // submission order (prim id)
@@ -125,6 +131,7 @@ struct Context {
 
 void commitScene(Context &ctx);
 void buildEnvTable(Context &ctx); // (re)builds ctx.env when the environment texture changed
+void buildTextureLod(Context &ctx); // HR_TEXTURE_LOD_CONE: missing mip chains + the per-triangle level offsets
 bool alphaPasses(const Context &ctx, int prim, float u, float v); // alpha-mask test for occlusion rays
 
 // ---- shading (oracle_shade.cpp) ----

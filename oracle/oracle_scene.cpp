@@ -136,6 +136,105 @@ vec4 sampleTexture(const Texture &t, float u, float v)
     return r;
 }
 
+// ---- HR_TEXTURE_LOD_CONE (include/hrcore.h): mip chain + trilinear lookup; the product's heatray_amd/csrc/hr_texture.h and the
+// mip / density kernels of hr_build.hip follow THIS arithmetic, operation for operation.
+static inline int mipDim(int n, int level)
+{
+    const int d = n >> level;
+    return d < 1 ? 1 : d;
+}
+static inline size_t mipOffset(const Texture &t, int level)
+{
+    size_t off = 0;
+    for (int l = 1; l < level; ++l) off += (size_t)mipDim(t.w, l) * (size_t)mipDim(t.h, l) * (size_t)t.c;
+    return off;
+}
+static inline vec4 texelAt(const Texture &t, int level, size_t levelOff, int lw, int x, int y)
+{
+    if (level == 0) return texel(t, x, y);
+    const float *f = &t.mips[levelOff + ((size_t)y * lw + x) * t.c];
+    if (t.c == 1) return vec4{f[0], f[0], f[0], 1.0f};
+    if (t.c == 3) return vec4{f[0], f[1], f[2], 1.0f};
+    return vec4{f[0], f[1], f[2], f[3]};
+}
+static vec4 sampleTextureLevel(const Texture &t, int level, float u, float v)
+{
+    if (level == 0) return sampleTexture(t, u, v);
+    const int lw = mipDim(t.w, level), lh = mipDim(t.h, level);
+    const size_t off = mipOffset(t, level);
+    float x = u * (float)lw - 0.5f;
+    float y = v * (float)lh - 0.5f;
+    float x0f = floorf(x), y0f = floorf(y);
+    float fx = x - x0f, fy = y - y0f;
+    int x0 = wrapIndex((int)x0f, lw, t.wrapS), x1 = wrapIndex((int)x0f + 1, lw, t.wrapS);
+    int y0 = wrapIndex((int)y0f, lh, t.wrapT), y1 = wrapIndex((int)y0f + 1, lh, t.wrapT);
+    vec4 c00 = texelAt(t, level, off, lw, x0, y0), c10 = texelAt(t, level, off, lw, x1, y0), c01 = texelAt(t, level, off, lw, x0, y1),
+         c11 = texelAt(t, level, off, lw, x1, y1);
+    float gx = 1.0f - fx, gy = 1.0f - fy;
+    vec4 r;
+    r.x = (c00.x * gx + c10.x * fx) * gy + (c01.x * gx + c11.x * fx) * fy;
+    r.y = (c00.y * gx + c10.y * fx) * gy + (c01.y * gx + c11.y * fx) * fy;
+    r.z = (c00.z * gx + c10.z * fx) * gy + (c01.z * gx + c11.z * fx) * fy;
+    r.w = (c00.w * gx + c10.w * fx) * gy + (c01.w * gx + c11.w * fx) * fy;
+    return r;
+}
+vec4 sampleTextureLod(const Texture &t, float u, float v, float lambda)
+{
+    if (t.nLevels <= 1 || t.filter == HR_FILTER_NEAREST || !(lambda > 0.0f)) return sampleTexture(t, u, v);
+    const float top = (float)(t.nLevels - 1);
+    const float l = lambda < top ? lambda : top;
+    const float lf = floorf(l);
+    const int l0 = (int)lf;
+    const float f = l - lf;
+    const vec4 a = sampleTextureLevel(t, l0, u, v);
+    if (!(f > 0.0f)) return a;
+    const vec4 b = sampleTextureLevel(t, l0 + 1, u, v);
+    const float g = 1.0f - f;
+    return vec4{a.x * g + b.x * f, a.y * g + b.y * f, a.z * g + b.z * f, a.w * g + b.w * f};
+}
+
+void buildTextureLod(Context &ctx)
+{
+    for (Texture &t : ctx.textures) {
+        if (!t.alive || t.nLevels != 0) continue;
+        int levels = 1;
+        t.mips.clear();
+        const float *src = t.px.data();
+        int sw = t.w, sh = t.h;
+        std::vector<float> prev;
+        while ((sw > 1 || sh > 1) && t.filter != HR_FILTER_NEAREST) {
+            const int dw = sw / 2 < 1 ? 1 : sw / 2, dh = sh / 2 < 1 ? 1 : sh / 2;
+            std::vector<float> lvl((size_t)dw * dh * t.c);
+            for (int y = 0; y < dh; ++y)
+                for (int x = 0; x < dw; ++x) {
+                    const int x0 = 2 * x < sw ? 2 * x : sw - 1, x1 = 2 * x + 1 < sw ? 2 * x + 1 : sw - 1;
+                    const int y0 = 2 * y < sh ? 2 * y : sh - 1, y1 = 2 * y + 1 < sh ? 2 * y + 1 : sh - 1;
+                    for (int k = 0; k < t.c; ++k) {
+                        const float a = src[((size_t)y0 * sw + x0) * t.c + k], b = src[((size_t)y0 * sw + x1) * t.c + k];
+                        const float c = src[((size_t)y1 * sw + x0) * t.c + k], d = src[((size_t)y1 * sw + x1) * t.c + k];
+                        lvl[((size_t)y * dw + x) * t.c + k] = ((a + b) + (c + d)) * 0.25f;
+                    }
+                }
+            t.mips.insert(t.mips.end(), lvl.begin(), lvl.end());
+            prev.swap(lvl);
+            src = prev.data(), sw = dw, sh = dh;
+            ++levels;
+        }
+        t.nLevels = levels;
+        t.lodScale = 0.5f * (log_((float)t.w * (float)t.h) * 1.4426950408889634f);
+    }
+    const size_t n = ctx.tris.size();
+    ctx.texDensity.assign(n, -1e30f);
+    for (size_t i = 0; i < n; ++i) {
+        const Tri &tr = ctx.tris[i];
+        const TriAttr &a = ctx.attrs[i];
+        const float world2 = length(cross(tr.e1, tr.e2));
+        const float du1 = a.uv[1].x - a.uv[0].x, dv1 = a.uv[1].y - a.uv[0].y, du2 = a.uv[2].x - a.uv[0].x, dv2 = a.uv[2].y - a.uv[0].y;
+        const float uv2 = fabsf(du1 * dv2 - dv1 * du2);
+        if (world2 > 0.0f && uv2 > 0.0f) ctx.texDensity[i] = 0.5f * (log_(uv2 / world2) * 1.4426950408889634f);
+    }
+}
+
 static inline vec3 fetch3(const std::vector<float> &a, uint32_t i) { return vec3(a[3 * i], a[3 * i + 1], a[3 * i + 2]); }
 
 void commitScene(Context &ctx)

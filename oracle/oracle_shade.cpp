@@ -15,6 +15,7 @@
 #include "oracle_internal.h"
 
 #include <cmath>
+#include <cstring>
 #include <omp.h>
 
 namespace ora {
@@ -35,7 +36,19 @@ struct Ray {
     int missKind = MISS_NONE, missIdx = 0; // rl_OutRay.defaultPrimitive
     int srcPrim = -1;
     bool valid = false;
+    float coneW = 0.0f, coneG = 0.0f; // ray cone of HR_TEXTURE_LOD_CONE: width at the origin, spread angle
 };
+
+// The product keeps the cone in one dword of its ray record (upper halves of the two floats): the truncation is part of the contract
+static inline float coneQuant(float x)
+{
+    uint32_t b;
+    std::memcpy(&b, &x, 4);
+    b &= 0xFFFF0000u;
+    std::memcpy(&x, &b, 4);
+    return x;
+}
+static inline float widenCone(float g, float roughness) { return fmin_(g + 0.25f * roughness, 1.0f); }
 
 struct Shader {
     Context &ctx;
@@ -45,6 +58,7 @@ struct Shader {
                      // and added to the accumulation buffer ONCE when the path ends
     hr_pass_stats &st;
     TraceCounters tc, tcAny;
+    float lodBase = -1e30f; // HR_TEXTURE_LOD_CONE: level offset of the current hit's footprint
 
     Shader(Context &c, const hr_pass_params &p, float *pixel, hr_pass_stats &s) : ctx(c), pp(p), fbPixel(pixel), st(s)
     {
@@ -92,6 +106,7 @@ struct Shader {
     vec4 tex(int id, vec2 uv) const
     {
         if (id < 0 || id >= (int)ctx.textures.size() || !ctx.textures[id].alive) return vec4{1.0f, 1.0f, 1.0f, 1.0f}; // dummy white texel (Texture.h:188-203)
+        if (pp.texture_lod == HR_TEXTURE_LOD_CONE) return sampleTextureLod(ctx.textures[id], uv.x, uv.y, lodBase + ctx.textures[id].lodScale);
         return sampleTexture(ctx.textures[id], uv.x, uv.y);
     }
 
@@ -505,6 +520,7 @@ struct Shader {
                 r.occlusionTest = (missKind != MISS_NONE);
                 r.missKind = missKind, r.missIdx = 0;
                 r.extraT = 0.0f;
+                r.coneG = widenCone(in.coneG, 1.0f);
                 if (missKind == MISS_ENV && !ctx.lights.env_enabled) return;
                 emit(r, nee, next);
             }
@@ -568,6 +584,7 @@ struct Shader {
                 r.occlusionTest = (missKind != MISS_NONE);
                 r.missKind = missKind, r.missIdx = 0;
                 r.extraT = 0.0f;
+                r.coneG = widenCone(in.coneG, roughness);
                 if (missKind == MISS_ENV && !ctx.lights.env_enabled) return;
                 emit(r, nee, next);
             }
@@ -830,6 +847,7 @@ struct Shader {
                 r.occlusionTest = (missKind != MISS_NONE);
                 r.missKind = missKind, r.missIdx = 0;
                 r.extraT = 0.0f;
+                r.coneG = widenCone(in.coneG, roughnessAlpha);
                 if (missKind == MISS_ENV && !ctx.lights.env_enabled) return;
                 emit(r, nee, next);
             }
@@ -953,6 +971,7 @@ struct Shader {
                 r.extraT = 0.0f;
                 r.missKind = ctx.lights.env_enabled ? MISS_ENV : MISS_NONE;
                 r.missIdx = 0;
+                r.coneG = widenCone(in.coneG, roughnessAlpha);
                 next = r;
             }
         } else { // :257-279
@@ -1029,7 +1048,22 @@ struct Shader {
         out.extraT = 0.0f;
         out.depth = 0;
         out.valid = true;
+        out.coneW = 0.0f;
+        out.coneG = 2.0f * pp.fov_tan / H;
         return true;
+    }
+
+    // Advance the ray's cone to the hit and derive the footprint's level offset on this triangle (HR_TEXTURE_LOD_CONE)
+    void setFootprint(Ray &in, const Hit &h)
+    {
+        const float hitW = in.coneW + in.coneG * h.t;
+        in.coneW = hitW;
+        lodBase = -1e30f;
+        if (pp.texture_lod != HR_TEXTURE_LOD_CONE || ctx.texDensity.size() != ctx.tris.size() || !(hitW > 0.0f)) return;
+        const TriAttr &a = ctx.attrs[h.prim];
+        const vec3 normal = lerp3(a.n, 1.0f - h.u - h.v, h.u, h.v);
+        const float cosT = fmax_(fabsf(dot(in.d, normal)), 0.1f);
+        lodBase = ctx.texDensity[h.prim] + log_(hitW / cosT) * 1.4426950408889634f;
     }
 
     void tracePath(int x, int y)
@@ -1038,6 +1072,7 @@ struct Shader {
         if (!generatePrimary(x, y, ray)) return;
         st.paths++;
         while (ray.valid) {
+            ray.coneW = coneQuant(ray.coneW), ray.coneG = coneQuant(ray.coneG); // (the product's ray record)
             st.rays_closest++;
             Hit h = traceClosest(ctx, ray.o, ray.d, ctx.rayEps, ray.maxT, ray.srcPrim, &tc, ctx.brute);
             if (h.prim < 0) {
@@ -1046,6 +1081,7 @@ struct Shader {
                 break;
             }
             Ray nee, next;
+            setFootprint(ray, h);
             const int mid = ctx.attrs[h.prim].material;
             if (mid >= 0 && mid < (int)ctx.materials.size()) {
                 const hr_material &M = ctx.materials[mid];
@@ -1070,6 +1106,7 @@ struct Shader {
 void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
 {
     if (pp.estimator == HR_ESTIMATOR_ENV_MIS) buildEnvTable(ctx);
+    if (pp.texture_lod == HR_TEXTURE_LOD_CONE) buildTextureLod(ctx);
     const int W = ctx.W, H = ctx.H, tile = ctx.tile > 0 ? ctx.tile : 32;
     const int tilesX = (W + tile - 1) / tile;
     if (nThreads <= 0) nThreads = omp_get_max_threads();
@@ -1220,6 +1257,49 @@ void ora_kat_env_sample(hr_ctx *ctx, float u1, float u2, float out[4])
     Shader sh(c, pp, px, st);
     vec3 d = sh.sampleEnv(u1, u2);
     out[0] = d.x, out[1] = d.y, out[2] = d.z, out[3] = sh.envPdf(d);
+}
+// HR_TEXTURE_LOD_CONE: trilinear lookup of texture `tex` at level `lambda` (builds the mip chain); out = rgba
+void ora_kat_texture_lod(hr_ctx *ctx, int tex, float u, float v, float lambda, float out[4])
+{
+    Context &c = contextOf(ctx);
+    buildTextureLod(c);
+    const vec4 r = sampleTextureLod(c.textures[tex], u, v, lambda);
+    out[0] = r.x, out[1] = r.y, out[2] = r.z, out[3] = r.w;
+}
+// number of levels of texture `tex` and a copy of level `level` (>= 1) into out (may be null); returns the level count
+int ora_kat_texture_level(hr_ctx *ctx, int tex, int level, float *out)
+{
+    Context &c = contextOf(ctx);
+    buildTextureLod(c);
+    const Texture &t = c.textures[tex];
+    if (out && level >= 1 && level < t.nLevels) {
+        size_t off = 0;
+        int w = t.w, h = t.h;
+        for (int l = 1; l <= level; ++l) {
+            if (l > 1) off += (size_t)w * h * t.c;
+            w = w / 2 < 1 ? 1 : w / 2, h = h / 2 < 1 ? 1 : h / 2;
+        }
+        std::memcpy(out, &t.mips[off], sizeof(float) * (size_t)w * h * t.c);
+    }
+    return t.nLevels;
+}
+// the footprint's level offset (Shader::setFootprint) for a ray with cone (coneW, coneG) hitting triangle `prim` at distance t with
+// barycentrics (u, v); out[0] = lodBase, out[1] = the cone width at the hit, out[2] = texDensity[prim]
+void ora_kat_footprint(hr_ctx *ctx, int prim, const float dir[3], float coneW, float coneG, float t, float u, float v, float out[3])
+{
+    Context &c = contextOf(ctx);
+    buildTextureLod(c);
+    hr_pass_params pp{};
+    pp.texture_lod = HR_TEXTURE_LOD_CONE;
+    hr_pass_stats st{};
+    float px[4] = {0, 0, 0, 0};
+    Shader sh(c, pp, px, st);
+    Ray r;
+    r.d = vec3(dir[0], dir[1], dir[2]), r.coneW = coneW, r.coneG = coneG;
+    Hit h;
+    h.prim = prim, h.t = t, h.u = u, h.v = v;
+    sh.setFootprint(r, h);
+    out[0] = sh.lodBase, out[1] = r.coneW, out[2] = c.texDensity[prim];
 }
 // the light / miss shaders (environmentLight / directionalLight / pointLight / spotLight.rlsl) for a ray that reached its light:
 // missKind 1 env 2 directional 3 point 4 spot; out = the value performAccumulate added (clamped by maxChannelValue)

@@ -40,7 +40,7 @@ def test_struct_sizes_match_the_c_layout():
     assert ctypes.sizeof(ffi.MeshDesc) == 6 * 8 + 7 * 4 + 4 + 8 + 4 + 4 + 64 + 12 + 4
     assert ctypes.sizeof(ffi.Material) == 4 * 10 + 4 * 15
     assert ctypes.sizeof(ffi.Lights) == 4 + 120 + 4 + 120 + 4 + 180 + 40 + 16
-    assert ctypes.sizeof(ffi.PassParams) == 7 * 4 + 64 + 4 + 16 + 4 + 6 * 4
+    assert ctypes.sizeof(ffi.PassParams) == 7 * 4 + 64 + 4 + 16 + 4 + 7 * 4
     assert ctypes.sizeof(ffi.PassStats) == 80
     assert ctypes.sizeof(ffi.Hit) == 16
 

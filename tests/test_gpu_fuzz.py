@@ -117,6 +117,8 @@ def random_scene(seed):
     o.max_channel_value = float(F(rng.choice([math.pi, 1.0, 50.0])))
     # the importance-sampled environment + MIS estimator (include/hrcore.h) on a part of the scenes (a no-op without a map)
     o.estimator = ffi.HR_ESTIMATOR_ENV_MIS if rng.random() < 0.4 else ffi.HR_ESTIMATOR_REFERENCE
+    # mip chain + ray-cone texture lookups (include/hrcore.h) on a third of the scenes
+    o.texture_lod = ffi.HR_TEXTURE_LOD_CONE if rng.random() < 0.35 else ffi.HR_TEXTURE_LOD_BASE
     return sc
 
 

@@ -394,6 +394,42 @@ def test_env_mis_estimator_bit_exact(golden, u8_env):
     assert_parity(g2, o2, "env MIS estimator, soup with HDRI")
 
 
+def test_texture_lod_cone_bit_exact(golden):
+    # HR_TEXTURE_LOD_CONE (include/hrcore.h): mip chains and per-triangle texel densities are built on the device, the ray cone rides
+    # in the ray record, the trilinear lookup follows the oracle's arithmetic — bit-exact HDR buffers, f32 and u8 textures
+    sc = scenes.multi_material(96, 54, bounces=5, passes=16, textured=True)
+    rng = np.random.default_rng(11)
+    sc.textures[0] = (rng.random((37, 50, 3)).astype(np.float32), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_LINEAR)            # odd, non-square
+    sc.textures[1] = ((rng.random((64, 16, 3)) * 255).astype(np.uint8), ffi.HR_WRAP_CLAMP_TO_EDGE, ffi.HR_FILTER_LINEAR)
+    sc.options.texture_lod = ffi.HR_TEXTURE_LOD_CONE
+    g, o, ge, oe = render_both(sc, 5, lut=golden["multiscatter_lut"])
+    assert_parity(g, o, "cone LOD, multi-material")
+    sc.options.texture_lod = ffi.HR_TEXTURE_LOD_BASE                   # switching back and forth on live engines
+    for eng in (ge, oe):
+        eng.clear()
+        for s_ in range(3):
+            eng.render_pass(sc.options.pass_params(s_))
+    base_g, base_o = ge.readback(), oe.readback()
+    assert_parity(base_g, base_o, "level 0 after the cone mode")
+    assert base_g.tobytes() != g.tobytes()
+    # a transform edit changes world areas, hence the per-triangle level offsets: they are rebuilt with the commit
+    sc.options.texture_lod = ffi.HR_TEXTURE_LOD_CONE
+    m = np.diag([2.5, 0.4, 1.7, 1.0]).astype(np.float32)
+    for eng in (ge, oe):
+        eng.set_transform(0, m)
+        eng.commit()
+        eng.clear()
+        for s_ in range(3):
+            eng.render_pass(sc.options.pass_params(s_))
+    assert_parity(ge.readback(), oe.readback(), "cone LOD after a transform edit")
+    # the lookup itself (base-colour visualiser) on a fine checker at three distances: level 0, a fractional level, the uniform top
+    import test_oracle_kat as kat
+    for dist in (0.05, 6.0, 40.0):
+        ck = kat.checker_plane(dist, ffi.HR_TEXTURE_LOD_CONE, size=32)
+        g2, o2, _, _ = render_both(ck, 1, lut=golden["multiscatter_lut"])
+        assert_parity(g2, o2, f"checker at {dist}")
+
+
 def test_debug_visualizers(golden):
     sc = scenes.multi_material(64, 36, bounces=2, textured=True)
     for mode in (ffi.HR_VIS_GEOMETRIC_NORMALS, ffi.HR_VIS_UVS, ffi.HR_VIS_FINAL_NORMALS, ffi.HR_VIS_BASE_COLOR,

@@ -711,3 +711,141 @@ def test_env_mis_table_density_and_light_pick():
     assert oi[0] == 1 and of[0] == pytest.approx(w_dir / (w_dir + w_env), rel=1e-4)
     s = light_sample(eng, (0, 1, 0), (0, 0, 0), 0.999)                                   # the reference estimator keeps the constant 50
     assert s["type"] == 4 and s["prob"] == pytest.approx(50.0 / (50.0 + w_dir), rel=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ texture LOD (mip chain + ray cones)
+# HR_TEXTURE_LOD_CONE (include/hrcore.h) is NOT in the reference-faithful path (OpenRL's level selection in ray shaders is closed).
+# Its oracle contract is pinned here against independent numpy restatements: the box-filtered chain, the trilinear blend, the
+# footprint-to-level formula, and two scene-level consequences (a distant fine checker turns into its mean; a near one is unchanged).
+def lod_lib():
+    L = oracle_lib.load()
+    L.ora_kat_texture_lod.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    L.ora_kat_texture_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.ora_kat_texture_level.restype = C.c_int
+    L.ora_kat_footprint.argtypes = [C.c_void_p, C.c_int, f3, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, f3]
+    return L
+
+
+def numpy_chain(px):
+    """2x2 box filter with source coordinates clamped to the level below (odd sizes), float32, pairwise sums."""
+    levels = [px.astype(F)]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        s = levels[-1]
+        sh, sw = s.shape[:2]
+        dh, dw = max(1, sh // 2), max(1, sw // 2)
+        ys0, ys1 = np.minimum(2 * np.arange(dh), sh - 1), np.minimum(2 * np.arange(dh) + 1, sh - 1)
+        xs0, xs1 = np.minimum(2 * np.arange(dw), sw - 1), np.minimum(2 * np.arange(dw) + 1, sw - 1)
+        a, b, c, d = s[ys0][:, xs0], s[ys0][:, xs1], s[ys1][:, xs0], s[ys1][:, xs1]
+        levels.append((((a + b).astype(F) + (c + d).astype(F)).astype(F) * F(0.25)).astype(F))
+    return levels
+
+
+def numpy_bilinear(level, u, v):
+    h, w = level.shape[:2]
+    x, y = u * w - 0.5, v * h - 0.5
+    x0, y0 = math.floor(x), math.floor(y)
+    fx, fy = x - x0, y - y0
+    g = lambda xx, yy: level[yy % h, xx % w].astype(np.float64)
+    return (g(x0, y0) * (1 - fx) + g(x0 + 1, y0) * fx) * (1 - fy) + (g(x0, y0 + 1) * (1 - fx) + g(x0 + 1, y0 + 1) * fx) * fy
+
+
+@pytest.mark.parametrize("shape,dtype", [((16, 16, 3), F), ((12, 7, 4), F), ((9, 32, 1), np.uint8), ((5, 5, 3), np.uint8)])
+def test_mip_chain_and_trilinear_lookup(shape, dtype):
+    rng = np.random.default_rng(3)
+    px = (rng.random(shape) * 255).astype(np.uint8) if dtype == np.uint8 else rng.random(shape).astype(F)
+    eng = oracle_lib.engine()
+    tid = eng.create_texture(px, ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_LINEAR)
+    L = lod_lib()
+    as_float = (px.astype(F) / F(255.0)).astype(F) if dtype == np.uint8 else px
+    want = numpy_chain(as_float)
+    n = L.ora_kat_texture_level(eng._ctx, tid, 0, None)
+    assert n == len(want) == 1 + int(math.floor(math.log2(max(shape[0], shape[1]))))
+    for lvl in range(1, n):
+        got = np.zeros(want[lvl].shape, dtype=F)
+        L.ora_kat_texture_level(eng._ctx, tid, lvl, got.ctypes.data_as(C.POINTER(C.c_float)))
+        assert got.tobytes() == want[lvl].tobytes(), lvl              # same float32 operations: bit-identical
+        assert abs(float(got.mean()) - float(as_float.mean())) < 0.12  # a box filter keeps the mean (up to the odd-size clamping)
+    out = (C.c_float * 4)()
+    for lam in [-1.0, 0.0, 0.3, 1.0, 1.75, n - 1.0, n + 3.0]:
+        for (u, v) in [(0.13, 0.71), (0.5, 0.5), (0.99, 0.02)]:
+            L.ora_kat_texture_lod(eng._ctx, tid, u, v, lam, out)
+            l = min(max(lam, 0.0), n - 1.0)
+            l0 = int(math.floor(l))
+            f = l - l0
+            a = numpy_bilinear(want[l0], u, v)
+            b = numpy_bilinear(want[min(l0 + 1, n - 1)], u, v)
+            ref = a * (1 - f) + b * f
+            c = shape[2]
+            got = np.array(out[:c if c > 1 else 1])
+            assert np.allclose(got, ref[:len(got)], atol=3e-6), (lam, u, v, got, ref)
+    tn = eng.create_texture(px, ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_NEAREST)      # nearest-filtered textures have no chain
+    assert L.ora_kat_texture_level(eng._ctx, tn, 0, None) == 1
+
+
+def checker_plane(distance, lod, size=24, checks=256, vis=True):
+    """The reference's ground plane (uv in [-1, 1]^2 over 8 x 8 world units) with a `checks` x `checks` one-texel checkerboard, seen
+    from straight above at `distance`; the base-colour visualiser shows the texture lookup itself."""
+    sc = scenes.Scene("checker", width=size, height=size, use_multiscatter_lut=False)
+    p, n, uv, i = scenes.plane_strip(8, 8)
+    chk = (np.add.outer(np.arange(checks), np.arange(checks)) % 2).astype(F)
+    sc.textures.append((np.stack([chk] * 3, axis=-1), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_LINEAR))
+    sc.materials[0] = host.bake_pbr(base_color=(1, 1, 1), roughness=1.0, metallic=0.0, specular_f0=0.0, base_color_texture=0)
+    sc.meshes.append(scenes.MeshData(p, n, i, uvs=uv, mode=ffi.HR_TRIANGLE_STRIP, material_id=0))
+    o = sc.options
+    o.max_ray_depth, o.aspect_ratio, o.fstop, o.focal_length = 1, 1.0, host.FSTOP_DISABLED, 50.0
+    o.view_matrix = host.orbit_view_matrix(distance, 0.0, math.pi / 2 - 1e-3)
+    o.texture_lod = lod
+    if vis:
+        o.visualizer_mode = ffi.HR_VIS_BASE_COLOR
+    return sc
+
+
+def test_footprint_level_formula():
+    # lambda = 0.5 log2(uv area / world area) + 0.5 log2(W H) + log2(cone width / |cos|): texels across the footprint, as a level
+    sc = checker_plane(10.0, ffi.HR_TEXTURE_LOD_CONE)
+    eng = oracle_lib.engine()
+    sc.apply(eng)
+    L = lod_lib()
+    out = f3()
+    for (cw, cg, t, cos_i) in [(0.0, 0.002, 10.0, 1.0), (0.01, 0.001, 3.0, 0.5), (0.0, 0.25, 1.0, 0.05)]:
+        d = f3(math.sqrt(1 - cos_i * cos_i), -cos_i, 0.0)
+        L.ora_kat_footprint(eng._ctx, 0, d, cw, cg, t, 0.3, 0.3, out)
+        w = cw + cg * t
+        density = 0.5 * math.log2((2.0 * 2.0) / (8.0 * 8.0))                 # uv spans 2 x 2 over 8 x 8 world units (per triangle: halves cancel)
+        want = density + math.log2(w / max(cos_i, 0.1))
+        assert abs(out[1] - w) < 1e-6 * max(1.0, w)
+        assert abs(out[2] - density) < 1e-5
+        assert abs(out[0] - want) < 2e-5, (out[0], want)
+
+
+def test_distant_checker_becomes_its_mean_and_a_near_one_is_untouched():
+    far_base, _ = render(checker_plane(40.0, ffi.HR_TEXTURE_LOD_BASE), 1)
+    far_cone, _ = render(checker_plane(40.0, ffi.HR_TEXTURE_LOD_CONE), 1)
+    base = (far_base[..., 0] / far_base[..., 3])[9:15, 9:15]         # the plane fills the central 40 % of the frame
+    cone = (far_cone[..., 0] / far_cone[..., 3])[9:15, 9:15]
+    # pixel angle 2 tan(fov/2) / H = 0.02 rad -> 0.8 world units = 25.6 texels at distance 40: level 4.7, where the checker is uniform 0.5
+    assert base.std() > 0.05                                      # level 0: aliased noise
+    assert np.ptp(cone) < 1e-7 and abs(float(cone.mean()) - float(base.mean())) < 0.02   # one value: the checker's mean as the visualiser shows it
+    near = checker_plane(0.05, ffi.HR_TEXTURE_LOD_CONE, checks=8)  # footprint 0.001 world units = 0.001 texels: level 0
+    near_b = checker_plane(0.05, ffi.HR_TEXTURE_LOD_BASE, checks=8)
+    assert render(near, 1)[0].tobytes() == render(near_b, 1)[0].tobytes()
+
+
+def test_cone_lod_leaves_the_expectation_of_a_smooth_texture_alone_and_widens_after_a_bounce():
+    # a constant texture is the same at every level: the two modes agree to the bit on a full path-traced render
+    def scene(lod):
+        sc = scenes.multi_material(48, 27, bounces=4, textured=True)
+        sc.textures[0] = (np.full((32, 32, 3), 0.6, dtype=F), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_LINEAR)
+        sc.textures[1] = (np.full((32, 32, 3), 128, dtype=np.uint8), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_LINEAR)
+        sc.options.texture_lod = lod
+        return sc
+    a, _ = render(scene(ffi.HR_TEXTURE_LOD_BASE), 3)
+    b, _ = render(scene(ffi.HR_TEXTURE_LOD_CONE), 3)
+    assert np.allclose(a, b, rtol=2e-6, atol=1e-7)               # (trilinear blends of equal values round differently in the last bit)
+    # the cone after a diffuse bounce: spread 0.25 rad on top of the pixel's angle (Ray.coneG travels as a bf16-truncated float)
+    sc = checker_plane(10.0, ffi.HR_TEXTURE_LOD_CONE)
+    eng = oracle_lib.engine()
+    sc.apply(eng)
+    out = f3()
+    lod_lib().ora_kat_footprint(eng._ctx, 0, f3(0, -1, 0), 0.2, 0.25 + 0.02, 2.0, 0.3, 0.3, out)
+    assert abs(out[1] - (0.2 + 0.27 * 2.0)) < 1e-6
