@@ -30,6 +30,11 @@ namespace hr {
 #endif
 static const int kBlock = 256;
 static const int kWavesPerBlock = kBlock / 64;
+#ifndef HR_TRACE_BLOCK
+#define HR_TRACE_BLOCK 256 // threads per workgroup of k_trace (an exited workgroup frees its CU slot only as a whole)
+#endif
+static const int kTraceBlock = HR_TRACE_BLOCK;
+static const int kTraceWaves = kTraceBlock / 64;
 
 HRD uint32_t laneId() { return threadIdx.x & 63u; }
 
@@ -251,17 +256,17 @@ __device__ unsigned long long g_tailprof[24]; // [0] min start clock, [1] min ex
 #endif
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
+__global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
                                                   StepTable *__restrict__ tbl, Stats *stats)
 {
-    __shared__ int stack[kWavesPerBlock][kStackLDS][64];
+    __shared__ int stack[kTraceWaves][kStackLDS][64];
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
 #if HR_TAIL_SHARE
     // merge slots of the drain phase (below): one per ray a wave held when the work queue ran dry
-    __shared__ unsigned long long mKey[kWavesPerBlock][64]; // min over the ray's fragments of (t bits, prim, face bit); kNoHitKey: none
-    __shared__ uint32_t mCount[kWavesPerBlock][64];         // fragments still traversing
-    __shared__ float2 mUV[kWavesPerBlock][64];              // barycentrics that belong to mKey
-    __shared__ uint32_t mDonor[kWavesPerBlock][64];         // k-th donating lane of this round
+    __shared__ unsigned long long mKey[kTraceWaves][64]; // min over the ray's fragments of (t bits, prim, face bit); kNoHitKey: none
+    __shared__ uint32_t mCount[kTraceWaves][64];         // fragments still traversing
+    __shared__ float2 mUV[kTraceWaves][64];              // barycentrics that belong to mKey
+    __shared__ uint32_t mDonor[kTraceWaves][64];         // k-th donating lane of this round
 #endif
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_trace(const SceneDev *__restrict__ S
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const int kRefill = tbl->refillLanes, kTriPhase = tbl->triPhaseLanes;
     const uint32_t fetchMax = (uint32_t)tbl->fetchMax, fetchMin = (uint32_t)tbl->fetchMin;
-    const uint32_t wavesTimes2 = 2u * gridDim.x * kWavesPerBlock;
+    const uint32_t wavesTimes2 = 2u * gridDim.x * kTraceWaves;
     uint32_t lastBase = 0; // wave-uniform: where the global cursor stood at this wave's previous reservation
 
     // ---- per-lane traversal state (one ray per lane, refilled from the work pool when a lane finishes)
@@ -841,11 +846,11 @@ void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &
 
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats)
 {
-    const int grid = cfg.numCUs * cfg.traceBlocksPerCU;
+    const int grid = cfg.numCUs * cfg.traceBlocksPerCU * (kBlock / kTraceBlock); // traceBlocksPerCU counts 256-thread workgroups
     if (cfg.collectStats)
-        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
+        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
     else
-        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
+        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
 }
 
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats)
