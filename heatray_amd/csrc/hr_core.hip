@@ -46,6 +46,9 @@ struct Geom {
 
 static const int kMaxGroups = 3;
 static const int kMaxSlots = 2 * kMaxSegs; // passes in flight over all groups
+#ifndef HR_BATCH_CAP
+#define HR_BATCH_CAP 32 // most passes injected per macro step (small frames / tile shards reach it: 1/8 of a 1080p frame runs 6.6 % faster with 32 than with 12, profiles/r2p_shard_batch.txt)
+#endif
 
 struct hr_ctx {
     int device = 0;
@@ -666,7 +669,7 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         const long long target = 9ll * 1920ll * 1080ll;
         const long long own = c->queueCapacity ? c->queueCapacity : 1;
         long long b = (target + own - 1) / own;
-        c->injectBatch = (int)(b < 1 ? 1 : (b > 16 ? 16 : b));
+        c->injectBatch = (int)(b < 1 ? 1 : (b > HR_BATCH_CAP ? HR_BATCH_CAP : b));
         if (c->tuneBatch > 0) c->injectBatch = c->tuneBatch;
         // Two pipeline groups (their steps alternate on two streams, so one group's trace tail and its shade / raygen run
         // under the other group's trace) pay off only while a launch carries little work: +11..14 % on a 1080p frame at one pass

@@ -46,7 +46,7 @@ struct SegDev {
 };
 
 #ifndef HR_MAX_SEGS
-#define HR_MAX_SEGS 120
+#define HR_MAX_SEGS 320
 #endif
 static const int kMaxSegs = HR_MAX_SEGS; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
 struct StepTable {
