@@ -13,6 +13,18 @@
 
 #define HRD __device__ __forceinline__
 
+// Pointers that the kernels read out of structures in memory (scene block, step table, texture descriptors) are "generic" to
+// the compiler: every access becomes a FLAT instruction, whose result can only be waited for with vmcnt(0) lgkmcnt(0) — a full
+// drain of everything in flight.  All of these pointers are hipMalloc'ed, so device code reads them through address space 1
+// (global_load / global_store, partial waits, SGPR-base addressing).  The host pass sees plain pointers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HR_GLOBAL __attribute__((address_space(1)))
+#else
+#define HR_GLOBAL
+#endif
+template <class T> HRD const HR_GLOBAL T *G(const T *p) { return (const HR_GLOBAL T *)p; }
+template <class T> HRD HR_GLOBAL T *G(T *p) { return (HR_GLOBAL T *)p; }
+
 namespace hr {
 
 struct v2 {

@@ -88,10 +88,10 @@ HRD uint32_t packMeta(const Ray &r)
 
 HRD void storeRay(const RayQueue &q, uint32_t slot, const Ray &r, uint32_t pixel, uint32_t srcPrim)
 {
-    q.A[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.maxT);
-    q.B[slot] = make_float4(r.d.x, r.d.y, r.d.z, r.extraT);
-    q.C[slot] = make_float4(r.weight.x, r.weight.y, r.weight.z, __uint_as_float(pixel));
-    q.D[slot] = make_int4((int)packMeta(r), r.sequenceIndexOffset, (int)srcPrim, (int)packCone(r.coneW, r.coneG));
+    G(q.A)[slot] = make_float4(r.o.x, r.o.y, r.o.z, r.maxT);
+    G(q.B)[slot] = make_float4(r.d.x, r.d.y, r.d.z, r.extraT);
+    G(q.C)[slot] = make_float4(r.weight.x, r.weight.y, r.weight.z, __uint_as_float(pixel));
+    G(q.D)[slot] = make_int4((int)packMeta(r), r.sequenceIndexOffset, (int)srcPrim, (int)packCone(r.coneW, r.coneG));
 }
 
 // pixel of thread `gid` in this context's tile shard: tiles in round-robin order, 8x8-pixel blocks inside
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
     bool active = inFrame;
     if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
     // the pass's sample starts at zero; perspective.rlsl:60 accumulate(vec4(0,0,0,1)) for sampled pixels
-    if (inFrame) reinterpret_cast<float4 *>(seg.passbuf)[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
+    if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
     const uint32_t slot = blockReserve(active, seg.qCountIn, scratch);
     if (active) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
     const uint32_t n = waveSum(active ? 1u : 0u);
@@ -356,11 +356,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     const SegDev &sg = tbl->seg[sI >> 1];
                     float4 a, b;
                     if (sI & 1) { // occlusion ray
-                        a = sg.sq.A[local], b = sg.sq.B[local];
+                        a = G(sg.sq.A)[local], b = G(sg.sq.B)[local];
                         skipPrim = __float_as_uint(b.w);
                     } else {
-                        a = sg.qin.A[local], b = sg.qin.B[local];
-                        skipPrim = (uint32_t)sg.qin.D[local].z;
+                        a = G(sg.qin.A)[local], b = G(sg.qin.B)[local];
+                        skipPrim = (uint32_t)G(sg.qin.D)[local].z;
                     }
                     o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
                     tmax = a.w, tlim = a.w;
@@ -565,8 +565,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 const SegDev &sg = tbl->seg[segIdx >> 1];
                 if (isAny) {
                     if (k == kNoHitKey) {
-                        const float4 c = sg.sq.C[local];
-                        float *px = sg.passbuf + (size_t)__float_as_uint(c.w) * 4;
+                        const float4 c = G(sg.sq.C)[local];
+                        HR_GLOBAL float *px = G(sg.passbuf) + (size_t)__float_as_uint(c.w) * 4;
                         px[0] = px[0] + c.x;
                         px[1] = px[1] + c.y;
                         px[2] = px[2] + c.z;
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                         const float2 uv = mUV[wave][slot];
                         h.prim = (lo >> 1) | (lo << 31), h.t = __uint_as_float((uint32_t)(k >> 32)), h.u = uv.x, h.v = uv.y;
                     }
-                    sg.hits[local] = h;
+                    G(sg.hits)[local] = h;
                 }
             }
 #ifdef HR_TAILPROF
@@ -593,15 +593,15 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
             const SegDev &sg = tbl->seg[segIdx >> 1];
             if (isAny) {
                 if (best.prim == kMissPrim) { // unoccluded: the light's shader accumulates into the pass's sample
-                    const float4 c = sg.sq.C[local];
-                    float *px = sg.passbuf + (size_t)__float_as_uint(c.w) * 4;
+                    const float4 c = G(sg.sq.C)[local];
+                    HR_GLOBAL float *px = G(sg.passbuf) + (size_t)__float_as_uint(c.w) * 4;
                     px[0] = px[0] + c.x;
                     px[1] = px[1] + c.y;
                     px[2] = px[2] + c.z;
                     ++nacc;
                 }
             } else {
-                sg.hits[local] = best;
+                G(sg.hits)[local] = best;
             }
 #ifdef HR_TAILPROF
             maxSteps = mySteps > maxSteps ? mySteps : maxSteps, sumSteps += mySteps, nRays += 1, mySteps = 0;
@@ -700,10 +700,10 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
             const uint32_t i0 = base + threadIdx.x;
             if (i0 < total) {
                 const int s0 = findSeg(i0);
-                const uint32_t hp = tbl->seg[s0].hits[i0 - segStart[2 * s0]].prim;
+                const uint32_t hp = G(tbl->seg[s0].hits)[i0 - segStart[2 * s0]].prim;
                 if (hp != kMissPrim) {
-                    const uint32_t mid0 = S.attrs[hp & 0x7FFFFFFFu].matflags & kMatMask;
-                    cls = (mid0 < (uint32_t)S.nMaterials && S.materials[mid0].type == HR_MAT_GLASS) ? 1 : 0;
+                    const uint32_t mid0 = G(S.attrs)[hp & 0x7FFFFFFFu].matflags & kMatMask;
+                    cls = (mid0 < (uint32_t)S.nMaterials && G(S.materials)[mid0].type == HR_MAT_GLASS) ? 1 : 0;
                 }
             }
         }
@@ -736,9 +736,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
         if (live) {
             const SegDev &sg = tbl->seg[sI];
             const uint32_t li = i - segStart[2 * sI];
-            const float4 a = sg.qin.A[li], b = sg.qin.B[li], c = sg.qin.C[li];
-            const int4 dm = sg.qin.D[li];
-            const HitRec h = sg.hits[li];
+            const float4 a = G(sg.qin.A)[li], b = G(sg.qin.B)[li], c = G(sg.qin.C)[li];
+            const int4 dm = G(sg.qin.D)[li];
+            const HitRec h = G(sg.hits)[li];
             Ray in;
             in.o = v3(a.x, a.y, a.z), in.d = v3(b.x, b.y, b.z), in.maxT = a.w, in.extraT = b.w;
             in.weight = v3(c.x, c.y, c.z);
@@ -750,7 +750,7 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
             in.occlusionTest = false, in.valid = true;
             in.coneW = in.coneG = 0.0f; // (the variant without the mode carries no cone: nothing to keep in registers)
             if (LOD) unpackCone((uint32_t)dm.w, in.coneW, in.coneG);
-            ShaderT<LOD> sh(S, sg.pp, sg.passbuf + (size_t)pixel * 4);
+            ShaderT<LOD> sh(S, sg.pp, G(sg.passbuf) + (size_t)pixel * 4);
             if (h.prim == kMissPrim) {
                 // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
                 if (in.missKind == MISS_ENV) sh.performAccumulate(sh.environmentRadiance(in.d, in.weight));
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                 const typename ShaderT<LOD>::Surface sf = sh.surface(in, prim, (h.prim >> 31) != 0u, h.t, h.u, h.v, mid);
                 sh.setFootprint(in, sf.normal, h.t, prim);
                 if (mid < (uint32_t)S.nMaterials) {
-                    const hr_material &M = S.materials[mid];
+                    const HR_GLOBAL hr_material &M = G(S.materials)[mid];
                     if (M.type == HR_MAT_GLASS) {
                         ++nShaded;
                         sh.glass(in, sf, h.t, M, nee, next);
@@ -781,9 +781,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
             const bool wantS = mine && nee.valid;
             const uint32_t sSlot = blockReserve(wantS, sg.sCountOut, scratch);
             if (wantS) {
-                sg.sq.A[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
-                sg.sq.B[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-                sg.sq.C[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+                G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
+                G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
             }
             const bool wantQ = mine && next.valid;
             const uint32_t qSlot = blockReserve(wantQ, sg.qCountOut, scratch);

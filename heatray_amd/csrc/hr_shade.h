@@ -36,11 +36,11 @@ HRD float widenCone(float g, float roughness) { return fmin_(g + 0.25f * roughne
 template <bool LOD> struct ShaderT {
     const SceneDev &S;
     const hr_pass_params &pp;
-    float *px; // RGBA of the pixel this path belongs to (single owner: plain read-modify-write)
+    HR_GLOBAL float *px; // RGBA of the pixel this path belongs to (single owner: plain read-modify-write)
     uint32_t nAccum;
     float lodBase; // HR_TEXTURE_LOD_CONE: log2(texels of a unit-uv-square texture under the cone's footprint); level 0 when <= 0
 
-    HRD ShaderT(const SceneDev &s, const hr_pass_params &p, float *pixel) : S(s), pp(p), px(pixel), nAccum(0), lodBase(-1e30f) {}
+    HRD ShaderT(const SceneDev &s, const hr_pass_params &p, HR_GLOBAL float *pixel) : S(s), pp(p), px(pixel), nAccum(0), lodBase(-1e30f) {}
 
     // Advance the ray's cone to the hit and derive the footprint's level offset on this triangle (HR_TEXTURE_LOD_CONE)
     HRD void setFootprint(Ray &in, v3 normal, float t, uint32_t prim)
@@ -51,7 +51,7 @@ template <bool LOD> struct ShaderT {
         in.coneW = hitW;
         if (pp.texture_lod != HR_TEXTURE_LOD_CONE || !S.texDensity || !(hitW > 0.0f)) return;
         const float cosT = fmax_(abs_(dot(in.d, normal)), 0.1f);
-        lodBase = S.texDensity[prim] + log_(hitW / cosT) * 1.4426950408889634f;
+        lodBase = G(S.texDensity)[prim] + log_(hitW / cosT) * 1.4426950408889634f;
     }
 
     // sequence.rlsl:18-28
@@ -59,7 +59,7 @@ template <bool LOD> struct ShaderT {
     {
         int ws = sequenceIndex % S.nSeq;
         int wv = sampleIndex % S.seqLen;
-        float2 f = S.seq[(size_t)ws * S.seqLen + wv];
+        float2 f = G(S.seq)[(size_t)ws * S.seqLen + wv];
         return v2{f.x, f.y};
     }
 
@@ -96,9 +96,11 @@ template <bool LOD> struct ShaderT {
 
     HRD v4 tex(int id, v2 uv) const
     {
-        if (id < 0 || id >= S.nTextures || !S.textures[id].px) return v4{1.0f, 1.0f, 1.0f, 1.0f}; // dummy white texel (Texture.h:188-203)
-        if (LOD && pp.texture_lod == HR_TEXTURE_LOD_CONE) return sampleTextureLod(S.textures[id], uv.x, uv.y, lodBase + S.textures[id].lodScale);
-        return sampleTexture(S.textures[id], uv.x, uv.y);
+        if (id < 0 || id >= S.nTextures) return v4{1.0f, 1.0f, 1.0f, 1.0f}; // dummy white texel (Texture.h:188-203)
+        const auto &t = G(S.textures)[id];
+        if (!t.px) return v4{1.0f, 1.0f, 1.0f, 1.0f};
+        if (LOD && pp.texture_lod == HR_TEXTURE_LOD_CONE) return sampleTextureLod(t, uv.x, uv.y, lodBase + t.lodScale);
+        return sampleTexture(t, uv.x, uv.y);
     }
 
     // environmentLight.rlsl:19-34 — radiance the environment shader passes to performAccumulate
@@ -111,7 +113,7 @@ template <bool LOD> struct ShaderT {
         float v = (-phi * HR_KONEOVERPI) + 0.5f;
         v4 t = v4{0.0f, 0.0f, 0.0f, 0.0f};
         int id = S.lights.env_texture;
-        if (id >= 0 && id < S.nTextures && S.textures[id].px) t = sampleTexture(S.textures[id], u, 1.0f - v);
+        if (id >= 0 && id < S.nTextures && G(S.textures)[id].px) t = sampleTexture(G(S.textures)[id], u, 1.0f - v);
         v3 sample = v3(t.x, t.y, t.z) * S.lights.env_exposure;
         return weight * sample;
     }
@@ -378,7 +380,7 @@ template <bool LOD> struct ShaderT {
     HRD v3 computeMultiscattering(int lut, v3 Cspec, float NdotI, float roughness) const // :17-23
     {
         float ms = 0.0f;
-        if (lut >= 0 && lut < S.nTextures && S.textures[lut].px) ms = sampleTexture(S.textures[lut], NdotI, roughness).x;
+        if (lut >= 0 && lut < S.nTextures && G(S.textures)[lut].px) ms = sampleTexture(G(S.textures)[lut], NdotI, roughness).x;
         return v3(1.0f) + Cspec * ms;
     }
     HRD void indirectDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float optionalLightSampleProbability, v2 rand,
@@ -427,9 +429,9 @@ template <bool LOD> struct ShaderT {
         envTexelOf(dir, i, j);
         const float cosEl = sqrt_(dir.x * dir.x + dir.z * dir.z);
         const float K = ((float)S.envW * (float)S.envH) / (HR_KTWOPI * HR_KPI);
-        return (S.envProb[(size_t)j * S.envW + i] * K) / fmax_(cosEl, 1e-6f);
+        return (G(S.envProb)[(size_t)j * S.envW + i] * K) / fmax_(cosEl, 1e-6f);
     }
-    static HRD int cdfFind(const float *cdf, int n, float x)
+    static HRD int cdfFind(const HR_GLOBAL float *cdf, int n, float x)
     {
         int lo = 0, hi = n - 1;
         while (lo < hi) {
@@ -444,10 +446,10 @@ template <bool LOD> struct ShaderT {
     HRD v3 sampleEnv(float u1, float u2) const
     {
         const int w = S.envW, h = S.envH;
-        const float *rc = S.envRowCdf;
+        const HR_GLOBAL float *rc = G(S.envRowCdf);
         const int j = cdfFind(rc, h, u1);
         const float fy = (u1 - rc[j]) / fmax_(rc[j + 1] - rc[j], 1e-20f);
-        const float *cc = S.envColCdf + (size_t)j * (w + 1);
+        const HR_GLOBAL float *cc = G(S.envColCdf) + (size_t)j * (w + 1);
         const int i = cdfFind(cc, w, u2);
         const float fx = (u2 - cc[i]) / fmax_(cc[i + 1] - cc[i], 1e-20f);
         const float t = ((float)j + saturate(fy)) / (float)h, u = ((float)i + saturate(fx)) / (float)w;
@@ -629,13 +631,13 @@ template <bool LOD> struct ShaderT {
         bool frontFacing;
         uint32_t triFlags;
     };
-    static HRD v3 lerp3(const float *a, float w, float u, float v)
+    static HRD v3 lerp3(const HR_GLOBAL float *a, float w, float u, float v)
     {
         return v3(a[0], a[1], a[2]) * w + v3(a[3], a[4], a[5]) * u + v3(a[6], a[7], a[8]) * v;
     }
     HRD Surface surface(const Ray &in, uint32_t prim, bool ccwFront, float t, float u, float v, uint32_t &material) const
     {
-        const TriAttr &a = S.attrs[prim];
+        const auto &a = G(S.attrs)[prim];
         Surface s;
         float w = 1.0f - u - v;
         s.P = in.o + in.d * t; // rl_IntersectionPoint
@@ -646,7 +648,7 @@ template <bool LOD> struct ShaderT {
         s.triFlags = mf >> 24;
         s.tangent = s.bitangent = s.color = v3(0.0f);
         if (S.attrsExt && (s.triFlags & (TF_HAS_TANGENTS | TF_HAS_COLORS))) {
-            const TriAttrExt &e = S.attrsExt[prim];
+            const auto &e = G(S.attrsExt)[prim];
             s.tangent = lerp3(e.tan, w, u, v);
             s.bitangent = lerp3(e.bit, w, u, v);
             s.color = lerp3(e.col, w, u, v);
@@ -657,7 +659,7 @@ template <bool LOD> struct ShaderT {
     }
 
     // ---- physicallyBased.rlsl:55-331 ----
-    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const hr_material &M, Ray &nee, Ray &next)
+    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next)
     {
         Ray in = inRay;
         const uint32_t F = M.flags;
@@ -863,7 +865,7 @@ template <bool LOD> struct ShaderT {
                                         MISS_ENV, nee, next);
         }
     }
-    HRD void glass(const Ray &in, const Surface &sf, float hitT, const hr_material &M, Ray &nee, Ray &next) // :138-280
+    HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next) // :138-280
     {
         const uint32_t F = M.flags;
         const bool hasTextures = (F & (HR_MF_HAS_BASE_COLOR_TEXTURE | HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE | HR_MF_HAS_NORMALMAP)) != 0;
@@ -997,10 +999,10 @@ HRD bool generatePrimary(const SceneDev &S, const hr_pass_params &pp, int W, int
     int sequenceID = (int)floor_(randomRL(fcx / Wf, fcy / Hf) * (float)S.nSeq); // :62
     int offIdx = (int)(fcy * Hf + fcx);                                         // :64 (height stride, pixel centres)
     offIdx = offIdx % S.nSeqOffsets;                                            // defined wrap instead of the reference's OOB read
-    float rnd = S.seqOffsets[offIdx].x;
+    float rnd = G(S.seqOffsets)[offIdx].x;
     int sequenceIndex = (int)floor_(rnd * pp.max_sample_index); // :65
     int ws = sequenceID % S.nSeq, wv = (pp.sample_index + sequenceIndex) % S.seqLen;
-    float2 sampleOffset = S.seq[(size_t)ws * S.seqLen + wv];
+    float2 sampleOffset = G(S.seq)[(size_t)ws * S.seqLen + wv];
     float spx = (fcx - 0.5f) + sampleOffset.x, spy = (fcy - 0.5f) + sampleOffset.y;
     float u = spx / Wf, v = spy / Hf;
     float cx = (2.0f * u - 1.0f) * pp.aspect_ratio * pp.fov_tan; // :72
@@ -1008,7 +1010,7 @@ HRD bool generatePrimary(const SceneDev &S, const hr_pass_params &pp, int W, int
     v3 dirCameraSpace = normalize(v3(cx, cy, -1.0f));
     v3 focalPoint = pp.focus_distance * dirCameraSpace; // :77
     int apIdx = (sequenceID * S.seqLen + pp.sample_index) % (S.nSeq * S.seqLen); // :78, wrapped
-    float2 ap = S.aperture[apIdx];
+    float2 ap = G(S.aperture)[apIdx];
     float ax = ((ap.x * 2.0f) - 1.0f) * pp.aperture_radius, ay = ((ap.y * 2.0f) - 1.0f) * pp.aperture_radius;
     v3 origin(ax, ay, 0.0f);
     v3 dir = focalPoint - origin;

@@ -16,15 +16,15 @@ HRD int wrapIndex(int i, int n, int mode)
     return m < 0 ? m + n : m;
 }
 
-HRD v4 texel(const TexDesc &t, int x, int y)
+template <class TD> HRD v4 texel(const TD &t, int x, int y)
 {
     const size_t at = ((size_t)y * t.w + x) * t.c;
     float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (t.dtype == HR_TEX_U8) { // openrl::Texture with RL_UNSIGNED_BYTE data: a quarter of the bytes of a float copy per texel fetched
-        const uint8_t *b = reinterpret_cast<const uint8_t *>(t.px) + at;
+        const HR_GLOBAL uint8_t *b = (const HR_GLOBAL uint8_t *)t.px + at;
         for (int k = 0; k < t.c; ++k) p[k] = (float)b[k] / 255.0f;
     } else {
-        const float *f = reinterpret_cast<const float *>(t.px) + at;
+        const HR_GLOBAL float *f = (const HR_GLOBAL float *)t.px + at;
         for (int k = 0; k < t.c; ++k) p[k] = f[k];
     }
     v4 r;
@@ -39,7 +39,7 @@ HRD v4 texel(const TexDesc &t, int x, int y)
     return r;
 }
 
-HRD v4 sampleTexture(const TexDesc &t, float u, float v)
+template <class TD> HRD v4 sampleTexture(const TD &t, float u, float v)
 {
     if (t.filter == HR_FILTER_NEAREST) {
         int x = wrapIndex((int)floor_(u * (float)t.w), t.w, t.wrapS);
@@ -70,16 +70,16 @@ HRD int mipDim(int n, int level)
     return d < 1 ? 1 : d;
 }
 // element offset of level `level` (>= 1) inside TexDesc::mips
-HRD size_t mipOffset(const TexDesc &t, int level)
+template <class TD> HRD size_t mipOffset(const TD &t, int level)
 {
     size_t off = 0;
     for (int l = 1; l < level; ++l) off += (size_t)mipDim(t.w, l) * (size_t)mipDim(t.h, l) * (size_t)t.c;
     return off;
 }
-HRD v4 texelAt(const TexDesc &t, int level, size_t levelOff, int lw, int x, int y)
+template <class TD> HRD v4 texelAt(const TD &t, int level, size_t levelOff, int lw, int x, int y)
 {
     if (level == 0) return texel(t, x, y);
-    const float *f = t.mips + levelOff + ((size_t)y * lw + x) * t.c;
+    const HR_GLOBAL float *f = (const HR_GLOBAL float *)t.mips + levelOff + ((size_t)y * lw + x) * t.c;
     v4 r;
     if (t.c == 1) {
         r.x = r.y = r.z = f[0], r.w = 1.0f;
@@ -90,7 +90,7 @@ HRD v4 texelAt(const TexDesc &t, int level, size_t levelOff, int lw, int x, int 
     }
     return r;
 }
-HRD v4 sampleTextureLevel(const TexDesc &t, int level, float u, float v)
+template <class TD> HRD v4 sampleTextureLevel(const TD &t, int level, float u, float v)
 {
     if (level == 0) return sampleTexture(t, u, v);
     const int lw = mipDim(t.w, level), lh = mipDim(t.h, level);
@@ -112,7 +112,7 @@ HRD v4 sampleTextureLevel(const TexDesc &t, int level, float u, float v)
     return r;
 }
 // trilinear: `lambda` is the level at which one texel covers the footprint (clamped to the chain)
-HRD v4 sampleTextureLod(const TexDesc &t, float u, float v, float lambda)
+template <class TD> HRD v4 sampleTextureLod(const TD &t, float u, float v, float lambda)
 {
     if (t.nLevels <= 1 || t.filter == HR_FILTER_NEAREST || !(lambda > 0.0f)) return sampleTexture(t, u, v);
     const float top = (float)(t.nLevels - 1);

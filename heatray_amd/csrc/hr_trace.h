@@ -236,18 +236,18 @@ HRD float safeInv(float d)
 // physicallyBased.rlsl:57-91 seen by an occlusion ray on a non-occluder (alpha-masked) primitive
 HRD bool alphaPasses(const SceneDev &S, uint32_t prim, float u, float v)
 {
-    const TriAttr &a = S.attrs[prim];
+    const auto &a = G(S.attrs)[prim];
     const uint32_t mid = a.matflags & kMatMask;
     if (mid >= (uint32_t)S.nMaterials) return false;
-    const hr_material &m = S.materials[mid];
+    const auto &m = G(S.materials)[mid];
     if (m.type != HR_MAT_PBR || !(m.flags & HR_MF_ALPHA_MASK)) return false;
     float alpha = 1.0f;
     if ((m.flags & HR_MF_HAS_BASE_COLOR_TEXTURE) && m.base_color_texture >= 0 && m.base_color_texture < S.nTextures &&
-        S.textures[m.base_color_texture].px) {
+        G(S.textures)[m.base_color_texture].px) {
         float w = 1.0f - u - v;
         float tu = a.uv[0] * w + a.uv[2] * u + a.uv[4] * v;
         float tv = a.uv[1] * w + a.uv[3] * u + a.uv[5] * v;
-        alpha = sampleTexture(S.textures[m.base_color_texture], tu, tv).w;
+        alpha = sampleTexture(G(S.textures)[m.base_color_texture], tu, tv).w;
     }
     return alpha < 1.0f;
 }
