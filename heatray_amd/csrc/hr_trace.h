@@ -54,7 +54,9 @@ struct RayK {
             cur = kSentinel;                                                       \
         else {                                                                     \
             --sp;                                                                  \
-            cur = (sp < kStackLDS) ? stackLane[sp * 64] : ovf[sp - kStackLDS];     \
+            /* two typed reads, not one read through a selected pointer: that one would be a FLAT load (both waitcnt counters, TA) */ \
+            cur = stackLane[(sp < kStackLDS ? sp : kStackLDS - 1) * 64];           \
+            if (sp >= kStackLDS) cur = ovf[sp - kStackLDS];                        \
         }                                                                          \
     } while (0)
 
