@@ -255,7 +255,7 @@ def main():
                     "sharded frame (no collective); the JSON line is marked emulated and is not a benchmark result")
     ap.add_argument("--converge", action="store_true", help="passes-to-converge p50 (BASELINE metric 2) over all 16 runs (default: 3 of them): an "
                     "8192-pass reference render + the runs; N = 1 only")
-    ap.add_argument("--estimator", default="reference", choices=["reference", "env_mis"], help="estimator of the timed region and of the convergence "
+    ap.add_argument("--estimator", default="reference", choices=["reference", "env_mis", "all_lights"], help="estimator of the timed region and of the convergence "
                     "leg: the reference's (BASELINE metric), or importance-sampled environment + one-sample MIS (include/hrcore.h)")
     ap.add_argument("--no-converge", action="store_true", help="skip the live passes-to-converge leg (the committed measurement is quoted, marked as such)")
     ap.add_argument("--converge-mis", action="store_true", help="also run the convergence leg with the env-MIS estimator")
@@ -316,7 +316,7 @@ def main():
     sc = build_scene(args.workload, args.width, args.height, max(32, passes_total))
     if args.depth >= 0:
         sc.options.max_ray_depth = args.depth
-    sc.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS if args.estimator == "env_mis" else ffi.HR_ESTIMATOR_REFERENCE
+    sc.options.estimator = {"reference": ffi.HR_ESTIMATOR_REFERENCE, "env_mis": ffi.HR_ESTIMATOR_ENV_MIS, "all_lights": ffi.HR_ESTIMATOR_ALL_LIGHTS}[args.estimator]
     stream = torch.cuda.current_stream().cuda_stream
     eng_rank = args.shard_rank if emulated else rank
     eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, time_kernels=True)
@@ -554,6 +554,11 @@ def main():
                 conv_mis = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
                 sc.options.estimator = ffi.HR_ESTIMATOR_REFERENCE
                 conv["env_mis"] = {k: conv_mis[k] for k in ("p50", "runs", "median_err_at_pass", "reference_render_s", "runs_s")}
+                # ... and with one analytic-light ray on top of it at every vertex (HR_ESTIMATOR_ALL_LIGHTS: no random choice of ONE light)
+                sc.options.estimator = ffi.HR_ESTIMATOR_ALL_LIGHTS
+                conv_all = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
+                sc.options.estimator = ffi.HR_ESTIMATOR_REFERENCE
+                conv["all_lights"] = {k: conv_all[k] for k in ("p50", "runs", "median_err_at_pass", "reference_render_s", "runs_s")}
         else:
             cpath = os.path.join(ROOT, "profiles", "converge.json")
             if os.path.exists(cpath):

@@ -38,7 +38,7 @@ HR_MF_VERTEX_COLORS = 1 << 9
 HR_SAMPLE_RANDOM, HR_SAMPLE_HALTON, HR_SAMPLE_HAMMERSLEY, HR_SAMPLE_BLUE_NOISE, HR_SAMPLE_SOBOL = range(5)
 HR_BOKEH_CIRCULAR, HR_BOKEH_PENTAGON, HR_BOKEH_HEXAGON, HR_BOKEH_OCTAGON = range(4)
 
-HR_ESTIMATOR_REFERENCE, HR_ESTIMATOR_ENV_MIS = 0, 1
+HR_ESTIMATOR_REFERENCE, HR_ESTIMATOR_ENV_MIS, HR_ESTIMATOR_ALL_LIGHTS = 0, 1, 2
 HR_TEXTURE_LOD_BASE, HR_TEXTURE_LOD_CONE = 0, 1
 (HR_VIS_NONE, HR_VIS_GEOMETRIC_NORMALS, HR_VIS_UVS, HR_VIS_TANGENTS, HR_VIS_BITANGENTS, HR_VIS_NORMALMAP,
  HR_VIS_FINAL_NORMALS, HR_VIS_BASE_COLOR, HR_VIS_ROUGHNESS, HR_VIS_METALLIC, HR_VIS_EMISSIVE, HR_VIS_CLEARCOAT,

@@ -55,6 +55,7 @@ struct hr_ctx {
     hipStream_t stream = nullptr;
     bool collectStats = false;
     bool textureLodUsed = false; // a pass has asked for HR_TEXTURE_LOD_CONE (kernel variant, see LaunchCfg)
+    bool allLightsUsed = false;  // a pass has asked for HR_ESTIMATOR_ALL_LIGHTS: pass slots hold two occlusion rays per path and a second partial sum
     int rank = 0, world = 1, tile = 32;
     int numCUs = 256;
     std::string err;
@@ -102,6 +103,7 @@ struct hr_ctx {
         ShadowQueue sq{};
         void *hits = nullptr;
         float *passbuf = nullptr;
+        float *passbufB = nullptr; // second partial sum (allLightsUsed): passbuf + W * H * 4, same allocation
         Counters *ctr = nullptr;
     };
     PassSlot slots[kMaxSlots];
@@ -252,7 +254,7 @@ struct hr_ctx {
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
     int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64;
-    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed}; }
+    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed}; }
 };
 
 #define FAIL(ctx, code, msg)  \
@@ -344,6 +346,21 @@ static void freeQueues(hr_ctx *c)
     }
     c->nSlotsAllocated = 0;
     c->queueCapacity = 0;
+}
+
+// how many passes may be in flight: each slot holds two ray queues, an occlusion queue, hit records and a pass buffer
+// (twice the occlusion queue and a second pass buffer once HR_ESTIMATOR_ALL_LIGHTS has been used)
+static void slotBudget(hr_ctx *c)
+{
+    size_t freeB = 0, totalB = 0;
+    c->maxSlots = kMaxSlots;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+        const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
+        const size_t k = c->allLightsUsed ? 2 : 1;
+        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 * k + hitRecordSize()) + fbBytes * k + sizeof(Counters);
+        const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
+        c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
+    }
 }
 
 static void freeTree(hr_ctx *c)
@@ -653,13 +670,7 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
     freeQueues(c);
     c->queueCapacity = (uint32_t)f.nOwnedTiles * (uint32_t)(c->tile * c->tile);
     // how many passes may be in flight: each slot holds two ray queues, an occlusion queue, hit records and a pass buffer
-    size_t freeB = 0, totalB = 0;
-    c->maxSlots = kMaxSlots;
-    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 + hitRecordSize()) + fbBytes + sizeof(Counters);
-        const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
-        c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
-    }
+    slotBudget(c);
     {
         // Paths per macro step worth launching for.  A trace launch ends in a tail of a few long rays (0.5-0.7 ms whatever it
         // carries) and every pass costs depth + 2 dependent launches, so passes requested back to back are collected and injected
@@ -1442,11 +1453,14 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
         if (e == hipSuccess) e = hipMalloc(&ps.q[i].C, n16);
         if (e == hipSuccess) e = hipMalloc(&ps.q[i].D, n16);
     }
-    if (e == hipSuccess) e = hipMalloc(&ps.sq.A, n16);
-    if (e == hipSuccess) e = hipMalloc(&ps.sq.B, n16);
-    if (e == hipSuccess) e = hipMalloc(&ps.sq.C, n16);
+    const size_t s16 = n16 * (c->allLightsUsed ? 2 : 1); // up to two occlusion rays per path with HR_ESTIMATOR_ALL_LIGHTS
+    if (e == hipSuccess) e = hipMalloc(&ps.sq.A, s16);
+    if (e == hipSuccess) e = hipMalloc(&ps.sq.B, s16);
+    if (e == hipSuccess) e = hipMalloc(&ps.sq.C, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.hits, cap * hitRecordSize());
-    if (e == hipSuccess) e = hipMalloc(&ps.passbuf, fbBytes);
+    // (with HR_ESTIMATOR_ALL_LIGHTS the sample's second partial sum lies right behind the first: k_trace indexes one buffer)
+    if (e == hipSuccess) e = hipMalloc(&ps.passbuf, fbBytes * (c->allLightsUsed ? 2 : 1));
+    if (e == hipSuccess && c->allLightsUsed) ps.passbufB = ps.passbuf + (size_t)c->W * c->H * 4;
     if (e != hipSuccess) { // say what ran out: a pass slot is the unit the pipeline's memory grows in
         size_t freeB = 0, totalB = 0;
         hipMemGetInfo(&freeB, &totalB);
@@ -1497,6 +1511,7 @@ static int resolveReady(hr_ctx *c)
                 if ((ps.active || ps.finished) && ps.order == want) next = &ps;
             if (!next || !next->finished) break;
             ready[bufs.n] = next;
+            bufs.bufB[bufs.n] = next->pp.estimator == HR_ESTIMATOR_ALL_LIGHTS ? next->passbufB : nullptr;
             bufs.buf[bufs.n++] = next->passbuf;
         }
         if (bufs.n == 0) return HR_OK;
@@ -1606,6 +1621,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         const int st = ps.step;
         sg.qin = ps.q[st & 1], sg.qout = ps.q[(st + 1) & 1], sg.sq = ps.sq;
         sg.hits = (HitRec *)ps.hits, sg.passbuf = ps.passbuf;
+        sg.passbufB = ps.pp.estimator == HR_ESTIMATOR_ALL_LIGHTS ? ps.passbufB : nullptr;
         sg.qCountIn = &ps.ctr->qCount[st];
         sg.sCountIn = st > 0 ? &ps.ctr->sCount[st - 1] : c->dZero;
         sg.qCountOut = &ps.ctr->qCount[st + 1];
@@ -1733,9 +1749,21 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
     if (pp->max_ray_depth < 0 || pp->max_ray_depth + 2 >= kMaxBounceSlots - 8) FAIL(c, HR_ERR_INVALID, "max_ray_depth out of range");
     if (pp->interactive_mode && (pp->block_size[0] <= 0 || pp->block_size[1] <= 0)) FAIL(c, HR_ERR_INVALID, "bad block size");
     int rc = HR_OK;
-    if (pp->estimator == HR_ESTIMATOR_ENV_MIS) {
+    if (pp->estimator == HR_ESTIMATOR_ENV_MIS || pp->estimator == HR_ESTIMATOR_ALL_LIGHTS) {
         rc = ensureEnvTable(c);
         if (rc) return rc;
+        if (pp->estimator == HR_ESTIMATOR_ALL_LIGHTS && !c->allLightsUsed) {
+            // pass slots grow (a second occlusion ray per path, a second partial sum per pass): the existing ones are released and
+            // re-allocated below with the new sizes
+            rc = drainPipeline(c);
+            if (rc) return rc;
+            QUIESCE(c);
+            const uint32_t keepCap = c->queueCapacity;
+            freeQueues(c);
+            c->queueCapacity = keepCap;
+            c->allLightsUsed = true;
+            slotBudget(c);
+        }
     } else if (pp->estimator != HR_ESTIMATOR_REFERENCE) {
         FAIL(c, HR_ERR_INVALID, "unknown estimator");
     }

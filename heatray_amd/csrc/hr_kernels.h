@@ -27,6 +27,7 @@ struct LaunchCfg {
     int shadeBlocksPerCU;
     bool collectStats;
     bool textureLod; // some pass has asked for HR_TEXTURE_LOD_CONE: launch the shading kernel that carries the trilinear sampler
+    bool allLights;  // some pass has asked for HR_ESTIMATOR_ALL_LIGHTS: the shading kernel that can emit two occlusion rays per vertex
 };
 
 // One in-flight pass as seen by the kernels of one macro step.
@@ -36,6 +37,7 @@ struct SegDev {
     ShadowQueue sq;      // occlusion rays: traced this step (emitted by the previous step's shade), then refilled by this step's shade
     HitRec *hits;        // closest-hit records of qin
     float *passbuf;      // RGBA32F sample of this pass (full-frame indexing)
+    float *passbufB;     // HR_ESTIMATOR_ALL_LIGHTS: the sample's second partial sum (analytic-light contributions), or null
     uint32_t *qCountIn;  // number of rays in qin
     uint32_t *sCountIn;  // number of occlusion rays to trace this step
     uint32_t *qCountOut; // counter shade appends qout with
@@ -70,6 +72,7 @@ struct SegList {
 struct PassBufList {
     int32_t n;
     const float *buf[kMaxBatch]; // pass samples, added to the frame in this order
+    const float *bufB[kMaxBatch]; // second partial sum of a pass sample (HR_ESTIMATOR_ALL_LIGHTS), or null
 };
 void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, const SegList &segs, const FrameDev &fr, Stats *stats);
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &bufs);

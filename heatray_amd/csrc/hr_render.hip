@@ -127,6 +127,7 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
     if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
     // the pass's sample starts at zero; perspective.rlsl:60 accumulate(vec4(0,0,0,1)) for sampled pixels
     if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
+    if (inFrame && seg.passbufB) G(reinterpret_cast<float4 *>(seg.passbufB))[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     const uint32_t slot = blockReserve(active, seg.qCountIn, scratch);
     if (active) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
     const uint32_t n = waveSum(active ? 1u : 0u);
@@ -142,7 +143,11 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, PassBufList buf
     const uint32_t pixel = (uint32_t)(y * fr.W + x);
     float4 a = reinterpret_cast<float4 *>(fr.fb)[pixel];
     for (int k = 0; k < bufs.n; ++k) {
-        const float4 s = reinterpret_cast<const float4 *>(bufs.buf[k])[pixel];
+        float4 s = reinterpret_cast<const float4 *>(bufs.buf[k])[pixel];
+        if (bufs.bufB[k]) { // HR_ESTIMATOR_ALL_LIGHTS: the pass's two partial sums meet here, then the sample joins the frame
+            const float4 t = reinterpret_cast<const float4 *>(bufs.bufB[k])[pixel];
+            s.x = s.x + t.x, s.y = s.y + t.y, s.z = s.z + t.z;
+        }
         a.x = a.x + s.x, a.y = a.y + s.y, a.z = a.z + s.z, a.w = a.w + s.w;
     }
     reinterpret_cast<float4 *>(fr.fb)[pixel] = a;
@@ -661,7 +666,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #define HR_SHADE_MINBLOCKS 4 // <= 128 VGPRs: four 256-thread workgroups per CU (measured best on MI355X; 5+ spills)
 #endif
 static const int kShadeBlock = HR_SHADE_BLOCK; // queue slots are reserved once per workgroup and pass (fewer same-address atomics)
-template <bool LOD>
+template <int MODE>
 __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
@@ -729,10 +734,11 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
         const uint32_t i = base + order[threadIdx.x];
         const bool live = i < total;
         const int sI = live ? findSeg(i) : 0;
-        Ray nee, next;
-        nee.valid = next.valid = false;
+        constexpr bool LOD = (MODE & 1) != 0, ALL = (MODE & 2) != 0;
+        Ray nee, next, nee2; // nee2: the analytic-light ray of HR_ESTIMATOR_ALL_LIGHTS (never valid in the kernels compiled without it)
+        nee.valid = next.valid = nee2.valid = false;
         uint32_t pixel = 0, prim = 0xFFFFFFFFu;
-        v3 neeValue(0.0f);
+        v3 neeValue(0.0f), neeValue2(0.0f);
         if (live) {
             const SegDev &sg = tbl->seg[sI];
             const uint32_t li = i - segStart[2 * sI];
@@ -750,14 +756,14 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
             in.occlusionTest = false, in.valid = true;
             in.coneW = in.coneG = 0.0f; // (the variant without the mode carries no cone: nothing to keep in registers)
             if (LOD) unpackCone((uint32_t)dm.w, in.coneW, in.coneG);
-            ShaderT<LOD> sh(S, sg.pp, G(sg.passbuf) + (size_t)pixel * 4);
+            ShaderT<MODE> sh(S, sg.pp, G(sg.passbuf) + (size_t)pixel * 4);
             if (h.prim == kMissPrim) {
                 // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
                 if (in.missKind == MISS_ENV) sh.performAccumulate(sh.environmentRadiance(in.d, in.weight));
             } else {
                 prim = h.prim & 0x7FFFFFFFu;
                 uint32_t mid;
-                const typename ShaderT<LOD>::Surface sf = sh.surface(in, prim, (h.prim >> 31) != 0u, h.t, h.u, h.v, mid);
+                const typename ShaderT<MODE>::Surface sf = sh.surface(in, prim, (h.prim >> 31) != 0u, h.t, h.u, h.v, mid);
                 sh.setFootprint(in, sf.normal, h.t, prim);
                 if (mid < (uint32_t)S.nMaterials) {
                     const HR_GLOBAL hr_material &M = G(S.materials)[mid];
@@ -766,10 +772,11 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                         sh.glass(in, sf, h.t, M, nee, next);
                     } else if (M.type == HR_MAT_PBR) {
                         ++nShaded;
-                        sh.physicallyBased(in, sf, M, nee, next);
+                        sh.physicallyBased(in, sf, M, nee, next, nee2);
                     }
                 }
                 if (nee.valid) nee.valid = sh.lightShaderValue(nee, neeValue);
+                if (ALL && nee2.valid) nee2.valid = sh.lightShaderValue(nee2, neeValue2);
             }
             nAccum += sh.nAccum;
         }
@@ -784,6 +791,17 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                 G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
                 G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
                 G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+            }
+            if (ALL) { // the second occlusion ray: its value goes to the pass's SECOND partial sum, which lies behind the first in the
+                       // same allocation — the trace kernel just sees a pixel index beyond the frame
+                const bool wantS2 = mine && nee2.valid;
+                const uint32_t s2 = blockReserve(wantS2, sg.sCountOut, scratch);
+                if (wantS2) {
+                    G(sg.sq.A)[s2] = make_float4(nee2.o.x, nee2.o.y, nee2.o.z, nee2.maxT);
+                    G(sg.sq.B)[s2] = make_float4(nee2.d.x, nee2.d.y, nee2.d.z, __uint_as_float(prim));
+                    const uint32_t pixelB = pixel + (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
+                    G(sg.sq.C)[s2] = make_float4(neeValue2.x, neeValue2.y, neeValue2.z, __uint_as_float(pixelB));
+                }
             }
             const bool wantQ = mine && next.valid;
             const uint32_t qSlot = blockReserve(wantQ, sg.qCountOut, scratch);
@@ -856,10 +874,13 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, co
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats)
 {
     const int grid = cfg.numCUs * cfg.shadeBlocksPerCU;
-    if (cfg.textureLod)
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
-    else
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
+    // four instantiations: bit 0 = HR_TEXTURE_LOD_CONE, bit 1 = HR_ESTIMATOR_ALL_LIGHTS compiled in; the plain one runs until a pass asks for more
+    switch ((cfg.textureLod ? 1 : 0) | (cfg.allLights ? 2 : 0)) {
+    case 0: hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+    case 1: hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+    case 2: hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+    default: hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+    }
 }
 
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out)

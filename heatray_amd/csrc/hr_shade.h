@@ -33,7 +33,9 @@ HRD float widenCone(float g, float roughness) { return fmin_(g + 0.25f * roughne
 
 // LOD: compiled with the ray-cone texture lookups of HR_TEXTURE_LOD_CONE.  The shading kernel exists in both variants; the one
 // without is what runs until a pass asks for the mode (its code and register allocation are those of the level-0 sampler alone).
-template <bool LOD> struct ShaderT {
+template <int MODE> struct ShaderT {
+    static constexpr bool LOD = (MODE & 1) != 0; // HR_TEXTURE_LOD_CONE compiled in
+    static constexpr bool ALL = (MODE & 2) != 0; // HR_ESTIMATOR_ALL_LIGHTS compiled in (a second occlusion ray per vertex)
     const SceneDev &S;
     const hr_pass_params &pp;
     HR_GLOBAL float *px; // RGBA of the pixel this path belongs to (single owner: plain read-modify-write)
@@ -249,7 +251,8 @@ template <bool LOD> struct ShaderT {
         float maxDistance;
         int type;
     };
-    HRD LightSample computeLightSample(v3 N, float lightProbability, v3 P) const
+    // withoutEnv: the pick among the analytic lights only (HR_ESTIMATOR_ALL_LIGHTS); type ENVIRONMENT with probability 0 if there is none
+    HRD LightSample computeLightSample(v3 N, float lightProbability, v3 P, bool withoutEnv = false) const
     {
         const hr_lights &L = S.lights;
         LightSample out;
@@ -295,9 +298,9 @@ template <bool LOD> struct ShaderT {
             }
         }
         float environment = 0.0f;
-        if (L.env_enabled) {
+        if (L.env_enabled && !withoutEnv) {
             // lightSampling.rlsl:74-79's constant 50, or for HR_ESTIMATOR_ENV_MIS the irradiance the map can deliver (pi x mean luminosity)
-            environment = (pp.estimator == HR_ESTIMATOR_ENV_MIS && S.envW > 0) ? (S.envMeanLum * HR_KPI) * L.env_exposure : 50.0f * L.env_exposure;
+            environment = (pp.estimator != HR_ESTIMATOR_REFERENCE && S.envW > 0) ? (S.envMeanLum * HR_KPI) * L.env_exposure : 50.0f * L.env_exposure;
             probabilitySum += environment;
         }
         float norm = 1.0f / greaterThanZero(probabilitySum);
@@ -409,7 +412,8 @@ template <bool LOD> struct ShaderT {
     }
     // ---- HR_ESTIMATOR_ENV_MIS (include/hrcore.h): importance sampling of the environment map + one-sample MIS.  Not in the
     // reference; the arithmetic is the oracle's (oracle/oracle_shade.cpp, same operations in the same order).
-    HRD bool envMis() const { return pp.estimator == HR_ESTIMATOR_ENV_MIS && S.envW > 0; }
+    HRD bool envMis() const { return pp.estimator != HR_ESTIMATOR_REFERENCE && S.envW > 0; }
+    HRD bool allLights() const { return ALL && pp.estimator == HR_ESTIMATOR_ALL_LIGHTS; }
     HRD void envTexelOf(v3 dir, int &i, int &j) const
     {
         float theta = atan2_(dir.x, -dir.z) + S.lights.env_theta_rotation;
@@ -522,9 +526,10 @@ template <bool LOD> struct ShaderT {
     }
 
     HRD void directDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float lightProbability, v2 rand, const m3 &frame,
-                                 Ray &nee, Ray &next) const // :52-98
+                                 Ray &nee, Ray &next, Ray &nee2) const // :52-98
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
+        const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
+        LightSample ls = computeLightSample(N, lightProbability, P, both);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -542,9 +547,21 @@ template <bool LOD> struct ShaderT {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    emit(r, nee, next);
+                    if (both)
+                        nee2 = r;
+                    else
+                        emit(r, nee, next);
                 }
             }
+        }
+        if (both) {
+            if (S.lights.env_enabled) {
+                if (envMis())
+                    envMisDiffuse(in, P, N, Cdiff, sampleProbability, 1.0f, rand, frame, nee, next);
+                else
+                    indirectDiffuseSample(in, P, N, Cdiff, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee, next);
+            }
+        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisDiffuse(in, P, N, Cdiff, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -586,9 +603,10 @@ template <bool LOD> struct ShaderT {
         }
     }
     HRD void directSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
-                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next) const // :153-220
+                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next, Ray &nee2) const // :153-220
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
+        const bool both = allLights();
+        LightSample ls = computeLightSample(N, lightProbability, P, both);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -613,9 +631,22 @@ template <bool LOD> struct ShaderT {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    emit(r, nee, next);
+                    if (both)
+                        nee2 = r;
+                    else
+                        emit(r, nee, next);
                 }
             }
+        }
+        if (both) {
+            if (S.lights.env_enabled) {
+                if (envMis())
+                    envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame, nee, next);
+                else
+                    indirectSpecularSample(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee,
+                                           next);
+            }
+        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -659,7 +690,7 @@ template <bool LOD> struct ShaderT {
     }
 
     // ---- physicallyBased.rlsl:55-331 ----
-    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next)
+    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, Ray &nee2)
     {
         Ray in = inRay;
         const uint32_t F = M.flags;
@@ -771,13 +802,13 @@ template <bool LOD> struct ShaderT {
             v2 rand = getSequenceValue(in.sequenceID + in.depth, si);
             v2 probability = getSequenceValue(in.sequenceID + in.depth + 1, si);
             if (probability.x <= diffuseProbability) {
-                directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next);
+                directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
                 directSpecularSample(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next);
+                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
                 directSpecularSample(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability, probability.y,
-                                     rand, frame, nee, next);
+                                     rand, frame, nee, next, nee2);
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330
@@ -973,7 +1004,7 @@ template <bool LOD> struct ShaderT {
         }
     }
 };
-using Shader = ShaderT<false>;
+using Shader = ShaderT<0>;
 
 // ---- perspective.rlsl:39-93 (frame shader) ----
 HRD float randomRL(float sx, float sy) { return fract(sin_(sx * 12.9898f + sy * 78.233f) * 43758.5453123f); } // utility.rlsl:15-18

@@ -59,6 +59,8 @@ struct Shader {
     hr_pass_stats &st;
     TraceCounters tc, tcAny;
     float lodBase = -1e30f; // HR_TEXTURE_LOD_CONE: level offset of the current hit's footprint
+    float pxB[3] = {0.0f, 0.0f, 0.0f}; // HR_ESTIMATOR_ALL_LIGHTS: second partial sum of the pass's sample (analytic-light NEE)
+    bool toB = false;
 
     Shader(Context &c, const hr_pass_params &p, float *pixel, hr_pass_stats &s) : ctx(c), pp(p), fbPixel(pixel), st(s)
     {
@@ -76,9 +78,10 @@ struct Shader {
     // ---- accumulator.rlsl:12-28 ----
     void accumulate3(vec3 c)
     {
-        px[0] = px[0] + c.x;
-        px[1] = px[1] + c.y;
-        px[2] = px[2] + c.z;
+        float *t = toB ? pxB : px; // HR_ESTIMATOR_ALL_LIGHTS keeps the analytic-light contributions in a second partial sum
+        t[0] = t[0] + c.x;
+        t[1] = t[1] + c.y;
+        t[2] = t[2] + c.z;
         st.accumulates++;
     }
     void accumulate4(vec3 c, float a) // accumulate(vec4) used by the debug visualisers
@@ -254,7 +257,7 @@ struct Shader {
         float maxDistance = INFINITY;
         int type = 0;
     };
-    LightSample computeLightSample(vec3 N, float lightProbability, vec3 P) const
+    LightSample computeLightSample(vec3 N, float lightProbability, vec3 P, bool withoutEnv = false) const
     {
         const hr_lights &L = ctx.lights;
         LightSample out;
@@ -291,7 +294,7 @@ struct Shader {
             }
         }
         float environment = 0.0f;
-        if (L.env_enabled) {
+        if (L.env_enabled && !withoutEnv) {
             // :74-79 "TODO: Add IBL importance sampling. Right now this is just a hack" — the constant 50 starves analytic lights
             // (a sun-like directional light is picked a few per cent of the time).  HR_ESTIMATOR_ENV_MIS weighs the map like the
             // other lights, by the irradiance it can deliver: pi x its mean luminosity.
@@ -376,7 +379,8 @@ struct Shader {
     // ---- HR_ESTIMATOR_ENV_MIS (include/hrcore.h): importance sampling of the environment map + one-sample MIS ----
     // Not in the reference (its shaders mark it TODO: lightSampling.rlsl:75-77, microfacet.rlsl:94-96); this is the contract the
     // HIP kernels reproduce bit for bit, with its own known-answer tests (tests/test_oracle_kat.py).
-    bool envMis() const { return pp.estimator == HR_ESTIMATOR_ENV_MIS && ctx.env.w > 0; }
+    bool envMis() const { return pp.estimator != HR_ESTIMATOR_REFERENCE && ctx.env.w > 0; }
+    bool allLights() const { return pp.estimator == HR_ESTIMATOR_ALL_LIGHTS; }
     // the texel a direction falls into, with environmentLight.rlsl:19-34's mapping (u to the right, t upwards)
     void envTexelOf(vec3 dir, int &i, int &j) const
     {
@@ -527,9 +531,10 @@ struct Shader {
         }
     }
     void directDiffuseSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 Cdiff, float sampleProbability, float lightProbability, vec2 rand,
-                             const mat3 &frame, Ray &nee, Ray &next) // :52-98
+                             const mat3 &frame, Ray &nee, Ray &next, Ray &nee2) // :52-98
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
+        const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
+        LightSample ls = computeLightSample(N, lightProbability, P, both);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -547,9 +552,21 @@ struct Shader {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    emit(r, nee, next);
+                    if (both)
+                        nee2 = r;
+                    else
+                        emit(r, nee, next);
                 }
             }
+        }
+        if (both) {
+            if (ctx.lights.env_enabled) {
+                if (envMis())
+                    envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, 1.0f, rand, frame, nee, next);
+                else
+                    indirectDiffuseSample(in, P, prim, N, Cdiff, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee, next);
+            }
+        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -592,9 +609,10 @@ struct Shader {
     }
     void directSpecularSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut,
                               float roughness, float sampleProbability, float lightProbability, vec2 rand, const mat3 &frame, Ray &nee,
-                              Ray &next) // :153-220
+                              Ray &next, Ray &nee2) // :153-220
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
+        const bool both = allLights();
+        LightSample ls = computeLightSample(N, lightProbability, P, both);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -619,9 +637,22 @@ struct Shader {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    emit(r, nee, next);
+                    if (both)
+                        nee2 = r;
+                    else
+                        emit(r, nee, next);
                 }
             }
+        }
+        if (both) {
+            if (ctx.lights.env_enabled) {
+                if (envMis())
+                    envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame, nee, next);
+                else
+                    indirectSpecularSample(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame,
+                                           MISS_ENV, nee, next);
+            }
+        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -683,7 +714,7 @@ struct Shader {
     }
 
     // ---- physicallyBased.rlsl:55-331 ----
-    void physicallyBased(const Ray &inRay, const Hit &h, const hr_material &M, Ray &nee, Ray &next)
+    void physicallyBased(const Ray &inRay, const Hit &h, const hr_material &M, Ray &nee, Ray &next, Ray &nee2)
     {
         Ray in = inRay;
         const TriAttr &attr = ctx.attrs[h.prim];
@@ -792,13 +823,13 @@ struct Shader {
             vec2 rand = getSequenceValue(in.sequenceID + in.depth, si);
             vec2 probability = getSequenceValue(in.sequenceID + in.depth + 1, si);
             if (probability.x <= diffuseProbability) {
-                directDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next);
+                directDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
                 directSpecularSample(in, sf.P, h.prim, clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next);
+                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
                 directSpecularSample(in, sf.P, h.prim, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
-                                     probability.y, rand, frame, nee, next);
+                                     probability.y, rand, frame, nee, next, nee2);
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330
@@ -1080,7 +1111,7 @@ struct Shader {
                 if (ray.missKind == MISS_ENV) environmentLight(ray.d, ray.weight);
                 break;
             }
-            Ray nee, next;
+            Ray nee, next, nee2;
             setFootprint(ray, h);
             const int mid = ctx.attrs[h.prim].material;
             if (mid >= 0 && mid < (int)ctx.materials.size()) {
@@ -1090,22 +1121,30 @@ struct Shader {
                     glass(ray, h, M, nee, next);
                 } else if (M.type == HR_MAT_PBR) {
                     st.shaded_hits++;
-                    physicallyBased(ray, h, M, nee, next);
+                    physicallyBased(ray, h, M, nee, next, nee2);
                 }
             }
             if (nee.valid) {
                 st.rays_any++;
                 if (!traceOccluded(ctx, nee.o, nee.d, ctx.rayEps, nee.maxT, nee.srcPrim, &tcAny, ctx.brute)) lightShader(nee, nee.maxT);
             }
+            if (nee2.valid) { // HR_ESTIMATOR_ALL_LIGHTS: the analytic-light ray; its light shader adds to the second partial sum
+                st.rays_any++;
+                toB = true;
+                if (!traceOccluded(ctx, nee2.o, nee2.d, ctx.rayEps, nee2.maxT, nee2.srcPrim, &tcAny, ctx.brute)) lightShader(nee2, nee2.maxT);
+                toB = false;
+            }
             ray = next;
         }
+        if (pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) // the two partial sums meet, then the sample joins the frame
+            for (int k = 0; k < 3; ++k) px[k] = px[k] + pxB[k];
         for (int k = 0; k < 4; ++k) fbPixel[k] = fbPixel[k] + px[k];
     }
 };
 
 void renderPass(Context &ctx, const hr_pass_params &pp, int nThreads)
 {
-    if (pp.estimator == HR_ESTIMATOR_ENV_MIS) buildEnvTable(ctx);
+    if (pp.estimator == HR_ESTIMATOR_ENV_MIS || pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) buildEnvTable(ctx);
     if (pp.texture_lod == HR_TEXTURE_LOD_CONE) buildTextureLod(ctx);
     const int W = ctx.W, H = ctx.H, tile = ctx.tile > 0 ? ctx.tile : 32;
     const int tilesX = (W + tile - 1) / tile;

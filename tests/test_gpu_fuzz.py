@@ -116,7 +116,7 @@ def random_scene(seed):
     o.sample_mode = int(rng.choice([ffi.HR_SAMPLE_SOBOL, ffi.HR_SAMPLE_HALTON, ffi.HR_SAMPLE_HAMMERSLEY]))
     o.max_channel_value = float(F(rng.choice([math.pi, 1.0, 50.0])))
     # the importance-sampled environment + MIS estimator (include/hrcore.h) on a part of the scenes (a no-op without a map)
-    o.estimator = ffi.HR_ESTIMATOR_ENV_MIS if rng.random() < 0.4 else ffi.HR_ESTIMATOR_REFERENCE
+    o.estimator = int(rng.choice([ffi.HR_ESTIMATOR_REFERENCE, ffi.HR_ESTIMATOR_ENV_MIS, ffi.HR_ESTIMATOR_ALL_LIGHTS], p=[0.5, 0.25, 0.25]))
     # mip chain + ray-cone texture lookups (include/hrcore.h) on a third of the scenes
     o.texture_lod = ffi.HR_TEXTURE_LOD_CONE if rng.random() < 0.35 else ffi.HR_TEXTURE_LOD_BASE
     return sc

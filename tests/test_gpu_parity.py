@@ -394,6 +394,37 @@ def test_env_mis_estimator_bit_exact(golden, u8_env):
     assert_parity(g2, o2, "env MIS estimator, soup with HDRI")
 
 
+def test_all_lights_estimator_bit_exact(golden):
+    # HR_ESTIMATOR_ALL_LIGHTS (include/hrcore.h): two occlusion rays per vertex, the pass sample kept as two partial sums that meet in
+    # the resolve — bit-exact against the oracle's restatement; pass slots are re-allocated when the mode is first used on a live engine
+    sc = scenes.multi_material(96, 54, bounces=5, passes=16, textured=True)
+    sc.env_pixels = scenes.synthetic_hdri(256, 128)
+    sc.lights.add_point((0.5, 2.0, 1.0), luminous_intensity=683.0 * 2.0)
+    sc.lights.add_spot((-1.0, 3.0, 0.5), luminous_intensity=683.0 * 40.0)
+    g0, o0, ge, oe = render_both(sc, 3, lut=golden["multiscatter_lut"])          # reference estimator first: slots exist at the old size
+    assert_parity(g0, o0, "reference estimator before the switch")
+    sc.options.estimator = ffi.HR_ESTIMATOR_ALL_LIGHTS
+    for eng in (ge, oe):
+        eng.clear()
+        for s_ in range(6):
+            eng.render_pass(sc.options.pass_params(s_))
+    g, o = ge.readback(), oe.readback()
+    assert_parity(g, o, "all-lights estimator, multi-material")
+    assert ge.stats().rays_any == oe.stats().rays_any
+    assert g.tobytes() != g0.tobytes()
+    sc.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS                              # and back, passes of both kinds in one pipeline
+    for eng in (ge, oe):
+        for s_ in range(6, 9):
+            eng.render_pass(sc.options.pass_params(s_))
+    assert_parity(ge.readback(), oe.readback(), "MIS passes on top of all-lights passes")
+    soup = scenes.triangle_soup(20000, width=64, height=36, bounces=6, passes=16, env=True)
+    soup.options.estimator = ffi.HR_ESTIMATOR_ALL_LIGHTS
+    soup.options.texture_lod = ffi.HR_TEXTURE_LOD_CONE
+    g2, o2, e2, oe2 = render_both(soup, 5, lut=golden["multiscatter_lut"])
+    assert_parity(g2, o2, "all-lights estimator + cone LOD, soup with HDRI")
+    assert e2.stats().rays_any == oe2.stats().rays_any
+
+
 def test_texture_lod_cone_bit_exact(golden):
     # HR_TEXTURE_LOD_CONE (include/hrcore.h): mip chains and per-triangle texel densities are built on the device, the ray cone rides
     # in the ray record, the trilinear lookup follows the oracle's arithmetic — bit-exact HDR buffers, f32 and u8 textures

@@ -849,3 +849,59 @@ def test_cone_lod_leaves_the_expectation_of_a_smooth_texture_alone_and_widens_af
     out = f3()
     lod_lib().ora_kat_footprint(eng._ctx, 0, f3(0, -1, 0), 0.2, 0.25 + 0.02, 2.0, 0.3, 0.3, out)
     assert abs(out[1] - (0.2 + 0.27 * 2.0)) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ all-lights estimator
+# HR_ESTIMATOR_ALL_LIGHTS (include/hrcore.h): every PBR vertex samples the environment (MIS) AND one analytic light, instead of ONE
+# light picked at random.  Same expectation as the reference estimator, without the light-pick variance.
+def sun_and_sky_plane(estimator, passes, size=8, roughness=1.0, metallic=0.0, depth=1):
+    sc = mis_plane(estimator, np.full((16, 32, 3), 0.4, dtype=F), roughness, metallic, passes, size=size)
+    sc.lights.add_directional(color=(1.0, 0.95, 0.9), illuminance=683.0 * 1.5, phi=0.3, theta=1.1)
+    sc.lights.add_point((1.0, 2.0, -0.5), luminous_intensity=683.0 * 0.8)
+    sc.options.max_ray_depth = depth
+    return sc
+
+
+@pytest.mark.parametrize("roughness,metallic", [(1.0, 0.0), (0.5, 1.0)])
+def test_all_lights_estimator_is_unbiased_and_removes_the_light_pick_noise(roughness, metallic):
+    n = 4096
+    ref, _ = render(sun_and_sky_plane(ffi.HR_ESTIMATOR_REFERENCE, n, roughness=roughness, metallic=metallic), n)
+    mis, _ = render(sun_and_sky_plane(ffi.HR_ESTIMATOR_ENV_MIS, n, roughness=roughness, metallic=metallic), n)
+    both, eng = render(sun_and_sky_plane(ffi.HR_ESTIMATOR_ALL_LIGHTS, n, roughness=roughness, metallic=metallic), n)
+    m = lambda img: float((img[..., :3] / img[..., 3:4]).mean())
+    assert abs(m(both) - m(ref)) < 0.02 * m(ref), (m(both), m(ref))            # the same integral ...
+    assert abs(m(both) - m(mis)) < 0.02 * m(mis)
+    st = eng.stats()
+    assert st.rays_any > 1.5 * st.paths                                          # ... with two occlusion rays at (nearly) every vertex
+    # short renders, several pixels: the pixel-to-pixel spread is the estimator's noise (the plane is uniformly lit)
+    k = 16
+    spread = {}
+    for est in (ffi.HR_ESTIMATOR_REFERENCE, ffi.HR_ESTIMATOR_ENV_MIS, ffi.HR_ESTIMATOR_ALL_LIGHTS):
+        img, _ = render(sun_and_sky_plane(est, k, size=16, roughness=roughness, metallic=metallic), k)
+        v = (img[..., :3] / img[..., 3:4]).mean(axis=-1)
+        spread[est] = float(v.std() / v.mean())
+    assert spread[ffi.HR_ESTIMATOR_ALL_LIGHTS] < 0.5 * spread[ffi.HR_ESTIMATOR_ENV_MIS], spread
+    assert spread[ffi.HR_ESTIMATOR_ALL_LIGHTS] < 0.75 * spread[ffi.HR_ESTIMATOR_REFERENCE], spread
+
+
+def test_all_lights_estimator_degenerate_rigs():
+    # no analytic light: exactly the ENV_MIS estimator; no environment: one analytic ray per vertex, every vertex
+    env = np.full((8, 16, 3), 0.7, dtype=F)
+    a = mis_plane(ffi.HR_ESTIMATOR_ENV_MIS, env, 1.0, 0.0, 8)
+    b = mis_plane(ffi.HR_ESTIMATOR_ALL_LIGHTS, env, 1.0, 0.0, 8)
+    assert render(a, 8)[0].tobytes() == render(b, 8)[0].tobytes()
+    def sun_only(est):
+        sc = scenes.Scene("sun_only", width=8, height=8, use_multiscatter_lut=False)
+        p, n, uv, i = scenes.plane_strip(100, 100)
+        sc.materials[0] = host.bake_pbr(base_color=(0.5, 0.5, 0.5), roughness=1.0, metallic=0.0, specular_f0=0.0)
+        sc.meshes.append(scenes.MeshData(p, n, i, uvs=uv, mode=ffi.HR_TRIANGLE_STRIP, material_id=0))
+        sc.lights.add_directional(color=(1, 1, 1), illuminance=683.0, phi=0.2, theta=0.8)
+        o = sc.options
+        o.max_ray_depth, o.aspect_ratio, o.fstop = 2, 1.0, host.FSTOP_DISABLED
+        o.view_matrix = host.orbit_view_matrix(5.0, 0.0, 0.6)
+        o.estimator = est
+        return sc
+    r, _ = render(sun_only(ffi.HR_ESTIMATOR_REFERENCE), 4)
+    b2, _ = render(sun_only(ffi.HR_ESTIMATOR_ALL_LIGHTS), 4)
+    # one light: the reference picks it with probability 1, so both estimators compute the same radiance (different summation order)
+    assert np.allclose(r[..., :3] / r[..., 3:4], b2[..., :3] / b2[..., 3:4], rtol=2e-6)
