@@ -356,7 +356,7 @@ static void slotBudget(hr_ctx *c)
     c->maxSlots = kMaxSlots;
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
-        const size_t k = c->allLightsUsed ? 2 : 1;
+        const size_t k = c->allLightsUsed ? 4 : 1;
         const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 * k + hitRecordSize()) + fbBytes * k + sizeof(Counters);
         const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
         c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
@@ -1453,13 +1453,13 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
         if (e == hipSuccess) e = hipMalloc(&ps.q[i].C, n16);
         if (e == hipSuccess) e = hipMalloc(&ps.q[i].D, n16);
     }
-    const size_t s16 = n16 * (c->allLightsUsed ? 2 : 1); // up to two occlusion rays per path with HR_ESTIMATOR_ALL_LIGHTS
+    const size_t s16 = n16 * (c->allLightsUsed ? 4 : 1); // up to four occlusion rays per path with HR_ESTIMATOR_ALL_LIGHTS
     if (e == hipSuccess) e = hipMalloc(&ps.sq.A, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.sq.B, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.sq.C, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.hits, cap * hitRecordSize());
     // (with HR_ESTIMATOR_ALL_LIGHTS the sample's second partial sum lies right behind the first: k_trace indexes one buffer)
-    if (e == hipSuccess) e = hipMalloc(&ps.passbuf, fbBytes * (c->allLightsUsed ? 2 : 1));
+    if (e == hipSuccess) e = hipMalloc(&ps.passbuf, fbBytes * (c->allLightsUsed ? 4 : 1));
     if (e == hipSuccess && c->allLightsUsed) ps.passbufB = ps.passbuf + (size_t)c->W * c->H * 4;
     if (e != hipSuccess) { // say what ran out: a pass slot is the unit the pipeline's memory grows in
         size_t freeB = 0, totalB = 0;

@@ -127,7 +127,10 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
     if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
     // the pass's sample starts at zero; perspective.rlsl:60 accumulate(vec4(0,0,0,1)) for sampled pixels
     if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
-    if (inFrame && seg.passbufB) G(reinterpret_cast<float4 *>(seg.passbufB))[pixel] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (inFrame && seg.passbufB) { // HR_ESTIMATOR_ALL_LIGHTS: three more partial sums behind the first
+        const size_t framePixels = (size_t)(seg.passbufB - seg.passbuf) >> 2;
+        for (int j = 1; j <= 3; ++j) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel + j * framePixels] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
     const uint32_t slot = blockReserve(active, seg.qCountIn, scratch);
     if (active) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
     const uint32_t n = waveSum(active ? 1u : 0u);
@@ -144,9 +147,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, PassBufList buf
     float4 a = reinterpret_cast<float4 *>(fr.fb)[pixel];
     for (int k = 0; k < bufs.n; ++k) {
         float4 s = reinterpret_cast<const float4 *>(bufs.buf[k])[pixel];
-        if (bufs.bufB[k]) { // HR_ESTIMATOR_ALL_LIGHTS: the pass's two partial sums meet here, then the sample joins the frame
-            const float4 t = reinterpret_cast<const float4 *>(bufs.bufB[k])[pixel];
-            s.x = s.x + t.x, s.y = s.y + t.y, s.z = s.z + t.z;
+        if (bufs.bufB[k]) { // HR_ESTIMATOR_ALL_LIGHTS: the pass's four partial sums meet here, in order, then the sample joins the frame
+            const size_t framePixels = (size_t)(bufs.bufB[k] - bufs.buf[k]) >> 2;
+            for (int j = 1; j <= 3; ++j) {
+                const float4 t = reinterpret_cast<const float4 *>(bufs.buf[k])[pixel + j * framePixels];
+                s.x = s.x + t.x, s.y = s.y + t.y, s.z = s.z + t.z;
+            }
         }
         a.x = a.x + s.x, a.y = a.y + s.y, a.z = a.z + s.z, a.w = a.w + s.w;
     }
@@ -735,10 +741,12 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
         const bool live = i < total;
         const int sI = live ? findSeg(i) : 0;
         constexpr bool LOD = (MODE & 1) != 0, ALL = (MODE & 2) != 0;
-        Ray nee, next, nee2; // nee2: the analytic-light ray of HR_ESTIMATOR_ALL_LIGHTS (never valid in the kernels compiled without it)
-        nee.valid = next.valid = nee2.valid = false;
+        // extra[]: the additional occlusion rays of HR_ESTIMATOR_ALL_LIGHTS — [0] the analytic light, [1], [2] the second and third
+        // environment sample of a camera ray's hit (never valid in the kernels compiled without the estimator)
+        Ray nee, next, extra[3];
+        nee.valid = next.valid = extra[0].valid = extra[1].valid = extra[2].valid = false;
         uint32_t pixel = 0, prim = 0xFFFFFFFFu;
-        v3 neeValue(0.0f), neeValue2(0.0f);
+        v3 neeValue(0.0f), extraValue[3] = {v3(0.0f), v3(0.0f), v3(0.0f)};
         if (live) {
             const SegDev &sg = tbl->seg[sI];
             const uint32_t li = i - segStart[2 * sI];
@@ -772,11 +780,15 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                         sh.glass(in, sf, h.t, M, nee, next);
                     } else if (M.type == HR_MAT_PBR) {
                         ++nShaded;
-                        sh.physicallyBased(in, sf, M, nee, next, nee2);
+                        sh.physicallyBased(in, sf, M, nee, next, extra[0], extra[1], extra[2]);
                     }
                 }
                 if (nee.valid) nee.valid = sh.lightShaderValue(nee, neeValue);
-                if (ALL && nee2.valid) nee2.valid = sh.lightShaderValue(nee2, neeValue2);
+                if (ALL) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+                        if (extra[j].valid) extra[j].valid = sh.lightShaderValue(extra[j], extraValue[j]);
+                }
             }
             nAccum += sh.nAccum;
         }
@@ -792,15 +804,19 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                 G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
                 G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
             }
-            if (ALL) { // the second occlusion ray: its value goes to the pass's SECOND partial sum, which lies behind the first in the
-                       // same allocation — the trace kernel just sees a pixel index beyond the frame
-                const bool wantS2 = mine && nee2.valid;
-                const uint32_t s2 = blockReserve(wantS2, sg.sCountOut, scratch);
-                if (wantS2) {
-                    G(sg.sq.A)[s2] = make_float4(nee2.o.x, nee2.o.y, nee2.o.z, nee2.maxT);
-                    G(sg.sq.B)[s2] = make_float4(nee2.d.x, nee2.d.y, nee2.d.z, __uint_as_float(prim));
-                    const uint32_t pixelB = pixel + (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
-                    G(sg.sq.C)[s2] = make_float4(neeValue2.x, neeValue2.y, neeValue2.z, __uint_as_float(pixelB));
+            if (ALL) {
+                // each extra ray adds to a partial sum of its own (no two rays of a launch may write one pixel): partial sum j + 1 lies
+                // (j + 1) frames behind the first in the pass's buffer — the trace kernel just sees a pixel index beyond the frame
+                const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const bool wantX = mine && extra[j].valid;
+                    const uint32_t sx = blockReserve(wantX, sg.sCountOut, scratch);
+                    if (wantX) {
+                        G(sg.sq.A)[sx] = make_float4(extra[j].o.x, extra[j].o.y, extra[j].o.z, extra[j].maxT);
+                        G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
+                        G(sg.sq.C)[sx] = make_float4(extraValue[j].x, extraValue[j].y, extraValue[j].z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
+                    }
                 }
             }
             const bool wantQ = mine && next.valid;

@@ -414,6 +414,10 @@ template <int MODE> struct ShaderT {
     // reference; the arithmetic is the oracle's (oracle/oracle_shade.cpp, same operations in the same order).
     HRD bool envMis() const { return pp.estimator != HR_ESTIMATOR_REFERENCE && S.envW > 0; }
     HRD bool allLights() const { return ALL && pp.estimator == HR_ESTIMATOR_ALL_LIGHTS; }
+#ifndef HR_ENV_SPLIT_DEPTH
+#define HR_ENV_SPLIT_DEPTH 0
+#endif
+    static constexpr int kPrimaryEnvSamples = 3; // environment samples HR_ESTIMATOR_ALL_LIGHTS takes at a camera ray's hit
     HRD void envTexelOf(v3 dir, int &i, int &j) const
     {
         float theta = atan2_(dir.x, -dir.z) + S.lights.env_theta_rotation;
@@ -464,18 +468,23 @@ template <int MODE> struct ShaderT {
         sincos_(azimuth, &sa, &ca);
         return v3(ce * sa, se, -(ce * ca));
     }
+    // which: 0 = the vertex's environment sample; 1, 2 = the extra ones HR_ESTIMATOR_ALL_LIGHTS takes at a camera ray's hit (own sequence values)
     HRD void envMisDiffuse(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee,
-                           Ray &next) const
+                           Ray &next, int which = 0) const
     {
-        const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
-        v3 O = (sel.x < 0.5f) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv(rand.x, rand.y);
+        const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        if (which > 0) rand = getSequenceValue(in.sequenceID + in.depth + 4 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        // how often the lobe's own sampler is used instead of the map's: half the time (ENV_MIS), an eighth with ALL_LIGHTS — a
+        // cosine lobe rarely finds a small bright source, and every such sample is one the source does not get
+        const float cLobe = (pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) ? 0.125f : 0.5f, cMap = 1.0f - cLobe;
+        v3 O = (sel.x < cLobe) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv(rand.x, rand.y);
         float NdotO = dot(N, O);
         if (!(NdotO > 0.0f)) return;
         NdotO = saturate(NdotO);
         const float pLobe = NdotO / HR_KPI, pMap = envPdf(O);
         v3 reflectance = (Cdiff / HR_KPI) * NdotO;
         reflectance = reflectance * in.weight;
-        reflectance = reflectance / (0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / (cLobe * pLobe + cMap * pMap);
         reflectance = reflectance / sampleProbability;
         reflectance = reflectance / envProbability;
         if (dot(reflectance, reflectance) > 0.0f) {
@@ -489,9 +498,10 @@ template <int MODE> struct ShaderT {
         }
     }
     HRD void envMisSpecular(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
-                            float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next) const
+                            float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next, int which = 0) const
     {
-        const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        if (which > 0) rand = getSequenceValue(in.sequenceID + in.depth + 4 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
         v3 O, H;
         if (sel.x < 0.5f) {
             H = mul(frame, sampleVisibleGGX(mulT(frame, I), rand.x, rand.y, roughnessAlpha));
@@ -526,7 +536,7 @@ template <int MODE> struct ShaderT {
     }
 
     HRD void directDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float lightProbability, v2 rand, const m3 &frame,
-                                 Ray &nee, Ray &next, Ray &nee2) const // :52-98
+                                 Ray &nee, Ray &next, Ray &nee2, Ray &nee3, Ray &nee4) const // :52-98
     {
         const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
         LightSample ls = computeLightSample(N, lightProbability, P, both);
@@ -556,10 +566,19 @@ template <int MODE> struct ShaderT {
         }
         if (both) {
             if (S.lights.env_enabled) {
-                if (envMis())
-                    envMisDiffuse(in, P, N, Cdiff, sampleProbability, 1.0f, rand, frame, nee, next);
-                else
+                if (envMis()) {
+                    // a camera ray's hit takes three environment samples (-> nee, nee3, nee4), a third of the value each: that is where
+                    // the image's noise comes from (c3: 1341 passes to converge with direct lighting alone, 1381 with eight bounces)
+                    const bool split = in.depth <= HR_ENV_SPLIT_DEPTH;
+                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
+                    envMisDiffuse(in, P, N, Cdiff, sampleProbability, nEnv, rand, frame, nee, next);
+                    if (split) {
+                        envMisDiffuse(in, P, N, Cdiff, sampleProbability, nEnv, rand, frame, nee3, next, 1);
+                        envMisDiffuse(in, P, N, Cdiff, sampleProbability, nEnv, rand, frame, nee4, next, 2);
+                    }
+                } else {
                     indirectDiffuseSample(in, P, N, Cdiff, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee, next);
+                }
             }
         } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
@@ -603,7 +622,8 @@ template <int MODE> struct ShaderT {
         }
     }
     HRD void directSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
-                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next, Ray &nee2) const // :153-220
+                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next, Ray &nee2, Ray &nee3,
+                                  Ray &nee4) const // :153-220
     {
         const bool both = allLights();
         LightSample ls = computeLightSample(N, lightProbability, P, both);
@@ -640,11 +660,18 @@ template <int MODE> struct ShaderT {
         }
         if (both) {
             if (S.lights.env_enabled) {
-                if (envMis())
-                    envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame, nee, next);
-                else
+                if (envMis()) {
+                    const bool split = in.depth <= HR_ENV_SPLIT_DEPTH;
+                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
+                    envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee, next);
+                    if (split) {
+                        envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee3, next, 1);
+                        envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee4, next, 2);
+                    }
+                } else {
                     indirectSpecularSample(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee,
                                            next);
+                }
             }
         } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
@@ -690,7 +717,7 @@ template <int MODE> struct ShaderT {
     }
 
     // ---- physicallyBased.rlsl:55-331 ----
-    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, Ray &nee2)
+    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, Ray &nee2, Ray &nee3, Ray &nee4)
     {
         Ray in = inRay;
         const uint32_t F = M.flags;
@@ -802,13 +829,13 @@ template <int MODE> struct ShaderT {
             v2 rand = getSequenceValue(in.sequenceID + in.depth, si);
             v2 probability = getSequenceValue(in.sequenceID + in.depth + 1, si);
             if (probability.x <= diffuseProbability) {
-                directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2);
+                directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
                 directSpecularSample(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2);
+                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
                 directSpecularSample(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability, probability.y,
-                                     rand, frame, nee, next, nee2);
+                                     rand, frame, nee, next, nee2, nee3, nee4);
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330

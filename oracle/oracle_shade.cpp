@@ -59,8 +59,9 @@ struct Shader {
     hr_pass_stats &st;
     TraceCounters tc, tcAny;
     float lodBase = -1e30f; // HR_TEXTURE_LOD_CONE: level offset of the current hit's footprint
-    float pxB[3] = {0.0f, 0.0f, 0.0f}; // HR_ESTIMATOR_ALL_LIGHTS: second partial sum of the pass's sample (analytic-light NEE)
-    bool toB = false;
+    // HR_ESTIMATOR_ALL_LIGHTS: partial sums 1..3 of the pass's sample (analytic-light ray; 2nd, 3rd environment sample of the primary hit)
+    float pxX[3][3] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+    int part = 0;
 
     Shader(Context &c, const hr_pass_params &p, float *pixel, hr_pass_stats &s) : ctx(c), pp(p), fbPixel(pixel), st(s)
     {
@@ -78,7 +79,7 @@ struct Shader {
     // ---- accumulator.rlsl:12-28 ----
     void accumulate3(vec3 c)
     {
-        float *t = toB ? pxB : px; // HR_ESTIMATOR_ALL_LIGHTS keeps the analytic-light contributions in a second partial sum
+        float *t = part ? pxX[part - 1] : px; // HR_ESTIMATOR_ALL_LIGHTS: every extra occlusion ray adds to a partial sum of its own
         t[0] = t[0] + c.x;
         t[1] = t[1] + c.y;
         t[2] = t[2] + c.z;
@@ -381,6 +382,7 @@ struct Shader {
     // HIP kernels reproduce bit for bit, with its own known-answer tests (tests/test_oracle_kat.py).
     bool envMis() const { return pp.estimator != HR_ESTIMATOR_REFERENCE && ctx.env.w > 0; }
     bool allLights() const { return pp.estimator == HR_ESTIMATOR_ALL_LIGHTS; }
+    static constexpr int kPrimaryEnvSamples = 3; // environment samples HR_ESTIMATOR_ALL_LIGHTS takes at a camera ray's hit
     // the texel a direction falls into, with environmentLight.rlsl:19-34's mapping (u to the right, t upwards)
     void envTexelOf(vec3 dir, int &i, int &j) const
     {
@@ -436,17 +438,22 @@ struct Shader {
     // The next-event ray towards the environment of a diffuse lobe: drawn from the lobe (cosine) or from the map, half the time
     // each; weight f cos / (p_lobe / 2 + p_map / 2) — the balance heuristic of the one-sample model.
     void envMisDiffuse(const Ray &in, vec3 P, int prim, vec3 N, vec3 Cdiff, float sampleProbability, float envProbability, vec2 rand,
-                       const mat3 &frame, Ray &nee, Ray &next)
+                       const mat3 &frame, Ray &nee, Ray &next, int which = 0)
     {
-        const vec2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
-        vec3 O = (sel.x < 0.5f) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv(rand.x, rand.y);
+        // which: 0 = the vertex's environment sample; 1, 2 = the extra ones HR_ESTIMATOR_ALL_LIGHTS takes at a camera ray's hit
+        const vec2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        if (which > 0) rand = getSequenceValue(in.sequenceID + in.depth + 4 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        // how often the lobe's own sampler is used instead of the map's: half the time (ENV_MIS), an eighth with ALL_LIGHTS — a
+        // cosine lobe rarely finds a small bright source, and every such sample is one the source does not get
+        const float cLobe = (pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) ? 0.125f : 0.5f, cMap = 1.0f - cLobe;
+        vec3 O = (sel.x < cLobe) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv(rand.x, rand.y);
         float NdotO = dot(N, O);
         if (!(NdotO > 0.0f)) return;
         NdotO = saturate(NdotO);
         const float pLobe = NdotO / kPI, pMap = envPdf(O);
         vec3 reflectance = (Cdiff / kPI) * NdotO;
         reflectance = reflectance * in.weight;
-        reflectance = reflectance / (0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / (cLobe * pLobe + cMap * pMap);
         reflectance = reflectance / sampleProbability;
         reflectance = reflectance / envProbability;
         // (no 1e-5 cut-off on the weight here: an importance-sampled ray towards a bright texel carries a small weight and a large radiance)
@@ -461,9 +468,10 @@ struct Shader {
         }
     }
     void envMisSpecular(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut, float roughness,
-                        float sampleProbability, float envProbability, vec2 rand, const mat3 &frame, Ray &nee, Ray &next)
+                        float sampleProbability, float envProbability, vec2 rand, const mat3 &frame, Ray &nee, Ray &next, int which = 0)
     {
-        const vec2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        const vec2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        if (which > 0) rand = getSequenceValue(in.sequenceID + in.depth + 4 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
         vec3 O, H;
         if (sel.x < 0.5f) { // the lobe's own sampler (microfacet.rlsl:100-151)
             H = mul(frame, sampleVisibleGGX(mulT(frame, I), rand.x, rand.y, roughnessAlpha));
@@ -531,7 +539,7 @@ struct Shader {
         }
     }
     void directDiffuseSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 Cdiff, float sampleProbability, float lightProbability, vec2 rand,
-                             const mat3 &frame, Ray &nee, Ray &next, Ray &nee2) // :52-98
+                             const mat3 &frame, Ray &nee, Ray &next, Ray &nee2, Ray &nee3, Ray &nee4) // :52-98
     {
         const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
         LightSample ls = computeLightSample(N, lightProbability, P, both);
@@ -561,10 +569,18 @@ struct Shader {
         }
         if (both) {
             if (ctx.lights.env_enabled) {
-                if (envMis())
-                    envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, 1.0f, rand, frame, nee, next);
-                else
+                if (envMis()) {
+                    // a camera ray's hit takes three environment samples (-> nee, nee3, nee4), a third of the value each
+                    const bool split = in.depth == 0;
+                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
+                    envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, nEnv, rand, frame, nee, next);
+                    if (split) {
+                        envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, nEnv, rand, frame, nee3, next, 1);
+                        envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, nEnv, rand, frame, nee4, next, 2);
+                    }
+                } else {
                     indirectDiffuseSample(in, P, prim, N, Cdiff, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee, next);
+                }
             }
         } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
@@ -609,7 +625,7 @@ struct Shader {
     }
     void directSpecularSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut,
                               float roughness, float sampleProbability, float lightProbability, vec2 rand, const mat3 &frame, Ray &nee,
-                              Ray &next, Ray &nee2) // :153-220
+                              Ray &next, Ray &nee2, Ray &nee3, Ray &nee4) // :153-220
     {
         const bool both = allLights();
         LightSample ls = computeLightSample(N, lightProbability, P, both);
@@ -646,11 +662,18 @@ struct Shader {
         }
         if (both) {
             if (ctx.lights.env_enabled) {
-                if (envMis())
-                    envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame, nee, next);
-                else
+                if (envMis()) {
+                    const bool split = in.depth == 0;
+                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
+                    envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee, next);
+                    if (split) {
+                        envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee3, next, 1);
+                        envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee4, next, 2);
+                    }
+                } else {
                     indirectSpecularSample(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame,
                                            MISS_ENV, nee, next);
+                }
             }
         } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
@@ -714,7 +737,7 @@ struct Shader {
     }
 
     // ---- physicallyBased.rlsl:55-331 ----
-    void physicallyBased(const Ray &inRay, const Hit &h, const hr_material &M, Ray &nee, Ray &next, Ray &nee2)
+    void physicallyBased(const Ray &inRay, const Hit &h, const hr_material &M, Ray &nee, Ray &next, Ray &nee2, Ray &nee3, Ray &nee4)
     {
         Ray in = inRay;
         const TriAttr &attr = ctx.attrs[h.prim];
@@ -823,13 +846,13 @@ struct Shader {
             vec2 rand = getSequenceValue(in.sequenceID + in.depth, si);
             vec2 probability = getSequenceValue(in.sequenceID + in.depth + 1, si);
             if (probability.x <= diffuseProbability) {
-                directDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2);
+                directDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
                 directSpecularSample(in, sf.P, h.prim, clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2);
+                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
                 directSpecularSample(in, sf.P, h.prim, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
-                                     probability.y, rand, frame, nee, next, nee2);
+                                     probability.y, rand, frame, nee, next, nee2, nee3, nee4);
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330
@@ -1111,7 +1134,7 @@ struct Shader {
                 if (ray.missKind == MISS_ENV) environmentLight(ray.d, ray.weight);
                 break;
             }
-            Ray nee, next, nee2;
+            Ray nee, next, extra[3];
             setFootprint(ray, h);
             const int mid = ctx.attrs[h.prim].material;
             if (mid >= 0 && mid < (int)ctx.materials.size()) {
@@ -1121,23 +1144,26 @@ struct Shader {
                     glass(ray, h, M, nee, next);
                 } else if (M.type == HR_MAT_PBR) {
                     st.shaded_hits++;
-                    physicallyBased(ray, h, M, nee, next, nee2);
+                    physicallyBased(ray, h, M, nee, next, extra[0], extra[1], extra[2]);
                 }
             }
             if (nee.valid) {
                 st.rays_any++;
                 if (!traceOccluded(ctx, nee.o, nee.d, ctx.rayEps, nee.maxT, nee.srcPrim, &tcAny, ctx.brute)) lightShader(nee, nee.maxT);
             }
-            if (nee2.valid) { // HR_ESTIMATOR_ALL_LIGHTS: the analytic-light ray; its light shader adds to the second partial sum
+            for (int j = 0; j < 3; ++j) { // HR_ESTIMATOR_ALL_LIGHTS: the analytic-light ray and the extra environment samples
+                const Ray &x = extra[j];
+                if (!x.valid) continue;
                 st.rays_any++;
-                toB = true;
-                if (!traceOccluded(ctx, nee2.o, nee2.d, ctx.rayEps, nee2.maxT, nee2.srcPrim, &tcAny, ctx.brute)) lightShader(nee2, nee2.maxT);
-                toB = false;
+                part = j + 1;
+                if (!traceOccluded(ctx, x.o, x.d, ctx.rayEps, x.maxT, x.srcPrim, &tcAny, ctx.brute)) lightShader(x, x.maxT);
+                part = 0;
             }
             ray = next;
         }
-        if (pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) // the two partial sums meet, then the sample joins the frame
-            for (int k = 0; k < 3; ++k) px[k] = px[k] + pxB[k];
+        if (pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) // the partial sums meet, in order, then the sample joins the frame
+            for (int j = 0; j < 3; ++j)
+                for (int k = 0; k < 3; ++k) px[k] = px[k] + pxX[j][k];
         for (int k = 0; k < 4; ++k) fbPixel[k] = fbPixel[k] + px[k];
     }
 };
