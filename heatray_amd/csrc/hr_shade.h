@@ -414,9 +414,6 @@ template <int MODE> struct ShaderT {
     // reference; the arithmetic is the oracle's (oracle/oracle_shade.cpp, same operations in the same order).
     HRD bool envMis() const { return pp.estimator != HR_ESTIMATOR_REFERENCE && S.envW > 0; }
     HRD bool allLights() const { return ALL && pp.estimator == HR_ESTIMATOR_ALL_LIGHTS; }
-#ifndef HR_ENV_SPLIT_DEPTH
-#define HR_ENV_SPLIT_DEPTH 0
-#endif
     static constexpr int kPrimaryEnvSamples = 3; // environment samples HR_ESTIMATOR_ALL_LIGHTS takes at a camera ray's hit
     HRD void envTexelOf(v3 dir, int &i, int &j) const
     {
@@ -536,10 +533,9 @@ template <int MODE> struct ShaderT {
     }
 
     HRD void directDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float lightProbability, v2 rand, const m3 &frame,
-                                 Ray &nee, Ray &next, Ray &nee2, Ray &nee3, Ray &nee4) const // :52-98
+                                 Ray &nee, Ray &next) const // :52-98
     {
-        const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
-        LightSample ls = computeLightSample(N, lightProbability, P, both);
+        LightSample ls = computeLightSample(N, lightProbability, P);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -557,30 +553,9 @@ template <int MODE> struct ShaderT {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    if (both)
-                        nee2 = r;
-                    else
-                        emit(r, nee, next);
+                    emit(r, nee, next);
                 }
             }
-        }
-        if (both) {
-            if (S.lights.env_enabled) {
-                if (envMis()) {
-                    // a camera ray's hit takes three environment samples (-> nee, nee3, nee4), a third of the value each: that is where
-                    // the image's noise comes from (c3: 1341 passes to converge with direct lighting alone, 1381 with eight bounces)
-                    const bool split = in.depth <= HR_ENV_SPLIT_DEPTH;
-                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
-                    envMisDiffuse(in, P, N, Cdiff, sampleProbability, nEnv, rand, frame, nee, next);
-                    if (split) {
-                        envMisDiffuse(in, P, N, Cdiff, sampleProbability, nEnv, rand, frame, nee3, next, 1);
-                        envMisDiffuse(in, P, N, Cdiff, sampleProbability, nEnv, rand, frame, nee4, next, 2);
-                    }
-                } else {
-                    indirectDiffuseSample(in, P, N, Cdiff, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee, next);
-                }
-            }
-        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisDiffuse(in, P, N, Cdiff, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -621,24 +596,28 @@ template <int MODE> struct ShaderT {
             }
         }
     }
-    HRD void directSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
-                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next, Ray &nee2, Ray &nee3,
-                                  Ray &nee4) const // :153-220
+    // the single-scatter GGX lobe x cos towards O, with the multiscatter factor: (D F G2) / (4 N.I) x ms (microfacet.rlsl:153-220)
+    HRD v3 specularTowards(v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness, v3 O, float NdotO) const
     {
-        const bool both = allLights();
-        LightSample ls = computeLightSample(N, lightProbability, P, both);
+        v3 H = normalize(I + O);
+        float NdotH = saturate(dot(N, H));
+        float IdotH = saturate(dot(I, H));
+        float D = D_GGX(NdotH, roughnessAlpha);
+        v3 F = F_Schlick(Cspec, IdotH);
+        float G = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha);
+        v3 specular = (D * F * G) / greaterThanZero(4.0f * NdotI);
+        specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+        return specular;
+    }
+    HRD void directSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
+                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next) const // :153-220
+    {
+        LightSample ls = computeLightSample(N, lightProbability, P);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
                 NdotO = saturate(NdotO);
-                v3 H = normalize(I + ls.dir);
-                float NdotH = saturate(dot(N, H));
-                float IdotH = saturate(dot(I, H));
-                float D = D_GGX(NdotH, roughnessAlpha);
-                v3 F = F_Schlick(Cspec, IdotH);
-                float G = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha);
-                v3 specular = (D * F * G) / greaterThanZero(4.0f * NdotI);
-                specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+                v3 specular = specularTowards(N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, ls.dir, NdotO);
                 v3 reflectance = specular;
                 reflectance = reflectance * in.weight;
                 reflectance = reflectance / sampleProbability;
@@ -651,29 +630,9 @@ template <int MODE> struct ShaderT {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    if (both)
-                        nee2 = r;
-                    else
-                        emit(r, nee, next);
+                    emit(r, nee, next);
                 }
             }
-        }
-        if (both) {
-            if (S.lights.env_enabled) {
-                if (envMis()) {
-                    const bool split = in.depth <= HR_ENV_SPLIT_DEPTH;
-                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
-                    envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee, next);
-                    if (split) {
-                        envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee3, next, 1);
-                        envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee4, next, 2);
-                    }
-                } else {
-                    indirectSpecularSample(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee,
-                                           next);
-                }
-            }
-        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisSpecular(in, P, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -828,14 +787,79 @@ template <int MODE> struct ShaderT {
         { // direct lighting :236-273
             v2 rand = getSequenceValue(in.sequenceID + in.depth, si);
             v2 probability = getSequenceValue(in.sequenceID + in.depth + 1, si);
-            if (probability.x <= diffuseProbability) {
-                directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
+            if (allLights()) {
+                // HR_ESTIMATOR_ALL_LIGHTS.  (1) One analytic light, picked among the analytic lights only, lights the WHOLE BSDF
+                // (diffuse + specular + clearcoat): a light in a single direction needs no choice of lobe, and the choice is noise.
+                LightSample ls = computeLightSample(N, probability.y, sf.P, true);
+                if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (probability.y > 0.0f)) {
+                    v3 f(0.0f);
+                    float NdotO = dot(N, ls.dir);
+                    if (NdotO > 0.0f) {
+                        NdotO = saturate(NdotO);
+                        f = (Cdiff / HR_KPI) * NdotO;
+                        if (specularProbability > 0.0f)
+                            f = f + specularTowards(N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, ls.dir, NdotO);
+                    }
+                    float coatNdotO = dot(clearCoatN, ls.dir);
+                    if (clearCoatProbability > 0.0f && coatNdotO > 0.0f)
+                        f = f + specularTowards(clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
+                                                clearCoatRoughness, ls.dir, saturate(coatNdotO));
+                    v3 reflectance = f * in.weight;
+                    reflectance = reflectance / ls.probability;
+                    if (dot(reflectance, reflectance) > 0.0f) {
+                        Ray r = createRay(in, sf.P);
+                        r.d = ls.dir;
+                        r.weight = reflectance;
+                        r.occlusionTest = true;
+                        r.missKind = ls.missKind, r.missIdx = ls.missIdx;
+                        r.extraT = 0.0f;
+                        if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
+                        nee2 = r;
+                    }
+                }
+                // (2) The environment, always: one MIS-weighted sample per vertex, three at a camera ray's hit (that is where the
+                // image's noise comes from: c3 needs 1341 passes with direct lighting alone, 1381 with eight bounces), each with its
+                // own choice of lobe (the lobe variable shifted by thirds) and its own sequence values
+                if (S.lights.env_enabled) {
+                    const bool mis = envMis();
+                    const int nSamples = (mis && in.depth == 0) ? kPrimaryEnvSamples : 1;
+                    const float nEnv = (float)nSamples;
+#pragma unroll
+                    for (int j = 0; j < kPrimaryEnvSamples; ++j) {
+                        if (j >= nSamples) break;
+                        Ray &out = (j == 0) ? nee : ((j == 1) ? nee3 : nee4);
+                        float u = probability.x + (float)j * 0.333333343f;
+                        if (u > 1.0f) u = u - 1.0f;
+                        if (u <= diffuseProbability) {
+                            if (mis)
+                                envMisDiffuse(in, sf.P, N, Cdiff, diffuseProbability, nEnv, rand, frame, out, next, j);
+                            else
+                                indirectDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, 1.0f, rand, frame, MISS_ENV, out, next);
+                        } else if (u <= (diffuseProbability + clearCoatProbability)) {
+                            if (mis)
+                                envMisSpecular(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
+                                               clearCoatRoughness, clearCoatProbability, nEnv, rand, frame, out, next, j);
+                            else
+                                indirectSpecularSample(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha,
+                                                       M.multiscatter_lut, clearCoatRoughness, clearCoatProbability, 1.0f, rand, frame, MISS_ENV, out, next);
+                        } else if (u <= (diffuseProbability + clearCoatProbability + specularProbability)) {
+                            if (mis)
+                                envMisSpecular(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability, nEnv, rand,
+                                               frame, out, next, j);
+                            else
+                                indirectSpecularSample(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
+                                                       1.0f, rand, frame, MISS_ENV, out, next);
+                        }
+                    }
+                }
+            } else if (probability.x <= diffuseProbability) {
+                directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
                 directSpecularSample(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
+                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
                 directSpecularSample(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability, probability.y,
-                                     rand, frame, nee, next, nee2, nee3, nee4);
+                                     rand, frame, nee, next);
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330

@@ -315,13 +315,17 @@ typedef struct hr_pass_params {
  * ray budget, light pick, lobe pick, analytic lights, glass — is the reference's. */
 #define HR_ESTIMATOR_REFERENCE 0
 #define HR_ESTIMATOR_ENV_MIS 1
-/* HR_ESTIMATOR_ALL_LIGHTS: HR_ESTIMATOR_ENV_MIS plus what removes the reference's remaining large variance term, the random choice of
- * ONE light per path vertex (lightSampling.rlsl:11-161: a scene lit by a sun and a sky of equal weight sees each at half the
- * vertices, at twice the value).  Every PBR vertex sends the MIS-weighted environment ray (probability 1, not the light pick's)
- * AND one ray to an analytic light picked among the analytic lights only (directional / point / spot; a single such light is
- * always sampled).  The pass's sample is kept as two partial sums — analytic-light contributions, everything else — which are
- * added when the pass resolves, so that no two rays of a launch write the same pixel.  One more occlusion ray per vertex at most;
- * glass keeps the reference's single pick.  Own oracle contract (bit-exact) and known-answer tests, like ENV_MIS. */
+/* HR_ESTIMATOR_ALL_LIGHTS: HR_ESTIMATOR_ENV_MIS without the reference's remaining large variance term, the random choice of ONE
+ * light per path vertex (lightSampling.rlsl:11-161: a scene lit by a sun and a sky of equal weight sees each at half the
+ * vertices, at twice the value).  Every PBR vertex sends
+ *   - one ray to an analytic light picked among the analytic lights only (directional / point / spot; a single such light is
+ *     always sampled), carrying the WHOLE BSDF (diffuse + specular + clearcoat: no choice of lobe for a single direction), and
+ *   - the MIS-weighted environment ray with probability 1 (the map's sampler 7 times out of 8 for the diffuse lobe); the hit of a
+ *     camera ray sends three, a third of the value each, each with its own choice of lobe and its own sequence values.
+ * No two rays of a launch may write the same pixel, so the pass's sample is kept as four partial sums (everything of the
+ * reference path + the first environment ray; the analytic-light ray; the second and third environment ray), added in this
+ * order when the pass resolves.  Up to three more occlusion rays per path; glass keeps the reference's single pick.  Own oracle
+ * contract (bit-exact) and known-answer tests, like ENV_MIS. */
 #define HR_ESTIMATOR_ALL_LIGHTS 2
 
 /* HR_TEXTURE_LOD_BASE: every lookup reads level 0 (bilinear), as in rounds 1-2: OpenRL's level selection inside ray shaders (no

@@ -539,10 +539,9 @@ struct Shader {
         }
     }
     void directDiffuseSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 Cdiff, float sampleProbability, float lightProbability, vec2 rand,
-                             const mat3 &frame, Ray &nee, Ray &next, Ray &nee2, Ray &nee3, Ray &nee4) // :52-98
+                             const mat3 &frame, Ray &nee, Ray &next) // :52-98
     {
-        const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
-        LightSample ls = computeLightSample(N, lightProbability, P, both);
+        LightSample ls = computeLightSample(N, lightProbability, P);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -560,29 +559,9 @@ struct Shader {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    if (both)
-                        nee2 = r;
-                    else
-                        emit(r, nee, next);
+                    emit(r, nee, next);
                 }
             }
-        }
-        if (both) {
-            if (ctx.lights.env_enabled) {
-                if (envMis()) {
-                    // a camera ray's hit takes three environment samples (-> nee, nee3, nee4), a third of the value each
-                    const bool split = in.depth == 0;
-                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
-                    envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, nEnv, rand, frame, nee, next);
-                    if (split) {
-                        envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, nEnv, rand, frame, nee3, next, 1);
-                        envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, nEnv, rand, frame, nee4, next, 2);
-                    }
-                } else {
-                    indirectDiffuseSample(in, P, prim, N, Cdiff, sampleProbability, 1.0f, rand, frame, MISS_ENV, nee, next);
-                }
-            }
-        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisDiffuse(in, P, prim, N, Cdiff, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -623,24 +602,29 @@ struct Shader {
             }
         }
     }
+    // the single-scatter GGX lobe x cos towards O, with the multiscatter factor: (D F G2) / (4 N.I) x ms (microfacet.rlsl:153-220)
+    vec3 specularTowards(vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut, float roughness, vec3 O, float NdotO) const
+    {
+        vec3 H = normalize(I + O);
+        float NdotH = saturate(dot(N, H));
+        float IdotH = saturate(dot(I, H));
+        float D = D_GGX(NdotH, roughnessAlpha);
+        vec3 F = F_Schlick(Cspec, IdotH);
+        float G = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha);
+        vec3 specular = (D * F * G) / greaterThanZero(4.0f * NdotI);
+        specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+        return specular;
+    }
     void directSpecularSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 Cspec, float roughnessAlpha, int lut,
                               float roughness, float sampleProbability, float lightProbability, vec2 rand, const mat3 &frame, Ray &nee,
-                              Ray &next, Ray &nee2, Ray &nee3, Ray &nee4) // :153-220
+                              Ray &next) // :153-220
     {
-        const bool both = allLights();
-        LightSample ls = computeLightSample(N, lightProbability, P, both);
+        LightSample ls = computeLightSample(N, lightProbability, P);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
                 NdotO = saturate(NdotO);
-                vec3 H = normalize(I + ls.dir);
-                float NdotH = saturate(dot(N, H));
-                float IdotH = saturate(dot(I, H));
-                float D = D_GGX(NdotH, roughnessAlpha);
-                vec3 F = F_Schlick(Cspec, IdotH);
-                float G = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha);
-                vec3 specular = (D * F * G) / greaterThanZero(4.0f * NdotI);
-                specular = specular * computeMultiscattering(lut, Cspec, NdotI, roughness);
+                vec3 specular = specularTowards(N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, ls.dir, NdotO);
                 vec3 reflectance = specular;
                 reflectance = reflectance * in.weight;
                 reflectance = reflectance / sampleProbability;
@@ -653,29 +637,9 @@ struct Shader {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    if (both)
-                        nee2 = r;
-                    else
-                        emit(r, nee, next);
+                    emit(r, nee, next);
                 }
             }
-        }
-        if (both) {
-            if (ctx.lights.env_enabled) {
-                if (envMis()) {
-                    const bool split = in.depth == 0;
-                    const float nEnv = split ? (float)kPrimaryEnvSamples : 1.0f;
-                    envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee, next);
-                    if (split) {
-                        envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee3, next, 1);
-                        envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, nEnv, rand, frame, nee4, next, 2);
-                    }
-                } else {
-                    indirectSpecularSample(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, 1.0f, rand, frame,
-                                           MISS_ENV, nee, next);
-                }
-            }
-        } else if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
         } else if (ls.probability > 0.0f) {
             if (envMis())
                 envMisSpecular(in, P, prim, N, I, NdotI, Cspec, roughnessAlpha, lut, roughness, sampleProbability, ls.probability, rand, frame, nee, next);
@@ -845,14 +809,76 @@ struct Shader {
         { // direct lighting :236-273
             vec2 rand = getSequenceValue(in.sequenceID + in.depth, si);
             vec2 probability = getSequenceValue(in.sequenceID + in.depth + 1, si);
-            if (probability.x <= diffuseProbability) {
-                directDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
+            if (allLights()) {
+                // HR_ESTIMATOR_ALL_LIGHTS.  (1) One analytic light, picked among the analytic lights only, lights the WHOLE BSDF
+                // (diffuse + specular + clearcoat): a light in a single direction needs no choice of lobe, and the choice is noise.
+                LightSample ls = computeLightSample(N, probability.y, sf.P, true);
+                if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (probability.y > 0.0f)) {
+                    vec3 f(0.0f);
+                    float NdotO = dot(N, ls.dir);
+                    if (NdotO > 0.0f) {
+                        NdotO = saturate(NdotO);
+                        f = (Cdiff / kPI) * NdotO;
+                        if (specularProbability > 0.0f)
+                            f = f + specularTowards(N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, ls.dir, NdotO);
+                    }
+                    float coatNdotO = dot(clearCoatN, ls.dir);
+                    if (clearCoatProbability > 0.0f && coatNdotO > 0.0f)
+                        f = f + specularTowards(clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
+                                                clearCoatRoughness, ls.dir, saturate(coatNdotO));
+                    vec3 reflectance = f * in.weight;
+                    reflectance = reflectance / ls.probability;
+                    if (dot(reflectance, reflectance) > 0.0f) {
+                        Ray r = createRay(in, sf.P, h.prim);
+                        r.d = ls.dir;
+                        r.weight = reflectance;
+                        r.occlusionTest = true;
+                        r.missKind = ls.missKind, r.missIdx = ls.missIdx;
+                        r.extraT = 0.0f;
+                        if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
+                        nee2 = r;
+                    }
+                }
+                // (2) The environment, always: one MIS-weighted sample per vertex, three at a camera ray's hit, each with its own
+                // choice of lobe (the lobe variable shifted by thirds) and its own sequence values
+                if (ctx.lights.env_enabled) {
+                    const bool mis = envMis();
+                    const int nSamples = (mis && in.depth == 0) ? kPrimaryEnvSamples : 1;
+                    const float nEnv = (float)nSamples;
+                    for (int j = 0; j < nSamples; ++j) {
+                        Ray &out = (j == 0) ? nee : ((j == 1) ? nee3 : nee4);
+                        float u = probability.x + (float)j * 0.333333343f;
+                        if (u > 1.0f) u = u - 1.0f;
+                        if (u <= diffuseProbability) {
+                            if (mis)
+                                envMisDiffuse(in, sf.P, h.prim, N, Cdiff, diffuseProbability, nEnv, rand, frame, out, next, j);
+                            else
+                                indirectDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, 1.0f, rand, frame, MISS_ENV, out, next);
+                        } else if (u <= (diffuseProbability + clearCoatProbability)) {
+                            if (mis)
+                                envMisSpecular(in, sf.P, h.prim, clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha,
+                                               M.multiscatter_lut, clearCoatRoughness, clearCoatProbability, nEnv, rand, frame, out, next, j);
+                            else
+                                indirectSpecularSample(in, sf.P, h.prim, clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha,
+                                                       M.multiscatter_lut, clearCoatRoughness, clearCoatProbability, 1.0f, rand, frame, MISS_ENV, out, next);
+                        } else if (u <= (diffuseProbability + clearCoatProbability + specularProbability)) {
+                            if (mis)
+                                envMisSpecular(in, sf.P, h.prim, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
+                                               nEnv, rand, frame, out, next, j);
+                            else
+                                indirectSpecularSample(in, sf.P, h.prim, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness,
+                                                       specularProbability, 1.0f, rand, frame, MISS_ENV, out, next);
+                        }
+                    }
+                }
+            } else if (probability.x <= diffuseProbability) {
+                directDiffuseSample(in, sf.P, h.prim, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
                 directSpecularSample(in, sf.P, h.prim, clearCoatN, V, clearCoatNdotV, vec3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next, nee2, nee3, nee4);
+                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
                 directSpecularSample(in, sf.P, h.prim, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
-                                     probability.y, rand, frame, nee, next, nee2, nee3, nee4);
+                                     probability.y, rand, frame, nee, next);
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330
