@@ -159,6 +159,7 @@ bool PassGenerator::runInitJob(const RLint renderWidth, const RLint renderHeight
     {
         const char* est = getenv("HEATRAY_ESTIMATOR");
         m_envMis = est && std::string(est) == "env_mis";
+        m_allLights = est && std::string(est) == "all_lights";
         const char* lod = getenv("HEATRAY_TEXTURE_LOD");
         m_textureLodCone = lod && std::string(lod) == "cone";
     }
@@ -288,7 +289,7 @@ void PassGenerator::runRenderFrameJob(const RenderOptions& newOptions, const Pas
         params.enable_accumulator_visualizer = (params.show_nans || params.show_inf) ? 1 : 0;
         // RenderOptions is the reference's struct, unchanged, so the estimator is chosen out of band: HEATRAY_ESTIMATOR=env_mis selects
         // the importance-sampled environment + MIS estimator of include/hrcore.h (default: the reference's estimator)
-        params.estimator = m_envMis ? HR_ESTIMATOR_ENV_MIS : HR_ESTIMATOR_REFERENCE;
+        params.estimator = m_allLights ? HR_ESTIMATOR_ALL_LIGHTS : (m_envMis ? HR_ESTIMATOR_ENV_MIS : HR_ESTIMATOR_REFERENCE);
         params.texture_lod = m_textureLodCone ? HR_TEXTURE_LOD_CONE : HR_TEXTURE_LOD_BASE; // HEATRAY_TEXTURE_LOD=cone: mip chain + ray cones
 
         // Interactive mode walks the 3x3 block; the sample index advances once per full block (:372-384).

@@ -194,6 +194,7 @@ private:
 
     hr_ctx* m_context = nullptr;
     bool m_envMis = false; // HEATRAY_ESTIMATOR=env_mis
+    bool m_allLights = false; // HEATRAY_ESTIMATOR=all_lights
     bool m_textureLodCone = false; // HEATRAY_TEXTURE_LOD=cone
     RLint m_width = 0, m_height = 0;
 
