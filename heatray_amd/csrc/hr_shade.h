@@ -470,11 +470,14 @@ template <int MODE> struct ShaderT {
                            Ray &next, int which = 0) const
     {
         const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        // the map's row variable is stratified over the vertex's samples (sample j of n draws it from the j-th n-th of [0, 1): the
+        // map's bright regions each get their sample), everything else comes from the sample's own sequence values
+        const float envU1 = (rand.x + (float)which) / envProbability;
         if (which > 0) rand = getSequenceValue(in.sequenceID + in.depth + 4 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
         // how often the lobe's own sampler is used instead of the map's: half the time (ENV_MIS), an eighth with ALL_LIGHTS — a
         // cosine lobe rarely finds a small bright source, and every such sample is one the source does not get
         const float cLobe = (pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) ? 0.125f : 0.5f, cMap = 1.0f - cLobe;
-        v3 O = (sel.x < cLobe) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv(rand.x, rand.y);
+        v3 O = (sel.x < cLobe) ? mul(frame, cosineWeightedSample(rand.x, rand.y)) : sampleEnv((pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) ? envU1 : rand.x, rand.y);
         float NdotO = dot(N, O);
         if (!(NdotO > 0.0f)) return;
         NdotO = saturate(NdotO);
@@ -498,13 +501,16 @@ template <int MODE> struct ShaderT {
                             float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next, int which = 0) const
     {
         const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
+        // the map's row variable is stratified over the vertex's samples (sample j of n draws it from the j-th n-th of [0, 1): the
+        // map's bright regions each get their sample), everything else comes from the sample's own sequence values
+        const float envU1 = (rand.x + (float)which) / envProbability;
         if (which > 0) rand = getSequenceValue(in.sequenceID + in.depth + 4 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
         v3 O, H;
         if (sel.x < 0.5f) {
             H = mul(frame, sampleVisibleGGX(mulT(frame, I), rand.x, rand.y, roughnessAlpha));
             O = normalize(2.0f * saturate(dot(I, H)) * H - I);
         } else {
-            O = sampleEnv(rand.x, rand.y);
+            O = sampleEnv((pp.estimator == HR_ESTIMATOR_ALL_LIGHTS) ? envU1 : rand.x, rand.y);
             H = normalize(I + O);
         }
         float NdotO = dot(N, O);

@@ -38,9 +38,7 @@ def no_env(sc):
 
 
 def no_sun(sc):
-    sc.lights.n_directional = 0 if hasattr(sc.lights, "n_directional") else None
-    if hasattr(sc.lights, "directional"):
-        sc.lights.directional.clear()
+    sc.lights.directional.clear()
 
 
 def direct_only(sc):
@@ -56,4 +54,5 @@ variant("full", lambda sc: None)
 variant("no_env", no_env)
 variant("flat_env", flat_env)
 variant("direct_only", direct_only)
+variant("no_sun", no_sun)
 json.dump(out, open(os.path.join(ROOT, "gpurun_out", "converge_variants.json"), "w"), indent=1)
