@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #endif
 #ifdef HR_TAILPROF
     const unsigned long long tStart = wall_clock64();
+    const unsigned long long cStart = clock64(); // shader clock, against the 100 MHz wall clock: the frequency the kernel really ran at
     unsigned long long tExh = 0;
     uint32_t mySteps = 0, maxSteps = 0;
     unsigned long long sumSteps = 0, nRays = 0, nGiven = 0, drainIters = 0, drainLanes = 0;
@@ -630,6 +631,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
         atomicAdd(&g_tailprof[4], sumSteps);
         atomicAdd(&g_tailprof[5], nRays);
         atomicAdd(&g_tailprof[6], nGiven);
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_tailprof[18] = clock64() - cStart, g_tailprof[19] = tEnd - tStart;
         if (lane == 0) {
             atomicMax(&g_tailprof[7], drainIters);
             atomicAdd(&g_tailprof[16], drainLanes);

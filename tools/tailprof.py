@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HRCORE_LIB", os.path.join(ROOT, "build_variants", "libhrcore_tail.so"))
-os.environ.setdefault("HR_TUNE", "groups=1")
+os.environ.setdefault("HR_TUNE", "groups=1,batch=1")  # one trace launch per pass
 import bench  # noqa: E402
 from heatray_amd import core  # noqa: E402
 
@@ -32,4 +32,6 @@ for i in range(12, 20):                  # steady state: one trace launch per pa
         print("launch: %8d rays  total %.3f ms  queue dry after %.3f ms  tail %.3f ms   steps/ray mean %.1f max %d" % (
             v[5], (v[2] - v[0]) / 1e5, (v[1] - v[0]) / 1e5, (v[2] - v[1]) / 1e5, v[4] / v[5], v[3]))
         print("        subtrees handed over %d; waves by drain time (0.05 ms buckets, first 8): %s" % (v[6], " ".join(str(x) for x in v[8:16])))
+        if v[19]:
+            print("        shader clock during the launch: %.0f MHz" % (v[18] / (v[19] / 100.0)))
         print("        drain rounds of a wave: max %d, mean %.1f; lanes busy in a drain round: %.1f of 64" % (v[7], v[17] / 5120.0, v[16] / max(v[17], 1)))
