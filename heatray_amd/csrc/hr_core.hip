@@ -155,6 +155,7 @@ struct hr_ctx {
     int32_t blockNx = 0, blockNy = 0, blockCoords[32] = {0};
     // importance table of the environment map (HR_ESTIMATOR_ENV_MIS), built on the device when a pass first asks for it
     float *dEnvRowCdf = nullptr, *dEnvColCdf = nullptr, *dEnvProb = nullptr;
+    uint16_t *dEnvRowGuide = nullptr, *dEnvColGuide = nullptr;
     int envW = 0, envH = 0, envTex = -2;
     float envMeanLum = 0.0f;
     bool committed = false, sceneDirty = true, hasPassthrough = false;
@@ -485,7 +486,7 @@ int hr_ctx_destroy(hr_ctx *c)
         if (c->stageEv[k]) hipEventDestroy(c->stageEv[k]);
     }
     hipFree(c->dConsts);
-    hipFree(c->dEnvRowCdf), hipFree(c->dEnvColCdf), hipFree(c->dEnvProb);
+    hipFree(c->dEnvRowCdf), hipFree(c->dEnvColCdf), hipFree(c->dEnvProb), hipFree(c->dEnvRowGuide), hipFree(c->dEnvColGuide);
     if (c->hConsts) hipHostFree(c->hConsts);
     if (c->pinnedDisplay) hipHostFree(c->pinnedDisplay);
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
@@ -1325,6 +1326,7 @@ static int uploadScene(hr_ctx *c)
     s.seq = c->dSeq, s.aperture = c->dAperture, s.seqOffsets = c->dSeqOffsets;
     s.nSeq = c->nSeq, s.seqLen = c->seqLen, s.nSeqOffsets = c->nSeqOffsets;
     s.envRowCdf = c->dEnvRowCdf, s.envColCdf = c->dEnvColCdf, s.envProb = c->dEnvProb;
+    s.envRowGuide = c->dEnvRowGuide, s.envColGuide = c->dEnvColGuide;
     s.envW = c->envW, s.envH = c->envH, s.envMeanLum = c->envMeanLum;
     s.blockNx = c->blockNx, s.blockNy = c->blockNy;
     std::memcpy(s.blockCoords, c->blockCoords, sizeof(s.blockCoords));
@@ -1353,9 +1355,11 @@ static int ensureEnvTable(hr_ctx *c)
     }
     const TexDesc &t = c->textures[id].desc;
     if (c->envTex == id && c->envW == t.w && c->envH == t.h) return HR_OK;
+    if (t.w > 65535 || t.h > 65535) FAIL(c, HR_ERR_UNSUPPORTED, "environment map too large for the importance table (65535 texels per side)");
     QUIESCE(c);
-    hipFree(c->dEnvRowCdf), hipFree(c->dEnvColCdf), hipFree(c->dEnvProb);
+    hipFree(c->dEnvRowCdf), hipFree(c->dEnvColCdf), hipFree(c->dEnvProb), hipFree(c->dEnvRowGuide), hipFree(c->dEnvColGuide);
     c->dEnvRowCdf = c->dEnvColCdf = c->dEnvProb = nullptr, c->envW = c->envH = 0, c->envTex = -2;
+    c->dEnvRowGuide = c->dEnvColGuide = nullptr;
     const size_t n = (size_t)t.w * t.h;
     float *lum = nullptr, *dil = nullptr;
     uint32_t *wq = nullptr, *maxBits = nullptr;
@@ -1363,6 +1367,8 @@ static int ensureEnvTable(hr_ctx *c)
     hipError_t e = hipMalloc(&c->dEnvRowCdf, sizeof(float) * ((size_t)t.h + 1));
     if (e == hipSuccess) e = hipMalloc(&c->dEnvColCdf, sizeof(float) * (size_t)t.h * ((size_t)t.w + 1));
     if (e == hipSuccess) e = hipMalloc(&c->dEnvProb, sizeof(float) * n);
+    if (e == hipSuccess) e = hipMalloc(&c->dEnvRowGuide, sizeof(uint16_t) * (kEnvRowGuide + 1));
+    if (e == hipSuccess) e = hipMalloc(&c->dEnvColGuide, sizeof(uint16_t) * (size_t)t.h * (kEnvColGuide + 1));
     if (e == hipSuccess) e = hipMalloc(&lum, sizeof(float) * n);
     if (e == hipSuccess) e = hipMalloc(&dil, sizeof(float) * n);
     if (e == hipSuccess) e = hipMalloc(&wq, sizeof(uint32_t) * n);
@@ -1371,6 +1377,7 @@ static int ensureEnvTable(hr_ctx *c)
     if (e == hipSuccess) {
         float *dMean = reinterpret_cast<float *>(maxBits) + 1;
         launchEnvTable(c->stream, t, lum, dil, wq, rowSum, rowSum + t.h, maxBits, c->dEnvRowCdf, c->dEnvColCdf, c->dEnvProb, dMean);
+        launchEnvGuides(c->stream, c->dEnvRowCdf, c->dEnvColCdf, t.w, t.h, c->dEnvRowGuide, c->dEnvColGuide);
         e = hipMemcpyAsync(&c->envMeanLum, dMean, sizeof(float), hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     }

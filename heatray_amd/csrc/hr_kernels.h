@@ -148,6 +148,7 @@ void launchHashWords(hipStream_t st, const void *words, size_t nWords, unsigned 
 void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts);
 
 // environment importance table (HR_ESTIMATOR_ENV_MIS): scratch and outputs are caller-owned device arrays
+void launchEnvGuides(hipStream_t st, const float *rowCdf, const float *colCdf, int w, int h, uint16_t *rowGuide, uint16_t *colGuide);
 void launchEnvTable(hipStream_t st, const TexDesc &tex, float *lum, float *dil, uint32_t *wq, unsigned long long *rowSum, unsigned long long *total,
                     uint32_t *maxBits, float *rowCdf, float *colCdf, float *prob, float *meanLum);
 

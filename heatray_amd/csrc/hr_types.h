@@ -101,6 +101,8 @@ static const uint32_t kMissPrim = 0x7FFFFFFFu;
 
 enum MissKind { MISS_NONE = 0, MISS_ENV = 1, MISS_DIR = 2, MISS_POINT = 3, MISS_SPOT = 4 };
 
+static const int kEnvRowGuide = 256, kEnvColGuide = 64; // buckets of the guide tables (powers of two: x * K is exact)
+
 // ---- per-scene constant block (device copy) ---------------------------------------------------
 struct SceneDev {
     const Node4 *nodes;
@@ -120,6 +122,7 @@ struct SceneDev {
     int32_t gridExpM7[3];
     // importance table of the environment map (HR_ESTIMATOR_ENV_MIS): P(row < j), P(col < i | row j), P(texel); envW == 0: none
     const float *envRowCdf, *envColCdf, *envProb;
+    const uint16_t *envRowGuide, *envColGuide; // guide tables of the two inverse-CDF searches (hr_build.hip::k_env_guides)
     int32_t envW, envH;
     float envMeanLum; // solid-angle-weighted mean luminosity of the map (light-pick weight of the MIS estimator)
     // interactive-mode block table (hr_interactive_blocks_set); blockNx == 0: the unshuffled list
