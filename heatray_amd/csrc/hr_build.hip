@@ -415,7 +415,7 @@ HRD uint32_t frameExponent(float ext, float cell)
 {
     uint32_t r = 0;
     float s = cell * (1.0f / 128.0f);
-    while (r < 15u && !(ext <= 127.0f * s)) s = s + s, ++r;
+    while (r < 15u && !(ext <= (float)kPlaneMax * s)) s = s + s, ++r;
     return r;
 }
 // Pack a 32-byte node (hr_types.h): frame origin on the scene grid (at or below the node's box), per-axis scale, 7-bit child planes.
@@ -434,20 +434,27 @@ HRD Node4 encodeNode4(const Box6 *cb, const Box6 &nb, int nValid, int nInner, ui
         inv[k] = 1.0f / __uint_as_float((uint32_t)(G->gridExpM7[k] + (int32_t)r[k]) << 23);
     }
     uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
-    for (int c = 0; c < 4; ++c) {
+    constexpr int kPlaneBits = (HR_NODE32 == 2) ? 8 : 7;
+    for (int c = 0; c < kNodeWidth; ++c) {
         for (int k = 0; k < 3; ++k) {
-            uint32_t lo7 = 127u, hi7 = 0u; // no child: an inverted box, never hit
+            uint32_t lo7 = (uint32_t)kPlaneMax, hi7 = 0u; // no child: an inverted box, never hit
             if (c < nValid) {
                 const float fl = floor_((cb[c].lo[k] - org[k]) * inv[k]);
                 const float fh = __builtin_ceilf((cb[c].hi[k] - org[k]) * inv[k]);
-                lo7 = (uint32_t)fmin_(fmax_(fl, 0.0f), 127.0f);
-                hi7 = (uint32_t)fmin_(fmax_(fh, 0.0f), 127.0f);
+                lo7 = (uint32_t)fmin_(fmax_(fl, 0.0f), (float)kPlaneMax);
+                hi7 = (uint32_t)fmin_(fmax_(fh, 0.0f), (float)kPlaneMax);
             }
-            qlo[k] |= lo7 << (7 * c);
-            qhi[k] |= hi7 << (7 * c);
+            qlo[k] |= lo7 << (kPlaneBits * c);
+            qhi[k] |= hi7 << (kPlaneBits * c);
         }
     }
     Node4 nd;
+#if HR_NODE32 == 2
+    nd.p = make_uint4(qlo[0] | ((g[2] & 255u) << 24), qlo[1] | (((g[2] >> 8) & 63u) << 24) | ((uint32_t)(nValid - 1) << 30),
+                      qlo[2] | (r[2] << 24) | ((uint32_t)nInner << 28), qhi[0]);
+    nd.q = make_uint4(qhi[1], qhi[2], g[0] | (g[1] << 14) | (r[0] << 28), (childBase & 0x0FFFFFFFu) | (r[1] << 28));
+    return nd;
+#endif
     nd.p = make_uint4(qlo[0] | ((g[2] & 15u) << 28), qlo[1] | (((g[2] >> 4) & 15u) << 28), qlo[2] | (((g[2] >> 8) & 15u) << 28),
                       qhi[0] | (((g[2] >> 12) & 3u) << 28) | ((uint32_t)(nValid - 1) << 30));
     nd.q = make_uint4(qhi[1] | (r[2] << 28), qhi[2] | ((uint32_t)nInner << 28), g[0] | (g[1] << 14) | (r[0] << 28), (childBase & 0x0FFFFFFFu) | (r[1] << 28));
@@ -501,7 +508,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
     int n = 2;
     cand[0] = knodes[b].left, cand[1] = knodes[b].right;
     cand[2] = cand[3] = 0;
-    for (int round = 0; round < 2; ++round) {
+    for (int round = 0; round < ((HR_NODE32 == 2) ? 1 : 2); ++round) { // (one opening: three children)
         int pick = -1;
         float bestArea = -1.0f;
         for (int c = 0; c < n; ++c) {
@@ -526,8 +533,8 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
     const int nLeaf = nValid - nInner;
     const uint32_t innerBase = nInner ? atomicAdd(counter, (uint32_t)nInner) : 0u;
 #if HR_NODE32
-    if (nLeaf) atomicAdd(leafCounter, (uint32_t)nLeaf);      // (only counted: a node's triangles live at 4 * node + 3 - slot)
-    const uint32_t leafBase = 4u * i + 4u - (uint32_t)nValid; // so that leafBase + (nValid - 1 - c) = 4 i + 3 - c
+    if (nLeaf) atomicAdd(leafCounter, (uint32_t)nLeaf);      // (only counted: a node's triangles live at W * node + W - 1 - slot)
+    const uint32_t leafBase = (uint32_t)kNodeWidth * i + (uint32_t)kNodeWidth - (uint32_t)nValid; // leafBase + (nValid - 1 - c) = W i + W - 1 - c
 #else
     const uint32_t leafBase = nLeaf ? atomicAdd(leafCounter, (uint32_t)nLeaf) : 0u;
 #endif
@@ -584,9 +591,14 @@ __global__ __launch_bounds__(256) void k_refit4(Node4 *__restrict__ nodes, Box6 
         const float pad = consts->pad;
         const Node4 nd = nodes[i];
 #if HR_NODE32
+#if HR_NODE32 == 2
+        const int nInner = (int)((nd.p.z >> 28) & 3u);
+        const int nValid = (int)(nd.p.y >> 30) + 1;
+#else
         const int nInner = (int)((nd.q.y >> 28) & 7u);
-        const uint32_t innerBase = nd.q.w & 0x0FFFFFFFu;
         const int nValid = (int)(nd.p.w >> 30) + 1;
+#endif
+        const uint32_t innerBase = nd.q.w & 0x0FFFFFFFu;
 #else
         const uint32_t meta = __float_as_uint(nd.a.w);
         const int nInner = (int)((meta >> 24) & 7u), nValid = (int)(meta >> 27);
@@ -602,7 +614,7 @@ __global__ __launch_bounds__(256) void k_refit4(Node4 *__restrict__ nodes, Box6 
             } else {
                 v3 bl, bh;
 #if HR_NODE32
-                triBounds(tris[4u * i + 3u - (uint32_t)c], bl, bh);
+                triBounds(tris[(uint32_t)kNodeWidth * i + (uint32_t)(kNodeWidth - 1) - (uint32_t)c], bl, bh);
 #else
                 triBounds(tris[~(leafKey + c)], bl, bh);
 #endif
@@ -712,8 +724,8 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         const uint32_t nMax = (uint32_t)nInternal; // every 4-wide node stands for one binary inner node
 #if HR_NODE32
         // a node's triangles live at 4 * node + 3 - slot: four slots per possible node, unused ones marked by 0xFF bytes (prim id -1)
-        HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * 4ull * (size_t)nMax));
-        HR_CHECK(hipMemsetAsync(finalTris, 0xFF, sizeof(Tri) * 4ull * (size_t)nMax, st));
+        HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)kNodeWidth * (size_t)nMax));
+        HR_CHECK(hipMemsetAsync(finalTris, 0xFF, sizeof(Tri) * (size_t)kNodeWidth * (size_t)nMax, st));
 #else
         HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)n));
 #endif
@@ -753,7 +765,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     out->tris = finalTris ? finalTris : sorted;
     out->triSlots = n;
 #if HR_NODE32
-    if (finalTris) out->triSlots = 4u * (uint32_t)out->nNodes;
+    if (finalTris) out->triSlots = (uint32_t)kNodeWidth * (uint32_t)out->nNodes;
 #endif
     HR_CHECK(hipMalloc(&out->slotOfPrim, 4ull * n));
     hipLaunchKernelGGL(k_slot_of_prim, dim3((out->triSlots + 255) / 256), dim3(256), 0, st, out->tris, out->triSlots, out->slotOfPrim);

@@ -78,6 +78,64 @@ HRD GridK gridOf(const SceneDev &S) { return GridK{S.gridCell[0], S.gridCell[1],
 
 HRD uint32_t q7(uint32_t x, int c) { return (x >> (7 * c)) & 127u; } // -> v_bfe_u32
 
+#if HR_NODE32 == 2
+// One step at the 3-wide node `cur` (32-byte format with 8-bit planes, hr_types.h): two dwordx4 loads, slab test of three child
+// boxes, continue with the nearest child that is hit and push the others farthest first; pop when nothing is hit.
+HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, const GridK &gk, float tmin, float tlim)
+{
+    const Node4 &n = nodes[cur];
+    const uint4 P = n.p, Q = n.q;
+    const uint32_t nInner = (P.z >> 28) & 3u;
+    const int innerBase = (int)(Q.w & 0x0FFFFFFFu), leafKey = ~(3 * cur + 2);
+    const uint32_t gx = Q.z & 0x3FFFu, gy = (Q.z >> 14) & 0x3FFFu;
+    const uint32_t gz = (P.x >> 24) | (((P.y >> 24) & 0x3Fu) << 8);
+    const float bx = __uint_as_float((uint32_t)(gk.expX + (int32_t)(Q.z >> 28)) << 23) * rk.idx;
+    const float by = __uint_as_float((uint32_t)(gk.expY + (int32_t)(Q.w >> 28)) << 23) * rk.idy;
+    const float bz = __uint_as_float((uint32_t)(gk.expZ + (int32_t)((P.z >> 24) & 15u)) << 23) * rk.idz;
+    const float ax = __builtin_fmaf((float)gx * gk.cellX, rk.idx, -rk.oix), ay = __builtin_fmaf((float)gy * gk.cellY, rk.idy, -rk.oiy),
+                az = __builtin_fmaf((float)gz * gk.cellZ, rk.idz, -rk.oiz);
+    const uint32_t nX = rk.idx < 0.0f ? P.w : P.x, fX = rk.idx < 0.0f ? P.x : P.w;
+    const uint32_t nY = rk.idy < 0.0f ? Q.x : P.y, fY = rk.idy < 0.0f ? P.y : Q.x;
+    const uint32_t nZ = rk.idz < 0.0f ? Q.y : P.z, fZ = rk.idz < 0.0f ? P.z : Q.y;
+    uint32_t key[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float tnx = __builtin_fmaf((float)byteOf(nX, c), bx, ax), tfx = __builtin_fmaf((float)byteOf(fX, c), bx, ax);
+        const float tny = __builtin_fmaf((float)byteOf(nY, c), by, ay), tfy = __builtin_fmaf((float)byteOf(fY, c), by, ay);
+        const float tnz = __builtin_fmaf((float)byteOf(nZ, c), bz, az), tfz = __builtin_fmaf((float)byteOf(fZ, c), bz, az);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
+        key[c] = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu; // (a slot without a child: inverted box)
+    }
+    cswap(key[0], key[1]), cswap(key[1], key[2]), cswap(key[0], key[1]);
+    int ref[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int sl = (int)(key[j] & 3u);
+        ref[j] = (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl;
+    }
+    if (sp <= kStackLDS - 2) {
+        stackLane[sp * 64] = ref[2];
+        sp += (key[2] != 0xFFFFFFFFu) ? 1 : 0;
+        stackLane[sp * 64] = ref[1];
+        sp += (key[1] != 0xFFFFFFFFu) ? 1 : 0;
+        const bool any = key[0] != 0xFFFFFFFFu;
+        const bool empty = !any && sp == 0;
+        sp -= (!any && sp > 0) ? 1 : 0;
+        const int popped = stackLane[(sp < kStackLDS - 1 ? sp : kStackLDS - 1) * 64];
+        cur = any ? ref[0] : (empty ? kSentinel : popped);
+    } else {
+#pragma unroll
+        for (int j = 2; j >= 1; --j)
+            if (key[j] != 0xFFFFFFFFu) HR_PUSH(ref[j]);
+        if (key[0] != 0xFFFFFFFFu) {
+            cur = ref[0];
+        } else {
+            HR_POP();
+        }
+    }
+}
+#else
 // One step at the 4-wide node `cur` (32-byte format, hr_types.h): TWO dwordx4 loads, slab test of the four 7-bit child boxes,
 // continue with the nearest child that is hit and push the others farthest first; pop when nothing is hit.
 HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, const GridK &gk, float tmin, float tlim)
@@ -144,6 +202,7 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
         }
     }
 }
+#endif // HR_NODE32 == 2
 
 #else
 // One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that

@@ -25,10 +25,17 @@ namespace hr {
 //   4 bits each, hi.x: 2 bits, above them the number of children - 1), r.z (hi.y) and the number of inner children (hi.z).
 // Children 0 .. nInner-1 are the nodes childBase + j (allocated together); the others are single triangles stored at
 // tris[4 * node + 3 - j]: the reference of child j is `base + j` for both kinds (base = childBase or ~(4 * node + 3)).
+// HR_NODE32 == 2: the same 32-byte record holding a THREE-wide node with 8-bit planes (byte c of a plane dword = child c: the
+// cheap v_cvt_f32_ubyteN decode of the 64-byte node again); the top bytes of the plane dwords carry g.z (lo.x: low 8 bits,
+// lo.y: high 6 bits, above them the number of children - 1) and r.z | nInner << 4 (lo.z); w6, w7 as above.  A node's triangles live
+// at tris[3 * node + 2 - j].  Two loads per visit like the 4-wide 32-byte node, and fewer VALU instructions per visit than the
+// 64-byte node (18 conversions, a 3-key sorting network) — against ~1.25 x the visits of a 4-wide tree.
 struct alignas(32) Node4 {
     uint4 p, q;
 };
 static const int kGridBits = 14;
+static const int kNodeWidth = (HR_NODE32 == 2) ? 3 : 4; // children per node, triangle slots per node
+static const int kPlaneMax = (HR_NODE32 == 2) ? 255 : 127;
 #else
 // 4-wide BVH node, child boxes quantised to 8 bits per plane against the node's own box: one 64-byte,
 // 64-byte-aligned record (never straddles a cache line) of which THREE dwordx4 loads are used.
