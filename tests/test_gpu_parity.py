@@ -544,6 +544,33 @@ def test_tile_shards_equal_full_frame(golden):
     assert (parts[0] + parts[1] + parts[2]).tobytes() == full.tobytes()
 
 
+def test_tile_shards_and_interactive_blocks_with_the_opt_in_modes(golden):
+    # the all-lights estimator keeps four partial sums per pass sample behind each other in full-frame indexing, the cone LOD carries
+    # per-path state: both under tile sharding (shards must add up to the full frame) and under the 3x3 interactive block mode
+    sc = scenes.multi_material(160, 96, bounces=4, textured=True)
+    sc.env_pixels = scenes.synthetic_hdri(128, 64)
+    sc.options.estimator = ffi.HR_ESTIMATOR_ALL_LIGHTS
+    sc.options.texture_lod = ffi.HR_TEXTURE_LOD_CONE
+    full, ofull, _, _ = render_both(sc, 3, lut=golden["multiscatter_lut"])
+    assert_parity(full, ofull, "all-lights + cone LOD, full frame")
+    parts = []
+    for r in range(3):
+        e = core.create_engine(rank=r, world=3, tile_size=32)
+        sc.apply(e, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        for s in range(3):
+            e.render_pass(sc.options.pass_params(s))
+        parts.append(e.readback())
+    assert (sum((p[..., 3] > 0).astype(int) for p in parts) == 1).all()
+    assert (parts[0] + parts[1] + parts[2]).tobytes() == full.tobytes()
+    sc.options.enable_interactive_mode = True
+    g, o = core.create_engine(), oracle_lib.engine()
+    for eng in (g, o):
+        sc.apply(eng, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        for k in range(9):
+            eng.render_pass(sc.options.pass_params(0, current_block_pixel=(k % 3, k // 3)))
+    assert_parity(g.readback(), o.readback(), "all-lights + cone LOD, interactive blocks")
+
+
 def test_reset_resize_and_transform(golden):
     sc = scenes.cornell_box(48, 48, bounces=3)
     g, o = core.create_engine(), oracle_lib.engine()
