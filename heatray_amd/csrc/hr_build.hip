@@ -332,6 +332,9 @@ HRD int deltaKey(const uint32_t *keys, int n, int i, int j)
     return __clz((int)(a ^ b));
 }
 
+#ifndef HR_ROTATE_SWEEPS
+#define HR_ROTATE_SWEEPS 0 // tree-rotation sweeps over the binary tree before the collapse (experiment knob)
+#endif
 struct KNode {
     int left, right; // >= 0: internal node, < 0: leaf ~index
     int first, last; // covered range of sorted triangles
@@ -385,6 +388,60 @@ __global__ __launch_bounds__(256) void k_refit_round(const KNode *__restrict__ n
     }
     nodeBox[i] = u;
     stamp[i] = round;
+}
+
+HRD float boxArea(const Box6 &b);
+// Tree rotations (Kensler 2008) on the binary tree before it is collapsed: node N with children L, R may exchange R with one of
+// L's children (or L with one of R's) when that shrinks the surface area of the rebuilt child — the LBVH splits by Morton prefix,
+// blind to the boxes, and a rotation repairs the worst of it.  One launch handles the nodes of ONE stamp value (the round of the
+// bottom-up refit that finished them: a parent's stamp is larger than its children's), bottom-up, so that no two nodes of a launch
+// are parent and child and the subtrees below are final: no locks.  Hits do not depend on the tree.
+__global__ __launch_bounds__(256) void k_rotate(KNode *__restrict__ nodes, int nInternal, const Box6 *__restrict__ leafBox, Box6 *__restrict__ nodeBox,
+                                                const uint32_t *__restrict__ stamp, uint32_t which, uint32_t *__restrict__ applied)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nInternal || stamp[i] != which) return;
+    const KNode N = nodes[i];
+    auto boxOf = [&](int ref) { return ref < 0 ? leafBox[~ref] : nodeBox[ref]; };
+    auto unite = [](const Box6 &a, const Box6 &b) {
+        Box6 u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) u.lo[c] = fmin_(a.lo[c], b.lo[c]), u.hi[c] = fmax_(a.hi[c], b.hi[c]);
+        return u;
+    };
+    // option k: 0/1 = R <-> L.left / L.right, 2/3 = L <-> R.left / R.right; gain = area of the child before - after
+    float bestGain = 0.0f;
+    int best = -1;
+    Box6 bestBox;
+    for (int side = 0; side < 2; ++side) {
+        const int inner = side == 0 ? N.left : N.right, other = side == 0 ? N.right : N.left;
+        if (inner < 0) continue;
+        const KNode A = nodes[inner];
+        const float before = boxArea(nodeBox[inner]);
+        const Box6 bo = boxOf(other), b1 = boxOf(A.left), b2 = boxOf(A.right);
+        const Box6 u0 = unite(bo, b2), u1 = unite(b1, bo); // `other` takes the place of A.left / of A.right
+        const float g0 = before - boxArea(u0), g1 = before - boxArea(u1);
+        if (g0 > bestGain) bestGain = g0, best = 2 * side, bestBox = u0;
+        if (g1 > bestGain) bestGain = g1, best = 2 * side + 1, bestBox = u1;
+    }
+    if (best < 0) return;
+    const int side = best >> 1;
+    const int inner = side == 0 ? N.left : N.right, other = side == 0 ? N.right : N.left;
+    KNode A = nodes[inner];
+    int moved; // the grandchild that becomes N's direct child
+    if (best & 1)
+        moved = A.right, A.right = other;
+    else
+        moved = A.left, A.left = other;
+    KNode M = N;
+    if (side == 0)
+        M.right = moved;
+    else
+        M.left = moved;
+    nodes[inner] = A;
+    nodes[i] = M;
+    nodeBox[inner] = bestBox;
+    atomicAdd(applied, 1u);
 }
 
 // Collapse the binary tree into 4-wide nodes, one tree level per launch.  binOf[i] is the binary (Karras)
@@ -721,6 +778,28 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
             HR_CHECK(hipStreamSynchronize(st));
         }
         if (rootStamp == 0) rc = 3;
+#if HR_ROTATE_SWEEPS
+        // tree rotations, bottom-up by stamp; between sweeps the refit rounds renew boxes and stamps (the heights have changed)
+        for (int sweep = 0; sweep < HR_ROTATE_SWEEPS && rc == 0; ++sweep) {
+            HR_CHECK(hipMemsetAsync(total, 0, 4, st));
+            for (uint32_t sv = 2; sv <= rootStamp; ++sv)
+                hipLaunchKernelGGL(k_rotate, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, stamp, sv, total);
+            HR_CHECK(hipMemsetAsync(stamp, 0, 4ull * nInternal, st));
+            rootStamp = 0;
+            for (uint32_t round = 1; round <= 96 && rootStamp == 0; ++round) {
+                hipLaunchKernelGGL(k_refit_round, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, stamp, round);
+                if ((round & 15u) == 0u) {
+                    HR_CHECK(hipMemcpyAsync(&rootStamp, stamp, 4, hipMemcpyDeviceToHost, st));
+                    HR_CHECK(hipStreamSynchronize(st));
+                }
+            }
+            if (rootStamp == 0) {
+                HR_CHECK(hipMemcpyAsync(&rootStamp, stamp, 4, hipMemcpyDeviceToHost, st));
+                HR_CHECK(hipStreamSynchronize(st));
+            }
+            if (rootStamp == 0) rc = 3;
+        }
+#endif
         const uint32_t nMax = (uint32_t)nInternal; // every 4-wide node stands for one binary inner node
 #if HR_NODE32
         // a node's triangles live at 4 * node + 3 - slot: four slots per possible node, unused ones marked by 0xFF bytes (prim id -1)
