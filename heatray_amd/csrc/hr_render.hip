@@ -779,7 +779,7 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                     const HR_GLOBAL hr_material &M = G(S.materials)[mid];
                     if (M.type == HR_MAT_GLASS) {
                         ++nShaded;
-                        sh.glass(in, sf, h.t, M, nee, next);
+                        sh.glass(in, sf, h.t, M, nee, next, extra[0]);
                     } else if (M.type == HR_MAT_PBR) {
                         ++nShaded;
                         sh.physicallyBased(in, sf, M, nee, next, extra[0], extra[1], extra[2]);

@@ -928,9 +928,11 @@ template <int MODE> struct ShaderT {
         }
     }
     HRD void directSpecularGlassSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 weight, v3 baseColor, float roughnessAlpha,
-                                       float materialRoughnessAlpha, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next) const // :83-129
+                                       float materialRoughnessAlpha, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next,
+                                       Ray &nee2) const // :83-129
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
+        const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
+        LightSample ls = computeLightSample(N, lightProbability, P, both);
         if (ls.type != LIGHT_TYPE_ENVIRONMENT) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -951,15 +953,24 @@ template <int MODE> struct ShaderT {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    emit(r, nee, next);
+                    if (both)
+                        nee2 = r;
+                    else
+                        emit(r, nee, next);
                 }
             }
+        }
+        if (both) {
+            if (S.lights.env_enabled)
+                indirectSpecularGlassSample(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, 1.0f, rand, frame, MISS_ENV, nee,
+                                            next);
+        } else if (ls.type != LIGHT_TYPE_ENVIRONMENT) {
         } else if (ls.probability > 0.0f) {
             indirectSpecularGlassSample(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, ls.probability, rand, frame,
                                         MISS_ENV, nee, next);
         }
     }
-    HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next) // :138-280
+    HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, Ray &nee2) // :138-280
     {
         const uint32_t F = M.flags;
         const bool hasTextures = (F & (HR_MF_HAS_BASE_COLOR_TEXTURE | HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE | HR_MF_HAS_NORMALMAP)) != 0;
@@ -1049,7 +1060,7 @@ template <int MODE> struct ShaderT {
             {
                 rand = getSequenceValue(in.sequenceID + in.depth + 2, si);
                 directSpecularGlassSample(in, sf.P, N, I, NdotI, weight, baseColor, roughnessAlpha, M.roughness_alpha, refractProbability.x, rand,
-                                          frame, nee, next);
+                                          frame, nee, next, nee2);
             }
             if (in.depth < pp.max_ray_depth) {
                 if (in.depth > 3) {

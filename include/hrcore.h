@@ -324,7 +324,8 @@ typedef struct hr_pass_params {
  *     camera ray sends three, a third of the value each, each with its own choice of lobe and its own sequence values.
  * No two rays of a launch may write the same pixel, so the pass's sample is kept as four partial sums (everything of the
  * reference path + the first environment ray; the analytic-light ray; the second and third environment ray), added in this
- * order when the pass resolves.  Up to three more occlusion rays per path; glass keeps the reference's single pick.  Own oracle
+ * order when the pass resolves.  Up to three more occlusion rays per path.  Glass vertices send the analytic-light ray and the
+ * (lobe-sampled) environment ray as well.  Own oracle
  * contract (bit-exact) and known-answer tests, like ENV_MIS. */
 #define HR_ESTIMATOR_ALL_LIGHTS 2
 

@@ -941,9 +941,10 @@ struct Shader {
     }
     void directSpecularGlassSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 weight, vec3 baseColor, float roughnessAlpha,
                                    float materialRoughnessAlpha, float lightProbability, vec2 rand, const mat3 &frame, Ray &nee,
-                                   Ray &next) // :83-129
+                                   Ray &next, Ray &nee2) // :83-129
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
+        const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
+        LightSample ls = computeLightSample(N, lightProbability, P, both);
         if (ls.type != LIGHT_TYPE_ENVIRONMENT) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -964,15 +965,24 @@ struct Shader {
                     r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                    emit(r, nee, next);
+                    if (both)
+                        nee2 = r;
+                    else
+                        emit(r, nee, next);
                 }
             }
+        }
+        if (both) {
+            if (ctx.lights.env_enabled)
+                indirectSpecularGlassSample(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, 1.0f, rand, frame,
+                                            MISS_ENV, nee, next);
+        } else if (ls.type != LIGHT_TYPE_ENVIRONMENT) {
         } else if (ls.probability > 0.0f) {
             indirectSpecularGlassSample(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, ls.probability, rand,
                                         frame, MISS_ENV, nee, next);
         }
     }
-    void glass(const Ray &in, const Hit &h, const hr_material &M, Ray &nee, Ray &next) // :138-280
+    void glass(const Ray &in, const Hit &h, const hr_material &M, Ray &nee, Ray &next, Ray &nee2) // :138-280
     {
         const TriAttr &attr = ctx.attrs[h.prim];
         Surface sf = surface(in, h);
@@ -1064,7 +1074,7 @@ struct Shader {
             {
                 rand = getSequenceValue(in.sequenceID + in.depth + 2, si);
                 directSpecularGlassSample(in, sf.P, h.prim, N, I, NdotI, weight, baseColor, roughnessAlpha, M.roughness_alpha, refractProbability.x,
-                                          rand, frame, nee, next);
+                                          rand, frame, nee, next, nee2);
             }
             if (in.depth < pp.max_ray_depth) {
                 if (in.depth > 3) {
@@ -1173,7 +1183,7 @@ struct Shader {
                 const hr_material &M = ctx.materials[mid];
                 if (M.type == HR_MAT_GLASS) {
                     st.shaded_hits++;
-                    glass(ray, h, M, nee, next);
+                    glass(ray, h, M, nee, next, extra[0]);
                 } else if (M.type == HR_MAT_PBR) {
                     st.shaded_hits++;
                     physicallyBased(ray, h, M, nee, next, extra[0], extra[1], extra[2]);

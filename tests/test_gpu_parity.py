@@ -425,6 +425,20 @@ def test_all_lights_estimator_bit_exact(golden):
     assert e2.stats().rays_any == oe2.stats().rays_any
 
 
+def test_all_lights_estimator_on_glass_and_clearcoat(golden):
+    # glass vertices send the analytic-light ray and the environment ray as well (glass.rlsl:83-129 picks one light)
+    sc = scenes.triangle_soup(6000, width=96, height=54, bounces=10, passes=16, env=True, glass_fraction=0.4, clearcoat_fraction=0.3)
+    sc.lights.add_point((0.3, 0.8, 0.2), luminous_intensity=683.0 * 3.0)
+    sc.options.estimator = ffi.HR_ESTIMATOR_ALL_LIGHTS
+    g, o, ge, oe = render_both(sc, 5, lut=golden["multiscatter_lut"])
+    assert_parity(g, o, "all-lights estimator, glass + clearcoat soup")
+    assert ge.stats().rays_any == oe.stats().rays_any
+    sc.options.estimator = ffi.HR_ESTIMATOR_REFERENCE
+    r, _, re, _ = render_both(sc, 5, lut=golden["multiscatter_lut"])
+    assert ge.stats().rays_any > re.stats().rays_any                    # more occlusion rays per vertex ...
+    assert abs(float(g[..., :3].mean()) - float(r[..., :3].mean())) < 0.25 * float(r[..., :3].mean())   # ... towards the same image
+
+
 def test_texture_lod_cone_bit_exact(golden):
     # HR_TEXTURE_LOD_CONE (include/hrcore.h): mip chains and per-triangle texel densities are built on the device, the ray cone rides
     # in the ray record, the trilinear lookup follows the oracle's arithmetic — bit-exact HDR buffers, f32 and u8 textures
