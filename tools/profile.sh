@@ -10,6 +10,9 @@ OUT="$ROOT/gpurun_out/prof_$tag"
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 cd "$ROOT"
+# (a throw-away process first: the first GPU process on a fresh box can run a fifth slower, and the summary compares the HIP-event
+# launch averages of the next run with rocprofv3's of the one after)
+python3 bench.py --quick --steps 16 > /dev/null 2>&1 || true
 python3 bench.py $ARGS > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 echo "[profile] plain bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace --output-format csv -- python3 bench.py $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
