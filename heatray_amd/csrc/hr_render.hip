@@ -745,10 +745,11 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
         constexpr bool LOD = (MODE & 1) != 0, ALL = (MODE & 2) != 0;
         // extra[]: the additional occlusion rays of HR_ESTIMATOR_ALL_LIGHTS — [0] the analytic light, [1], [2] the second and third
         // environment sample of a camera ray's hit (never valid in the kernels compiled without the estimator)
-        Ray nee, next, extra[3];
+        Ray nee, next;
+        ExtraRay extra[3];
         nee.valid = next.valid = extra[0].valid = extra[1].valid = extra[2].valid = false;
         uint32_t pixel = 0, prim = 0xFFFFFFFFu;
-        v3 neeValue(0.0f), extraValue[3] = {v3(0.0f), v3(0.0f), v3(0.0f)};
+        v3 neeValue(0.0f), hitP(0.0f);
         if (live) {
             const SegDev &sg = tbl->seg[sI];
             const uint32_t li = i - segStart[2 * sI];
@@ -786,11 +787,7 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                     }
                 }
                 if (nee.valid) nee.valid = sh.lightShaderValue(nee, neeValue);
-                if (ALL) {
-#pragma unroll
-                    for (int j = 0; j < 3; ++j)
-                        if (extra[j].valid) extra[j].valid = sh.lightShaderValue(extra[j], extraValue[j]);
-                }
+                if (ALL) hitP = sf.P; // (where the additional occlusion rays start)
             }
             nAccum += sh.nAccum;
         }
@@ -815,9 +812,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
                     const bool wantX = mine && extra[j].valid;
                     const uint32_t sx = blockReserve(wantX, sg.sCountOut, scratch);
                     if (wantX) {
-                        G(sg.sq.A)[sx] = make_float4(extra[j].o.x, extra[j].o.y, extra[j].o.z, extra[j].maxT);
+                        G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
                         G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
-                        G(sg.sq.C)[sx] = make_float4(extraValue[j].x, extraValue[j].y, extraValue[j].z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
+                        G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
                     }
                 }
             }

@@ -31,6 +31,15 @@ HRD uint32_t packCone(float w, float g) { return (__float_as_uint(w) & 0xFFFF000
 HRD void unpackCone(uint32_t bits, float &w, float &g) { w = __uint_as_float(bits & 0xFFFF0000u), g = __uint_as_float(bits << 16); }
 HRD float widenCone(float g, float roughness) { return fmin_(g + 0.25f * roughness, 1.0f); }
 
+// An additional occlusion ray of HR_ESTIMATOR_ALL_LIGHTS as the shading kernel keeps it until the queue append: it starts at the hit
+// point like the vertex's first one, so direction, range and the value its light shader adds are all there is to it (a third of
+// the registers of a Ray; the value is evaluated where the ray is made)
+struct ExtraRay {
+    v3 d, value;
+    float maxT;
+    bool valid;
+};
+
 // LOD: compiled with the ray-cone texture lookups of HR_TEXTURE_LOD_CONE.  The shading kernel exists in both variants; the one
 // without is what runs until a pass asks for the mode (its code and register allocation are those of the level-0 sampler alone).
 template <int MODE> struct ShaderT {
@@ -414,6 +423,13 @@ template <int MODE> struct ShaderT {
     // reference; the arithmetic is the oracle's (oracle/oracle_shade.cpp, same operations in the same order).
     HRD bool envMis() const { return pp.estimator != HR_ESTIMATOR_REFERENCE && S.envW > 0; }
     HRD bool allLights() const { return ALL && pp.estimator == HR_ESTIMATOR_ALL_LIGHTS; }
+    // evaluate an additional occlusion ray's light shader now and keep what the queue append needs
+    HRD void keep(const Ray &r, ExtraRay &x) const
+    {
+        v3 value(0.0f);
+        x.valid = r.valid && lightShaderValue(r, value);
+        x.d = r.d, x.maxT = r.maxT, x.value = value;
+    }
     static constexpr int kPrimaryEnvSamples = 3; // environment samples HR_ESTIMATOR_ALL_LIGHTS takes at a camera ray's hit
     HRD void envTexelOf(v3 dir, int &i, int &j) const
     {
@@ -688,7 +704,7 @@ template <int MODE> struct ShaderT {
     }
 
     // ---- physicallyBased.rlsl:55-331 ----
-    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, Ray &nee2, Ray &nee3, Ray &nee4)
+    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, ExtraRay &nee2, ExtraRay &nee3, ExtraRay &nee4)
     {
         Ray in = inRay;
         const uint32_t F = M.flags;
@@ -826,7 +842,7 @@ template <int MODE> struct ShaderT {
                         r.missKind = ls.missKind, r.missIdx = ls.missIdx;
                         r.extraT = 0.0f;
                         if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
-                        nee2 = r;
+                        keep(r, nee2);
                     }
                 }
                 // (2) The environment, always: one MIS-weighted sample per vertex, three at a camera ray's hit (that is where the
@@ -836,32 +852,40 @@ template <int MODE> struct ShaderT {
                     const bool mis = envMis();
                     const int nSamples = (mis && in.depth == 0) ? kPrimaryEnvSamples : 1;
                     const float nEnv = (float)nSamples;
-#pragma unroll
-                    for (int j = 0; j < kPrimaryEnvSamples; ++j) {
-                        if (j >= nSamples) break;
-                        Ray &out = (j == 0) ? nee : ((j == 1) ? nee3 : nee4);
+                    for (int j = 0; j < nSamples; ++j) {
                         float u = probability.x + (float)j * 0.333333343f;
                         if (u > 1.0f) u = u - 1.0f;
-                        if (u <= diffuseProbability) {
+                        // the lobe of this sample: 0 diffuse, 1 clearcoat, 2 specular, 3 none
+                        const int lobe = (u <= diffuseProbability) ? 0
+                                         : ((u <= (diffuseProbability + clearCoatProbability))
+                                                ? 1
+                                                : ((u <= (diffuseProbability + clearCoatProbability + specularProbability)) ? 2 : 3));
+                        if (lobe == 3) continue;
+                        Ray out, unusedNext;
+                        out.valid = false;
+                        if (lobe == 0) {
                             if (mis)
-                                envMisDiffuse(in, sf.P, N, Cdiff, diffuseProbability, nEnv, rand, frame, out, next, j);
+                                envMisDiffuse(in, sf.P, N, Cdiff, diffuseProbability, nEnv, rand, frame, out, unusedNext, j);
                             else
-                                indirectDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, 1.0f, rand, frame, MISS_ENV, out, next);
-                        } else if (u <= (diffuseProbability + clearCoatProbability)) {
+                                indirectDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, 1.0f, rand, frame, MISS_ENV, out, unusedNext);
+                        } else {
+                            const bool coat = lobe == 1;
+                            const v3 lN = coat ? clearCoatN : N, lC = coat ? v3(clearCoatScale) : Cspec;
+                            const float lNdotV = coat ? clearCoatNdotV : NdotV, lAlpha = coat ? clearCoatRoughnessAlpha : roughnessAlpha,
+                                        lRough = coat ? clearCoatRoughness : roughness, lProb = coat ? clearCoatProbability : specularProbability;
                             if (mis)
-                                envMisSpecular(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                               clearCoatRoughness, clearCoatProbability, nEnv, rand, frame, out, next, j);
+                                envMisSpecular(in, sf.P, lN, V, lNdotV, lC, lAlpha, M.multiscatter_lut, lRough, lProb, nEnv, rand, frame, out, unusedNext, j);
                             else
-                                indirectSpecularSample(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha,
-                                                       M.multiscatter_lut, clearCoatRoughness, clearCoatProbability, 1.0f, rand, frame, MISS_ENV, out, next);
-                        } else if (u <= (diffuseProbability + clearCoatProbability + specularProbability)) {
-                            if (mis)
-                                envMisSpecular(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability, nEnv, rand,
-                                               frame, out, next, j);
-                            else
-                                indirectSpecularSample(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability,
-                                                       1.0f, rand, frame, MISS_ENV, out, next);
+                                indirectSpecularSample(in, sf.P, lN, V, lNdotV, lC, lAlpha, M.multiscatter_lut, lRough, lProb, 1.0f, rand, frame, MISS_ENV, out,
+                                                       unusedNext);
                         }
+                        if (!out.valid) continue;
+                        if (j == 0)
+                            nee = out;
+                        else if (j == 1)
+                            keep(out, nee3);
+                        else
+                            keep(out, nee4);
                     }
                 }
             } else if (probability.x <= diffuseProbability) {
@@ -929,7 +953,7 @@ template <int MODE> struct ShaderT {
     }
     HRD void directSpecularGlassSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 weight, v3 baseColor, float roughnessAlpha,
                                        float materialRoughnessAlpha, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next,
-                                       Ray &nee2) const // :83-129
+                                       ExtraRay &nee2) const // :83-129
     {
         const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
         LightSample ls = computeLightSample(N, lightProbability, P, both);
@@ -954,7 +978,7 @@ template <int MODE> struct ShaderT {
                     r.extraT = 0.0f;
                     if (ls.type == LIGHT_TYPE_POINT || ls.type == LIGHT_TYPE_SPOT) r.maxT = ls.maxDistance;
                     if (both)
-                        nee2 = r;
+                        keep(r, nee2);
                     else
                         emit(r, nee, next);
                 }
@@ -970,7 +994,7 @@ template <int MODE> struct ShaderT {
                                         MISS_ENV, nee, next);
         }
     }
-    HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, Ray &nee2) // :138-280
+    HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, ExtraRay &nee2) // :138-280
     {
         const uint32_t F = M.flags;
         const bool hasTextures = (F & (HR_MF_HAS_BASE_COLOR_TEXTURE | HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE | HR_MF_HAS_NORMALMAP)) != 0;
