@@ -58,7 +58,8 @@ struct StepTable {
     int32_t triPhaseLanes; // run the triangle phase once this many lanes are blocked on a postponed leaf
     int32_t fetchMax;      // work items a wave reserves per global atomic while plenty of work is left ...
     int32_t fetchMin;      // ... shrinking to this near the end of the pool (guided self-scheduling: short tail)
-    int32_t pad0, pad1;
+    int32_t staticPerWave; // launches of at most this many rays per resident wave are dealt out statically (k_trace)
+    int32_t pad1;
     SegDev seg[kMaxSegs];
 };
 

@@ -311,6 +311,23 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 
     uint32_t poolLo = 0, poolHi = 0; // wave-uniform: indices this wave has reserved and not handed out yet
     bool exhausted = false;          // wave-uniform: the global cursor ran past the end
+    // Small launches (the late stages of a pass hold a few hundred to a few thousand rays; a tile shard's stages even earlier): up to
+    // tbl->staticPerWave rays per resident wave are dealt out statically — wave g takes items [g * per, (g + 1) * per) — instead of
+    // through the global cursor.  No same-address atomics (5120 waves learning from one counter that nothing is left took ~60 us of
+    // every such launch), every CU gets some of the rays instead of a few waves getting 64 each, and the lanes a wave has left over
+    // take subtrees of its rays at once (the drain phase below): a late-stage launch went from ~210 to 50-80 us.  With only a few
+    // 64-ray chunks per wave the cursor also balances badly (+-1 chunk is +-40 %): 865 k rays on 5120 waves take 0.80 ms dealt out
+    // against 1.30 ms fetched; from ~500 rays per wave on the cursor wins (profiles/r3e_static_deal.txt).
+    const uint32_t gridWaves = gridDim.x * kTraceWaves;
+    const bool staticDeal = (unsigned long long)total <= (unsigned long long)gridWaves * (unsigned long long)(tbl->staticPerWave > 0 ? tbl->staticPerWave : 0);
+    if (staticDeal) {
+        const uint32_t per = (total + gridWaves - 1u) / gridWaves;
+        const uint32_t gw = wave * gridDim.x + blockIdx.x; // the first gridDim.x chunks go to different workgroups
+        const unsigned long long lo = (unsigned long long)gw * per;
+        poolLo = lo < total ? (uint32_t)lo : total;
+        poolHi = (lo + per < total) ? (uint32_t)(lo + per) : total;
+        if (poolLo == poolHi) exhausted = true;
+    }
     uint32_t nvC = 0, ntC = 0, nvA = 0, ntA = 0, nacc = 0;
 
     int pend = 0; // postponed leaf (a negative leaf reference) or 0: the lane keeps descending while a leaf waits
@@ -333,6 +350,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
         if (!exhausted && (nIdle >= kRefill || nIdle == 64)) {
             for (int round = 0; round < 2 && nIdle > 0; ++round) {
                 if (poolLo == poolHi) { // reserve another chunk of the global index space
+                    if (staticDeal) { // (this wave's share of a small launch has been handed out)
+                        exhausted = true;
+#ifdef HR_TAILPROF
+                        tExh = wall_clock64();
+#endif
+                        break;
+                    }
                     // chunk ~ (work left) / (2 x waves), from the cursor value this wave saw last (any size is valid)
                     uint32_t chunk = (total - lastBase) / wavesTimes2;
                     chunk = chunk > fetchMax ? fetchMax : (chunk < fetchMin ? fetchMin : chunk);
@@ -793,6 +817,43 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
         }
         // per-pass compaction of the emitted rays (the passes present in this batch are a contiguous range)
         const int sLo = segRange[0], sHi = segRange[1];
+        if (sHi - sLo >= 2) {
+            // A batch that spans several passes (the late stages of a pass hold a few rays each, and a launch carries dozens of passes):
+            // one reservation per wave and pass PRESENT in the wave, instead of two or more block-wide reservations — barriers and a
+            // returning atomic each — for every pass of the range whether it emitted anything or not (that loop was the 35-45 us floor
+            // of every late-stage launch).  Slot order inside a queue never matters: every ray carries its pixel.
+            unsigned long long todo = __ballot(live && (nee.valid || next.valid || (ALL && (extra[0].valid || extra[1].valid || extra[2].valid))));
+            while (todo != 0ull) {
+                const int s = __shfl(sI, __ffsll((long long)todo) - 1);
+                const bool mine = live && sI == s;
+                todo &= ~__ballot(mine);
+                const SegDev &sg = tbl->seg[s];
+                const bool wantS = mine && nee.valid;
+                const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
+                if (wantS) {
+                    G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                    G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
+                    G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+                }
+                if (ALL) {
+                    const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const bool wantX = mine && extra[j].valid;
+                        const uint32_t sx = waveReserve(wantX, sg.sCountOut);
+                        if (wantX) {
+                            G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
+                            G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
+                            G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
+                        }
+                    }
+                }
+                const bool wantQ = mine && next.valid;
+                const uint32_t qSlot = waveReserve(wantQ, sg.qCountOut);
+                if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
+            }
+            continue;
+        }
         for (int s = sLo; s <= sHi; ++s) {
             const SegDev &sg = tbl->seg[s];
             const bool mine = live && sI == s;
