@@ -102,6 +102,7 @@ struct hr_ctx {
         RayQueue q[2]{};
         ShadowQueue sq{};
         void *hits = nullptr;
+        uint32_t *hitIdx = nullptr; // hit list: PBR hits from the front, glass hits from the back (k_shade_sort -> k_shade_hit)
         float *passbuf = nullptr;
         float *passbufB = nullptr; // second partial sum (allLightsUsed): passbuf + W * H * 4, same allocation
         Counters *ctr = nullptr;
@@ -159,6 +160,7 @@ struct hr_ctx {
     int envW = 0, envH = 0, envTex = -2;
     float envMeanLum = 0.0f;
     bool committed = false, sceneDirty = true, hasPassthrough = false;
+    bool hasGlass = false; // some material is glass (decides whether the glass shading kernel is launched)
     // What changed since the last commit decides what a commit does: a change of the set of geometries rebuilds the tree, a
     // change of transforms only (Scene::applyTransform while the user drags a slider) REFITS it — same topology, every box
     // recomputed bottom-up on the device, no allocation, one synchronisation at the end.
@@ -254,8 +256,8 @@ struct hr_ctx {
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
-    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256;
-    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed}; }
+    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1;
+    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass, tuneSplitShade == 0}; }
 };
 
 #define FAIL(ctx, code, msg)  \
@@ -340,7 +342,7 @@ static void freeQueues(hr_ctx *c)
     for (hr_ctx::PassSlot &ps : c->slots) {
         for (int i = 0; i < 2; ++i) hipFree(ps.q[i].A), hipFree(ps.q[i].B), hipFree(ps.q[i].C), hipFree(ps.q[i].D);
         hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C);
-        hipFree(ps.hits), hipFree(ps.passbuf);
+        hipFree(ps.hits), hipFree(ps.hitIdx), hipFree(ps.passbuf);
         if (ps.evFinal) hipEventDestroy(ps.evFinal);
         if (ps.evResolved) hipEventDestroy(ps.evResolved);
         ps = hr_ctx::PassSlot();
@@ -358,7 +360,7 @@ static void slotBudget(hr_ctx *c)
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
         const size_t k = c->allLightsUsed ? 4 : 1;
-        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 * k + hitRecordSize()) + fbBytes * k + sizeof(Counters);
+        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 * k + hitRecordSize() + 4) + fbBytes * k + sizeof(Counters);
         const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
         c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
     }
@@ -427,7 +429,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -1333,9 +1335,11 @@ static int uploadScene(hr_ctx *c)
     s.texDensity = c->texDensityStale ? nullptr : c->dTexDensity;
     HIP_TRY(c, hipMemcpy(c->dScene, &s, sizeof(SceneDev), hipMemcpyHostToDevice));
     // rays can outlive maxRayDepth only by passing through single-sided / alpha-masked surfaces
-    c->hasPassthrough = false;
-    for (const hr_material &m : c->materials)
+    c->hasPassthrough = false, c->hasGlass = false;
+    for (const hr_material &m : c->materials) {
         if (m.type == HR_MAT_PBR && (!(m.flags & HR_MF_DOUBLE_SIDED) || (m.flags & HR_MF_ALPHA_MASK))) c->hasPassthrough = true;
+        if (m.type == HR_MAT_GLASS) c->hasGlass = true;
+    }
     c->sceneDirty = false;
     return HR_OK;
 }
@@ -1465,6 +1469,7 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
     if (e == hipSuccess) e = hipMalloc(&ps.sq.B, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.sq.C, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.hits, cap * hitRecordSize());
+    if (e == hipSuccess) e = hipMalloc(&ps.hitIdx, cap * sizeof(uint32_t));
     // (with HR_ESTIMATOR_ALL_LIGHTS the sample's second partial sum lies right behind the first: k_trace indexes one buffer)
     if (e == hipSuccess) e = hipMalloc(&ps.passbuf, fbBytes * (c->allLightsUsed ? 4 : 1));
     if (e == hipSuccess && c->allLightsUsed) ps.passbufB = ps.passbuf + (size_t)c->W * c->H * 4;
@@ -1619,7 +1624,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     tbl.nSeg = n;
     tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
     tbl.fetchMax = c->tuneFetchMax > 0 ? c->tuneFetchMax : 1, tbl.fetchMin = c->tuneFetchMin > 0 ? c->tuneFetchMin : 1;
-    tbl.staticPerWave = c->tuneStaticDeal, tbl.pad1 = 0;
+    tbl.staticPerWave = c->tuneStaticDeal, tbl.hasGlass = c->hasGlass ? 1 : 0;
     int injectedSegs[kMaxSegs];
     int nInjectedSegs = 0;
     for (int k = 0; k < n; ++k) {
@@ -1633,6 +1638,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         sg.sCountIn = st > 0 ? &ps.ctr->sCount[st - 1] : c->dZero;
         sg.qCountOut = &ps.ctr->qCount[st + 1];
         sg.sCountOut = &ps.ctr->sCount[st];
+        sg.hitIdx = ps.hitIdx, sg.pCount = &ps.ctr->pCount[st], sg.gCount = &ps.ctr->gCount[st];
+        sg.hitCap = (uint32_t)(c->queueCapacity ? c->queueCapacity : 1), sg.pad2 = 0;
         sg.pp = ps.pp;
         sg.closestEnabled = (c->hasPassthrough || st < ps.nIter) ? 1 : 0;
         for (int j = 0; j < nInjected; ++j)

@@ -28,6 +28,8 @@ struct LaunchCfg {
     bool collectStats;
     bool textureLod; // some pass has asked for HR_TEXTURE_LOD_CONE: launch the shading kernel that carries the trilinear sampler
     bool allLights;  // some pass has asked for HR_ESTIMATOR_ALL_LIGHTS: the shading kernel that can emit two occlusion rays per vertex
+    bool hasGlass;   // some material of the scene is glass: the glass shading kernel is launched too
+    bool fusedShade; // HR_TUNE="shade=0": the single shading kernel of rounds 1-2 (A/B experiments)
 };
 
 // One in-flight pass as seen by the kernels of one macro step.
@@ -42,6 +44,11 @@ struct SegDev {
     uint32_t *sCountIn;  // number of occlusion rays to trace this step
     uint32_t *qCountOut; // counter shade appends qout with
     uint32_t *sCountOut; // counter shade appends sq with
+    uint32_t *hitIdx;    // hit list of this step: indices into qin of the rays that hit a PBR material from the front, a glass material from the back
+    uint32_t *pCount;    // entries at the front of hitIdx (k_shade_sort appends, k_shade_hit<.., 0> reads)
+    uint32_t *gCount;    // entries at the back of hitIdx
+    uint32_t hitCap;     // capacity of hitIdx (= of the ray queues)
+    uint32_t pad2;
     hr_pass_params pp;   // per-pass uniforms
     int32_t closestEnabled; // 0 in a pass's last step (only its occlusion rays remain)
     int32_t pad;
@@ -59,7 +66,7 @@ struct StepTable {
     int32_t fetchMax;      // work items a wave reserves per global atomic while plenty of work is left ...
     int32_t fetchMin;      // ... shrinking to this near the end of the pool (guided self-scheduling: short tail)
     int32_t staticPerWave; // launches of at most this many rays per resident wave are dealt out statically (k_trace)
-    int32_t pad1;
+    int32_t hasGlass;      // some material of the scene is glass (else the glass hit list is never appended to)
     SegDev seg[kMaxSegs];
 };
 

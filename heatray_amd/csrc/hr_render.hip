@@ -891,6 +891,255 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
     }
 }
 
+// ------------------------------------------------------------------------- shade, split by shader
+// Round 3: the shading stage as three kernels instead of one (the one above stays buildable behind HR_TUNE="shade=0" for A/Bs).
+//
+//   k_shade_sort            one lane per closest-hit ray: a ray that hit nothing runs its defaultPrimitive's shader right here (the
+//                           environment lookup; nothing at all for rl_NullPrimitive); a ray that hit something is appended to its
+//                           pass's hit list — PBR hits from the front, glass hits from the back.  40 VGPRs, bandwidth-bound.
+//   k_shade_hit<MODE, 0>    physicallyBased.rlsl on the PBR hit lists: every lane of every wave runs the material shader
+//   k_shade_hit<MODE, 1>    glass.rlsl on the glass hit lists (launched only when the scene has a glass material)
+//
+// In the single kernel a wave carried the hit fraction of its 64 rays (~26 % on c3) through the material code — regrouping inside a
+// 256-ray workgroup raised that to 38 % — and every instantiation paid the register budget of PBR + glass + miss together
+// (128 VGPRs + 120 B of scratch).  Which lane shades which ray never matters: every ray carries its pixel, and a pixel has at most
+// one closest-hit ray per pass and stage.
+template <class F> HRD void buildStarts(uint32_t *start /* LDS, kMaxSegs + 1 */, int n, F countOf)
+{
+    for (int k = threadIdx.x; k < n; k += blockDim.x) start[k] = countOf(k);
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        constexpr int kPer = (kMaxSegs + 1 + 63) / 64;
+        const int first = (int)threadIdx.x * kPer;
+        uint32_t v[kPer];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            v[j] = (first + j < n) ? start[first + j] : 0u;
+            sum += v[j];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+            if ((int)threadIdx.x >= d) incl += up;
+        }
+        uint32_t acc = incl - sum;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            if (first + j <= n) start[first + j] = acc;
+            acc += v[j];
+        }
+    }
+    __syncthreads();
+}
+HRD int findStart(const uint32_t *start, int n, uint32_t item) // last entry whose first index is <= item
+{
+    int lo = 0, hiB = n - 1;
+    while (lo < hiB) {
+        const int mid = (lo + hiB + 1) >> 1;
+        if (item >= start[mid])
+            lo = mid;
+        else
+            hiB = mid - 1;
+    }
+    return lo;
+}
+
+static const int kSortBlock = 256;
+__global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
+{
+    __shared__ uint32_t start[kMaxSegs + 1];
+    __shared__ uint32_t scratch[2 + kSortBlock / 64];
+    const SceneDev &S = *Sp;
+    stats += blockIdx.x & (kStatSlots - 1);
+    const int nSeg = tbl->nSeg;
+    buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? *tbl->seg[k].qCountIn : 0u; });
+    const uint32_t total = start[nSeg];
+    const bool glassToo = tbl->hasGlass != 0;
+    uint32_t nAccum = 0;
+    for (uint32_t base = blockIdx.x * kSortBlock; base < total; base += gridDim.x * kSortBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const bool live = i < total;
+        const int sI = live ? findStart(start, nSeg, i) : 0;
+        const uint32_t li = live ? i - start[sI] : 0u;
+        int cls = -1; // 0: PBR hit, 1: glass hit
+        if (live) {
+            const SegDev &sg = tbl->seg[sI];
+            const uint32_t hp = G(sg.hits)[li].prim;
+            if (hp == kMissPrim) {
+                // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
+                const uint32_t meta = (uint32_t)G(sg.qin.D)[li].x;
+                if (((meta >> 24) & 7u) == (uint32_t)MISS_ENV) {
+                    const float4 b = G(sg.qin.B)[li], c = G(sg.qin.C)[li];
+                    ShaderT<0> sh(S, sg.pp, G(sg.passbuf) + (size_t)__float_as_uint(c.w) * 4);
+                    sh.performAccumulate(sh.environmentRadiance(v3(b.x, b.y, b.z), v3(c.x, c.y, c.z)));
+                    nAccum += sh.nAccum;
+                }
+            } else {
+                const uint32_t mid = G(S.attrs)[hp & 0x7FFFFFFFu].matflags & kMatMask;
+                if (mid < (uint32_t)S.nMaterials) {
+                    const int32_t type = G(S.materials)[mid].type;
+                    cls = type == HR_MAT_PBR ? 0 : (type == HR_MAT_GLASS ? 1 : -1);
+                }
+            }
+        }
+        const uint32_t last = (total - base < (uint32_t)kSortBlock ? total - base : (uint32_t)kSortBlock) - 1u;
+        const int sLo = findStart(start, nSeg, base), sHi = findStart(start, nSeg, base + last); // (uniform over the workgroup)
+        if (sLo == sHi) { // the usual case: one reservation per workgroup and list
+            const SegDev &sg = tbl->seg[sLo];
+            const uint32_t pSlot = blockReserve(cls == 0, sg.pCount, scratch);
+            if (cls == 0) G(sg.hitIdx)[pSlot] = li;
+            if (glassToo) {
+                const uint32_t gSlot = blockReserve(cls == 1, sg.gCount, scratch);
+                if (cls == 1) G(sg.hitIdx)[sg.hitCap - 1u - gSlot] = li;
+            }
+        } else { // a batch that straddles passes: one reservation per wave, list and pass present in the wave
+            unsigned long long todo = __ballot(cls >= 0);
+            while (todo != 0ull) {
+                const int s = __shfl(sI, __ffsll((long long)todo) - 1);
+                const bool mine = cls >= 0 && sI == s;
+                todo &= ~__ballot(mine);
+                const SegDev &sg = tbl->seg[s];
+                const uint32_t pSlot = waveReserve(mine && cls == 0, sg.pCount);
+                if (mine && cls == 0) G(sg.hitIdx)[pSlot] = li;
+                const uint32_t gSlot = waveReserve(mine && cls == 1, sg.gCount);
+                if (mine && cls == 1) G(sg.hitIdx)[sg.hitCap - 1u - gSlot] = li;
+            }
+        }
+    }
+    nAccum = waveSum(nAccum);
+    if (laneId() == 0 && nAccum) atomicAdd(&stats->accumulates, (unsigned long long)nAccum);
+}
+
+#ifndef HR_HIT_MINBLOCKS
+#define HR_HIT_MINBLOCKS 4
+#endif
+// CLS 0: the PBR hit lists, CLS 1: the glass hit lists
+template <int MODE, int CLS>
+__global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
+{
+    __shared__ uint32_t start[kMaxSegs + 1];
+    __shared__ uint32_t scratch[2 + kShadeBlock / 64];
+    const SceneDev &S = *Sp;
+    stats += blockIdx.x & (kStatSlots - 1);
+    const int nSeg = tbl->nSeg;
+    buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? *(CLS == 0 ? tbl->seg[k].pCount : tbl->seg[k].gCount) : 0u; });
+    const uint32_t total = start[nSeg];
+    constexpr bool LOD = (MODE & 1) != 0, ALL = (MODE & 2) != 0;
+    uint32_t nShaded = 0, nAccum = 0;
+    for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock) {
+        const uint32_t i = base + threadIdx.x;
+        const bool live = i < total;
+        const int sI = live ? findStart(start, nSeg, i) : 0;
+        Ray nee, next;
+        ExtraRay extra[3];
+        nee.valid = next.valid = extra[0].valid = extra[1].valid = extra[2].valid = false;
+        uint32_t pixel = 0, prim = 0xFFFFFFFFu;
+        v3 neeValue(0.0f), hitP(0.0f);
+        if (live) {
+            const SegDev &sg = tbl->seg[sI];
+            const uint32_t j = i - start[sI];
+            const uint32_t li = G(sg.hitIdx)[CLS == 0 ? j : sg.hitCap - 1u - j];
+            const float4 a = G(sg.qin.A)[li], b = G(sg.qin.B)[li], c = G(sg.qin.C)[li];
+            const int4 dm = G(sg.qin.D)[li];
+            const HitRec h = G(sg.hits)[li];
+            Ray in;
+            in.o = v3(a.x, a.y, a.z), in.d = v3(b.x, b.y, b.z), in.maxT = a.w, in.extraT = b.w;
+            in.weight = v3(c.x, c.y, c.z);
+            pixel = __float_as_uint(c.w);
+            const uint32_t meta = (uint32_t)dm.x;
+            in.sequenceID = (int)(meta & 0xFFu), in.depth = (int)((meta >> 8) & 0xFFFFu);
+            in.missKind = (int)((meta >> 24) & 7u), in.missIdx = (int)((meta >> 27) & 7u);
+            in.sequenceIndexOffset = dm.y;
+            in.occlusionTest = false, in.valid = true;
+            in.coneW = in.coneG = 0.0f;
+            if (LOD) unpackCone((uint32_t)dm.w, in.coneW, in.coneG);
+            ShaderT<MODE> sh(S, sg.pp, G(sg.passbuf) + (size_t)pixel * 4);
+            prim = h.prim & 0x7FFFFFFFu;
+            uint32_t mid;
+            const typename ShaderT<MODE>::Surface sf = sh.surface(in, prim, (h.prim >> 31) != 0u, h.t, h.u, h.v, mid);
+            sh.setFootprint(in, sf.normal, h.t, prim);
+            const HR_GLOBAL hr_material &M = G(S.materials)[mid]; // (k_shade_sort listed the ray because mid is a material of this class)
+            ++nShaded;
+            if (CLS == 1)
+                sh.glass(in, sf, h.t, M, nee, next, extra[0]);
+            else
+                sh.physicallyBased(in, sf, M, nee, next, extra[0], extra[1], extra[2]);
+            if (nee.valid) nee.valid = sh.lightShaderValue(nee, neeValue);
+            if (ALL) hitP = sf.P; // (where the additional occlusion rays start)
+            nAccum += sh.nAccum;
+        }
+        // the emitted rays leave through compacted appends to the pass's queues
+        const uint32_t last = (total - base < (uint32_t)kShadeBlock ? total - base : (uint32_t)kShadeBlock) - 1u;
+        const int sLo = findStart(start, nSeg, base), sHi = findStart(start, nSeg, base + last); // (uniform over the workgroup)
+        if (sLo == sHi) {
+            const SegDev &sg = tbl->seg[sLo];
+            const bool wantS = live && nee.valid;
+            const uint32_t sSlot = blockReserve(wantS, sg.sCountOut, scratch);
+            if (wantS) {
+                G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
+                G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+            }
+            if (ALL) {
+                // each extra ray adds to a partial sum of its own (no two rays of a launch may write one pixel): partial sum j + 1 lies
+                // (j + 1) frames behind the first in the pass's buffer — the trace kernel just sees a pixel index beyond the frame
+                const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
+#pragma unroll
+                for (int j = 0; j < (CLS == 1 ? 1 : 3); ++j) {
+                    const bool wantX = live && extra[j].valid;
+                    const uint32_t sx = blockReserve(wantX, sg.sCountOut, scratch);
+                    if (wantX) {
+                        G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
+                        G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
+                        G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
+                    }
+                }
+            }
+            const bool wantQ = live && next.valid;
+            const uint32_t qSlot = blockReserve(wantQ, sg.qCountOut, scratch);
+            if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
+        } else {
+            unsigned long long todo = __ballot(live && (nee.valid || next.valid || (ALL && (extra[0].valid || extra[1].valid || extra[2].valid))));
+            while (todo != 0ull) {
+                const int s = __shfl(sI, __ffsll((long long)todo) - 1);
+                const bool mine = live && sI == s;
+                todo &= ~__ballot(mine);
+                const SegDev &sg = tbl->seg[s];
+                const bool wantS = mine && nee.valid;
+                const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
+                if (wantS) {
+                    G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                    G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
+                    G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+                }
+                if (ALL) {
+                    const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
+#pragma unroll
+                    for (int j = 0; j < (CLS == 1 ? 1 : 3); ++j) {
+                        const bool wantX = mine && extra[j].valid;
+                        const uint32_t sx = waveReserve(wantX, sg.sCountOut);
+                        if (wantX) {
+                            G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
+                            G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
+                            G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
+                        }
+                    }
+                }
+                const bool wantQ = mine && next.valid;
+                const uint32_t qSlot = waveReserve(wantQ, sg.qCountOut);
+                if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
+            }
+        }
+    }
+    nShaded = waveSum(nShaded), nAccum = waveSum(nAccum);
+    if (laneId() == 0) {
+        if (nShaded) atomicAdd(&stats->shadedHits, (unsigned long long)nShaded);
+        if (nAccum) atomicAdd(&stats->accumulates, (unsigned long long)nAccum);
+    }
+}
+
 // ------------------------------------------------------------------------------------ debug trace
 __global__ __launch_bounds__(kBlock) void k_debug_trace(const SceneDev *__restrict__ Sp, int n, const float *__restrict__ o,
                                                         const float *__restrict__ d, const float *__restrict__ tmax,
@@ -947,15 +1196,32 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, co
         hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
 }
 
+template <int MODE> static void launchShadeHit(const LaunchCfg &cfg, int grid, const SceneDev *S, const StepTable *tbl, Stats *stats)
+{
+    hipLaunchKernelGGL((k_shade_hit<MODE, 0>), dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
+    if (cfg.hasGlass) hipLaunchKernelGGL((k_shade_hit<MODE, 1>), dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats);
+}
+
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats)
 {
     const int grid = cfg.numCUs * cfg.shadeBlocksPerCU;
     // four instantiations: bit 0 = HR_TEXTURE_LOD_CONE, bit 1 = HR_ESTIMATOR_ALL_LIGHTS compiled in; the plain one runs until a pass asks for more
-    switch ((cfg.textureLod ? 1 : 0) | (cfg.allLights ? 2 : 0)) {
-    case 0: hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
-    case 1: hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
-    case 2: hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
-    default: hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+    const int mode = (cfg.textureLod ? 1 : 0) | (cfg.allLights ? 2 : 0);
+    if (cfg.fusedShade) {
+        switch (mode) {
+        case 0: hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+        case 1: hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+        case 2: hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+        default: hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
+        }
+        return;
+    }
+    hipLaunchKernelGGL(k_shade_sort, dim3(cfg.numCUs * 8), dim3(kSortBlock), 0, cfg.stream, S, tbl, stats);
+    switch (mode) {
+    case 0: launchShadeHit<0>(cfg, grid, S, tbl, stats); break;
+    case 1: launchShadeHit<1>(cfg, grid, S, tbl, stats); break;
+    case 2: launchShadeHit<2>(cfg, grid, S, tbl, stats); break;
+    default: launchShadeHit<3>(cfg, grid, S, tbl, stats); break;
     }
 }
 

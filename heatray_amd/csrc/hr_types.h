@@ -144,8 +144,8 @@ static const int kMaxBounceSlots = 72;
 struct Counters {
     uint32_t qCount[kMaxBounceSlots]; // rays in the closest-hit queue of iteration i
     uint32_t sCount[kMaxBounceSlots]; // rays in the occlusion queue produced by iteration i
-    uint32_t qHead[kMaxBounceSlots];  // work-fetch cursors of the persistent trace kernels
-    uint32_t sHead[kMaxBounceSlots];
+    uint32_t pCount[kMaxBounceSlots]; // closest-hit rays of iteration i that hit a PBR material (entries of the pass's hit list, from the front)
+    uint32_t gCount[kMaxBounceSlots]; // ... that hit a glass material (entries from the back of the same list)
 };
 
 } // namespace hr
