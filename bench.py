@@ -275,7 +275,26 @@ def main():
     if args.quick:
         args.cpu_seconds, args.no_stats_pass, args.no_pmc, args.no_converge = 0.0, True, True, True
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started plainly with --gpus N: this process becomes the launcher.  It starts the N rank processes itself — one per GPU,
+        # through torch.distributed.run on 127.0.0.1, exactly as the driver does — BEFORE anything here touches the GPU (a process
+        # that holds the GPU never execs or forks workers), relays rank 0's JSON line (the children inherit stdout) and exits with
+        # the launcher's code: a rank that fails makes the whole run fail.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        # (checked before the GPU is touched: a line that says n_gpus = 1 for a run asked to use 8 must never be printed)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: start it as `python bench.py --gpus N` (it launches its own "
+                         f"ranks) or under torch.distributed.run with --nproc-per-node equal to --gpus")
     pmc = None
     if world_env == 1 and not args.no_pmc and not args.pmc_child and args.shard_of <= 1:
         # child processes under rocprofv3, before this process initialises the GPU (a process that holds the GPU never execs)
@@ -290,25 +309,37 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if os.environ.get("HR_BENCH_ONE_DEVICE"):  # rehearsal of the N > 1 code path on a one-GPU box (not a benchmark)
+    # HR_BENCH_ONE_DEVICE: rehearsal of the N > 1 path on a one-GPU box (NOT a benchmark; the line says so): every rank renders its
+    # shard on device 0, and because RCCL refuses two ranks on one device the process group is gloo and the tile gather is staged
+    # through host memory.  Everything else — launcher, rank environment, sharding, per-batch exchange, assembly, checks — is the
+    # code the real run executes.
+    one_device = bool(os.environ.get("HR_BENCH_ONE_DEVICE")) and world > 1
+    if one_device:
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} device(s) visible (HR_BENCH_ONE_DEVICE=1 rehearses the "
+                         f"path on one device; its line is marked as a rehearsal)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # HR_BENCH_FORCE_EXCHANGE: rehearsal of the N > 1 control flow (process group, per-step tile gather, final assembly) in a
-    # single process — RCCL refuses two ranks on one device, so this is how the path is exercised on a one-GPU box
+    # HR_BENCH_FORCE_EXCHANGE: the exchange code path (process group, per-step tile gather, final assembly) in a single process
     forced = bool(os.environ.get("HR_BENCH_FORCE_EXCHANGE")) and world == 1
     exchange = world > 1 or forced
+    backend = "gloo" if one_device else "nccl"
     if forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     elif world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus or dist.get_rank() != rank:
+            raise SystemExit(f"bench.py: the communicator has {dist.get_world_size()} rank(s), --gpus says {args.gpus}")
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the few scalars reduced over the ranks live
 
     emulated = args.shard_of > 1 and world == 1
     eng_world = args.shard_of if emulated else world
@@ -324,7 +355,7 @@ def main():
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
     eng.bind_external_frame(fb.data_ptr())
-    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3, engine=eng) if exchange else None
+    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3, engine=eng, host_staged=one_device) if exchange else None
 
     # libhrcore injects (and therefore resolves) passes in batches (hr_frame_pass_batch): the accumulation buffer changes once per
     # batch, so that is the exchange cadence as well.
@@ -380,8 +411,8 @@ def main():
 
     st = eng.stats()
     kt = eng.kernel_times()
-    rays = torch.tensor([float(st.rays_closest + st.rays_any), float(st.paths), float(st.rays_closest)], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    rays = torch.tensor([float(st.rays_closest + st.rays_any), float(st.paths), float(st.rays_closest)], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if exchange:
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -575,7 +606,7 @@ def main():
         mrays = total_rays / elapsed / 1e6
         out = {
             "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3") else f"Mrays/s ({args.workload})",
-            "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": mrays, "unit": "Mrays/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
             # untimed device wake-up BEFORE the W warm-up steps (clock ramp / first touch of the pass slots on a freshly started box)
             "wakeup_passes": n_wake, "wakeup_s": wake_s,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
@@ -595,6 +626,9 @@ def main():
                       "display_resolve_ms_rgba8": disp_ms,
                       "gpu_traversal_counters": gpu_counts},
         }
+        if one_device:
+            out["rehearsal_one_device"] = True
+            out["metric"] += f" [REHEARSAL: {world} ranks on ONE device over gloo, not a benchmark result]"
         if emulated:
             out["emulated_shard_of"] = eng_world
             out["metric"] += f" [EMULATED rank {eng_rank} of {eng_world}, not a benchmark result]"

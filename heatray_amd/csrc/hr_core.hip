@@ -1601,8 +1601,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
                 hr_ctx::PassSlot &ps = c->slots[i];
                 if (!ps.active || ps.group != g || G.statusOrder[ring][i] != ps.order + 1ull) continue;
                 const int st = ps.step;
-                const bool empty = st >= 2 && snap[(size_t)i * kMaxBounceSlots + (st - 1)] == 0u;
-                if (empty || st >= kMaxBounceSlots - 2) {
+                const bool empty = st >= 2 && snap[(size_t)i * kMaxBounceSlots + ((st - 1) % kMaxBounceSlots)] == 0u;
+                if (empty) {
                     ps.active = false, ps.finished = true;
                     HIP_TRY(c, hipEventRecord(ps.evFinal, G.stream));
                 }
@@ -1634,11 +1634,23 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         sg.qin = ps.q[st & 1], sg.qout = ps.q[(st + 1) & 1], sg.sq = ps.sq;
         sg.hits = (HitRec *)ps.hits, sg.passbuf = ps.passbuf;
         sg.passbufB = ps.pp.estimator == HR_ESTIMATOR_ALL_LIGHTS ? ps.passbufB : nullptr;
-        sg.qCountIn = &ps.ctr->qCount[st];
-        sg.sCountIn = st > 0 ? &ps.ctr->sCount[st - 1] : c->dZero;
-        sg.qCountOut = &ps.ctr->qCount[st + 1];
-        sg.sCountOut = &ps.ctr->sCount[st];
-        sg.hitIdx = ps.hitIdx, sg.pCount = &ps.ctr->pCount[st], sg.gCount = &ps.ctr->gCount[st];
+        // The per-stage counters are a ring: a chain of pass-through rays (stacked single-sided sheets seen from behind, alpha holes:
+        // physicallyBased.rlsl:70-108 re-emits without a depth bound) can outlive any fixed number of stages, so from stage
+        // kMaxBounceSlots - 1 on the entries this step appends to are cleared first (their previous use lies a whole ring back).
+        const int R = kMaxBounceSlots;
+        if (st + 1 >= R) {
+            HIP_TRY(c, hipMemsetAsync(&ps.ctr->qCount[(st + 1) % R], 0, sizeof(uint32_t), G.stream));
+            if (st >= R) {
+                HIP_TRY(c, hipMemsetAsync(&ps.ctr->sCount[st % R], 0, sizeof(uint32_t), G.stream));
+                HIP_TRY(c, hipMemsetAsync(&ps.ctr->pCount[st % R], 0, sizeof(uint32_t), G.stream));
+                HIP_TRY(c, hipMemsetAsync(&ps.ctr->gCount[st % R], 0, sizeof(uint32_t), G.stream));
+            }
+        }
+        sg.qCountIn = &ps.ctr->qCount[st % R];
+        sg.sCountIn = st > 0 ? &ps.ctr->sCount[(st - 1) % R] : c->dZero;
+        sg.qCountOut = &ps.ctr->qCount[(st + 1) % R];
+        sg.sCountOut = &ps.ctr->sCount[st % R];
+        sg.hitIdx = ps.hitIdx, sg.pCount = &ps.ctr->pCount[st % R], sg.gCount = &ps.ctr->gCount[st % R];
         sg.hitCap = (uint32_t)(c->queueCapacity ? c->queueCapacity : 1), sg.pad2 = 0;
         sg.pp = ps.pp;
         sg.closestEnabled = (c->hasPassthrough || st < ps.nIter) ? 1 : 0;

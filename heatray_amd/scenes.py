@@ -387,3 +387,42 @@ def multi_material(width=320, height=180, bounces=8, passes=32, slices=24, env_c
     o.focus_distance = 8.0
     o.fstop = host.FSTOP_DISABLED
     return sc
+
+
+def stacked_sheets(n_sheets=120, width=64, height=36, bounces=3, passes=8, alpha_every=3):
+    """`n_sheets` parallel single-sided quads seen from BEHIND, every `alpha_every`-th one an alpha-masked sheet full of holes
+    instead; behind them a lit double-sided wall.  Every camera ray is re-emitted through every sheet (physicallyBased.rlsl:70-108:
+    back faces of single-sided materials and alpha holes pass rays on without counting a bounce), so a path is more than
+    `n_sheets` ray segments long whatever maxRayDepth says — the case the pass pipeline's per-stage counters must survive."""
+    sc = Scene("stacked_sheets", width=width, height=height)
+    chk = np.zeros((8, 8), dtype=F)  # alpha: holes everywhere but for one opaque texel in 64
+    chk[3, 5] = 1.0
+    rgba = np.stack([np.full_like(chk, 0.9), np.full_like(chk, 0.8), np.full_like(chk, 0.7), chk], axis=-1).astype(F)
+    sc.textures.append((rgba, ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_NEAREST))
+    sc.materials[0] = host.bake_pbr(base_color=(0.8, 0.3, 0.2), roughness=0.6, double_sided=False)                       # back faces pass rays on
+    sc.materials[1] = host.bake_pbr(base_color=(1.0, 1.0, 1.0), roughness=1.0, specular_f0=0.0, alpha_mask=True, base_color_texture=0)
+    sc.materials[2] = host.bake_pbr(base_color=(0.7, 0.7, 0.75), roughness=0.9)                                          # the wall
+    solid, holes = [], []
+    for k in range(n_sheets):
+        z = -0.02 * k
+        # CCW seen from -z (normal -z): the camera at +z sees the back face
+        q = _quad((-1.5, -1.0, z), (-1.5, 1.0, z), (1.5, 1.0, z), (1.5, -1.0, z))
+        (holes if (alpha_every and k % alpha_every == alpha_every - 1) else solid).append(q)
+    p, n, i = _merge(solid)
+    sc.meshes.append(MeshData(p, n, i, material_id=0))
+    if holes:
+        p, n, i = _merge(holes)
+        uv = np.tile(np.array([[0, 0], [0, 3], [3, 3], [3, 0]], dtype=F), (len(holes), 1))
+        sc.meshes.append(MeshData(p, n, i, uvs=uv, material_id=1, is_occluder=False))  # Mesh.cpp:95-100
+    zw = -0.02 * n_sheets - 0.5
+    p, n, i = _quad((-3, -2, zw), (3, -2, zw), (3, 2, zw), (-3, 2, zw))  # faces +z
+    sc.meshes.append(MeshData(p, n, i, material_id=2))
+    sc.lights.add_directional(illuminance=683.0 * 2.0, phi=0.3, theta=1.2)
+    sc.env_pixels = np.array((0.4, 0.5, 0.6), dtype=F).reshape(1, 1, 3)
+    o = sc.options
+    o.max_ray_depth, o.max_render_passes = bounces, passes
+    o.aspect_ratio = width / height
+    o.view_matrix = host.orbit_view_matrix(4.0, 0.0, 0.0, target=(0, 0, 0))
+    o.focus_distance = 4.0
+    o.fstop = host.FSTOP_DISABLED
+    return sc

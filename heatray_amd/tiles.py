@@ -104,12 +104,15 @@ class FrameGatherer:
 
     Bit-exact by construction: pixels are copied, never summed."""
 
-    def __init__(self, width, height, rank, world, device, tile=32, dst=0, n_buffers=2, overlap=True, engine=None):
+    def __init__(self, width, height, rank, world, device, tile=32, dst=0, n_buffers=2, overlap=True, engine=None, host_staged=False):
         import torch
         self.torch = torch
         self.w, self.h, self.rank, self.world, self.dst = width, height, rank, world, dst
         self.device = torch.device(device)
         self.engine = engine
+        # host_staged: the collective runs on host copies of the staging buffers (a gloo group with the frames on a GPU: the one-device
+        # rehearsal of bench.py); packing and unpacking stay on the device
+        self.host_staged = bool(host_staged)
         if engine is not None:
             self.idx = None
             self.n_max = max(engine.packed_slots(r, world) for r in range(world))
@@ -122,7 +125,7 @@ class FrameGatherer:
             if rank == dst else None
         self.full = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device) if rank == dst else None
         self.cuda = self.device.type == "cuda"
-        self.side = torch.cuda.Stream(device=self.device) if (self.cuda and overlap) else None
+        self.side = torch.cuda.Stream(device=self.device) if (self.cuda and overlap and not self.host_staged) else None
         self.free_ev = [None] * n_buffers  # recorded on the side stream when a staging buffer may be reused
         self.turn = 0
         self.posted = False
@@ -159,7 +162,15 @@ class FrameGatherer:
         self.posted = True
 
     def _exchange(self, b, dist, stream):
-        dist.gather(self.send[b], self.recv[b] if self.rank == self.dst else None, dst=self.dst)
+        if self.host_staged:
+            host = self.send[b].cpu()  # (synchronises with the packing kernel on the current stream)
+            got = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(host, got, dst=self.dst)
+            if self.rank == self.dst:
+                for r in range(self.world):
+                    self.recv[b][r].copy_(got[r])
+        else:
+            dist.gather(self.send[b], self.recv[b] if self.rank == self.dst else None, dst=self.dst)
         if self.rank == self.dst:
             if self.engine is not None:
                 for r in range(self.world):

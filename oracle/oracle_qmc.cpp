@@ -244,8 +244,11 @@ void randomPolygonal(vec2 *results, uint32_t numEdges, uint32_t count, uint32_t 
 }
 
 // ---- multiscatter LUT (MultiScatterUtil.cpp:20-139) --------------------------------
-// Host-side generator in the reference: uses libm and glm::normalize
-// (v * inversesqrt(dot)), restated as such.
+// Host-side generator in the reference: libm's cosf / sinf and glm::normalize (v * inversesqrt(dot)).  The last bit of libm's
+// cosf / sinf is library-specific, so — like every other transcendental of the arithmetic contract (oracle_math.h) — they are
+// the Cephes single-precision algorithms here, on this side and in the product's k_multiscatter_lut alike: the two tables are
+// then the same bits (tests/test_gpu_parity.py), and both stay within 2e-6 of the TIFF the reference ships (the reference's
+// own libm differs from any other by as much).
 static inline float sq(float f) { return f * f; }
 static float lutG1(float NdotI, float alpha) // :22-27
 {
@@ -264,7 +267,9 @@ static float lutValue(float NdotV, float alpha, const std::vector<vec2> &seq) //
         const float cosTheta = sqrtf(std::max(0.0f, (1.0f - seq[i].x) / ((a2 - 1.0f) * seq[i].x + 1.0f)));
         const float sinTheta = sqrtf(std::max(0.0f, 1.0f - sq(cosTheta)));
         const float phi = two_pi * seq[i].y;
-        vec3 H(sinTheta * cosf(phi), sinTheta * sinf(phi), cosTheta);
+        float sn, cs;
+        sincos_(phi, &sn, &cs);
+        vec3 H(sinTheta * cs, sinTheta * sn, cosTheta);
         H = H * (1.0f / sqrtf(dot(H, H))); // glm::normalize
         const vec3 L = 2.0f * dot(V, H) * H - V;
         float NdotL = clamp_(L.z, 0.0f, 1.0f);

@@ -1,0 +1,62 @@
+"""bench.py --gpus N: the launcher contract.
+
+Started plainly with --gpus N > 1 the script starts its N ranks itself (torch.distributed.run on 127.0.0.1); any
+disagreement between --gpus, WORLD_SIZE and the communicator ends the run with a non-zero code and no JSON line, so a
+line that says n_gpus = 1 can never come out of a run that was asked for 8.  The CPU tests cover the refusals (nothing
+here touches a GPU); the GPU test rehearses the whole N = 2 path on one device (gloo group, host-staged tile gather)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None, timeout=600):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HR_BENCH_ONE_DEVICE", "HR_BENCH_FORCE_EXCHANGE"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout, cwd=ROOT)
+
+
+def _json_lines(out):
+    return [l for l in out.decode(errors="replace").splitlines() if l.startswith("{")]
+
+
+def test_world_size_mismatch_is_refused_before_the_gpu_is_touched():
+    r = _run(["--gpus", "3", "--quick"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode != 0
+    assert b"--gpus 3 but WORLD_SIZE=2" in r.stderr
+    assert not _json_lines(r.stdout)
+    # ... also when the environment says one rank and the command line eight
+    r = _run(["--gpus", "8", "--quick"], env={"WORLD_SIZE": "1"}, timeout=120)
+    assert r.returncode != 0 and not _json_lines(r.stdout)
+    r = _run(["--gpus", "0", "--quick"], timeout=120)
+    assert r.returncode != 0
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="CPU-only check: on a GPU box the launcher's children would render")
+def test_plain_start_with_two_gpus_launches_ranks_and_fails_loudly_without_devices():
+    # no GPU here: the launcher must start the ranks (torch.distributed.run), they must refuse, and the launcher must pass the failure on
+    r = _run(["--gpus", "2", "--quick", "--steps", "2", "--workload", "c1"], timeout=400)
+    assert r.returncode != 0
+    assert not _json_lines(r.stdout)
+    err = r.stderr.decode(errors="replace")
+    assert "torch.distributed" in err or "ChildFailedError" in err or "device(s) visible" in err or "HIP" in err, err[-2000:]
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_on_one_device():
+    r = _run(["--gpus", "2", "--quick", "--steps", "6", "--warmup", "1", "--workload", "c2", "--width", "512", "--height", "288"],
+             env={"HR_BENCH_ONE_DEVICE": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout.decode(errors="replace")[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rehearsal_one_device"] is True and d["steps"] == 6
+    assert "REHEARSAL" in d["metric"]
+    assert d["value"] > 0 and d["extra"]["rays"] > 0
