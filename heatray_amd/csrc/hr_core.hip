@@ -782,6 +782,9 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     total += ((size_t)g.nIdx * 4 + 15) & ~(size_t)15;
     g.blockBytes = total;
     HIP_TRY(c, hipMalloc((void **)&g.dBlock, total ? total : 16));
+    // (the 16-byte alignment padding behind each range is never uploaded, yet the tree cache's content hash covers the whole block:
+    // recycled device memory there made the key differ from run to run)
+    HIP_TRY(c, hipMemsetAsync(g.dBlock, 0, total ? total : 16, c->stream));
     int rc = HR_OK;
     for (int a = 0; a < 6 && rc == HR_OK; ++a)
         if (g.has[a]) rc = stagedUpload(c, g.dBlock + g.off[a], tight[a].empty() ? (const char *)src[a] : (const char *)tight[a].data(), bytesOf[a]);
@@ -834,8 +837,62 @@ struct CacheHeader {
     unsigned long long key;
     uint32_t nTris, nNodes, levels, rootLeafCount, triSlots, pad;
     uint32_t levelStart[kMaxLevels + 1];
+    unsigned long long payloadSum; // checksum of everything behind the header (the key covers the SCENE, not the file)
 };
-const uint32_t kCacheVersion = 2;
+const uint32_t kCacheVersion = 3;
+
+// 64-bit checksum of the payload, eight bytes at a time (the files are tens to hundreds of MB)
+unsigned long long payloadChecksum(const char *p, size_t bytes)
+{
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        unsigned long long w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0xFF51AFD7ED558CCDull;
+        h ^= h >> 29;
+    }
+    unsigned long long tail = 0;
+    if (i < bytes) std::memcpy(&tail, p + i, bytes - i);
+    h = (h ^ tail ^ (unsigned long long)bytes) * 0xC4CEB9FE1A85EC53ull;
+    return h ^ (h >> 32);
+}
+
+// Everything the kernels index with comes out of the file: child ranges, leaf triangle slots, the prim -> slot map, the level table.
+// A file that passes the checksum can still have been written by something else, so every index is range-checked before the arrays
+// reach the device (an out-of-range child or slot is a GPU fault or a hang in k_refit4 / k_trace, not a wrong pixel).
+bool cachedTreeIsSane(const CacheHeader &h, const char *nodesBytes, const uint32_t *slotOfPrim)
+{
+    if (h.triSlots < h.nTris || h.triSlots >= (1u << 28) || h.rootLeafCount > 4u || h.levels > (uint32_t)kMaxLevels) return false;
+    if (h.rootLeafCount > 0 && h.rootLeafCount > h.triSlots) return false;
+    if (h.levelStart[0] != 0u) return false;
+    for (uint32_t l = 0; l < h.levels; ++l)
+        if (h.levelStart[l + 1] < h.levelStart[l] || h.levelStart[l + 1] > h.nNodes) return false;
+    if (h.levels > 0 && h.levelStart[h.levels] != h.nNodes) return false;
+    for (uint32_t i = 0; i < h.nTris; ++i)
+        if (slotOfPrim[i] >= h.triSlots) return false;
+#if !HR_NODE32
+    for (uint32_t i = 0; i < h.nNodes; ++i) {
+        Node4 n;
+        std::memcpy(&n, nodesBytes + (size_t)i * sizeof(Node4), sizeof(Node4));
+        uint32_t meta;
+        std::memcpy(&meta, &n.a.w, 4);
+        const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
+        if (nValid > 4u || nInner > nValid) return false;
+        if (nInner > 0) { // inner children are nodes innerBase .. innerBase + nInner - 1, allocated behind their parent (breadth-first)
+            const uint32_t base = n.c.z;
+            if (base <= i || base >= h.nNodes || nInner > h.nNodes - base) return false;
+        }
+        for (uint32_t j = nInner; j < nValid; ++j) { // leaf child j is the triangle ~(leafKey + j)
+            const uint32_t slot = ~(n.c.w + j);
+            if (slot >= h.triSlots) return false;
+        }
+    }
+#else
+    (void)nodesBytes;
+#endif
+    return true;
+}
 } // namespace
 
 // digest of everything the tree depends on: geometry bytes (hashed on the device), transforms, modes, strides
@@ -878,7 +935,9 @@ static bool loadTree(hr_ctx *c, unsigned long long key, uint32_t nTris, BuildRes
     if (ok) {
         const size_t nb = (size_t)h.nNodes * sizeof(Node4), bb = (size_t)h.nNodes * sizeof(Box6), sb = (size_t)nTris * 4;
         buf.resize(nb + bb + sb);
-        ok = fread(buf.data(), 1, buf.size(), f) == buf.size();
+        ok = fread(buf.data(), 1, buf.size(), f) == buf.size() && fgetc(f) == EOF; // exactly the payload: nothing missing, nothing appended
+        ok = ok && payloadChecksum(buf.data(), buf.size()) == h.payloadSum;
+        ok = ok && cachedTreeIsSane(h, buf.data(), reinterpret_cast<const uint32_t *>(buf.data() + nb + bb));
         if (ok) {
             ok = hipMalloc(&br.nodes, nb) == hipSuccess && hipMalloc(&br.nodeBox, bb) == hipSuccess && hipMalloc(&br.slotOfPrim, sb) == hipSuccess &&
                  hipMalloc(&br.tris, sizeof(Tri) * (size_t)h.triSlots) == hipSuccess;
@@ -912,6 +971,7 @@ static void saveTree(hr_ctx *c, unsigned long long key, uint32_t nTris, const Bu
     h.version = kCacheVersion, h.nodeBytes = sizeof(Node4), h.key = key, h.nTris = nTris, h.nNodes = (uint32_t)br.nNodes, h.levels = (uint32_t)br.levels;
     h.rootLeafCount = (uint32_t)br.rootLeafCount, h.triSlots = br.triSlots;
     std::memcpy(h.levelStart, br.levelStart, sizeof(h.levelStart));
+    h.payloadSum = payloadChecksum(buf.data(), buf.size());
     const std::string tmp = c->cachePath + ".tmp";
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;

@@ -448,9 +448,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 const uint32_t nGive = (uint32_t)__popcll(giveMask);
                 const uint32_t nMove = nGive < (uint32_t)nIdle ? nGive : (uint32_t)nIdle;
                 const uint32_t giveRank = (uint32_t)__popcll(giveMask & ltMask), idleRank = (uint32_t)__popcll(idleMask & ltMask);
+                // (LDS hand-offs between lanes of ONE wave: the hardware executes a wave's LDS instructions in order, and the wave barriers
+                // keep the compiler from moving or caching the plain accesses across them)
                 if (canGive && giveRank < nMove) mDonor[wave][giveRank] = lane;
+                __builtin_amdgcn_wave_barrier();
                 const bool takes = idle && idleRank < nMove;
-                const uint32_t src = takes ? mDonor[wave][idleRank] : lane;
+                const uint32_t src = takes ? ((volatile uint32_t *)mDonor[wave])[idleRank] : lane;
                 // the ray travels by cross-lane reads (every lane executes them), the subtree through the donor's stack column
                 const float sox = __shfl(o.x, (int)src), soy = __shfl(o.y, (int)src), soz = __shfl(o.z, (int)src);
                 const float sdx = __shfl(d.x, (int)src), sdy = __shfl(d.y, (int)src), sdz = __shfl(d.z, (int)src);
@@ -458,7 +461,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 const uint32_t sSkip = (uint32_t)__shfl((int)skipPrim, (int)src), sItem = (uint32_t)__shfl((int)item, (int)src);
                 const uint32_t sLocal = (uint32_t)__shfl((int)local, (int)src), sSlot = (uint32_t)__shfl((int)slot, (int)src);
                 const int sSeg = __shfl(segIdx, (int)src);
-                const int given = stack[wave][0][src]; // the donor's OLDEST entry: the farthest subtree, usually the largest
+                const int given = ((volatile int *)stack[wave][0])[src]; // the donor's OLDEST entry: the farthest subtree, usually the largest
+                __builtin_amdgcn_wave_barrier(); // (read by the taker before the donor compacts its stack)
                 if (canGive && giveRank < nMove) {
                     sp -= 1;
                     if (sp > 0) stackLane[0] = stackLane[sp * 64];
@@ -576,7 +580,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                             const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)prim << 1) |
                                                           (unsigned long long)(det > 0.0f ? 1u : 0u);
                             atomicMin(&mKey[wave][slot], kk);
-                            if (mKey[wave][slot] == kk) mUV[wave][slot] = make_float2(u, v);
+                            __builtin_amdgcn_wave_barrier();
+                            if (((volatile unsigned long long *)mKey[wave])[slot] == kk) mUV[wave][slot] = make_float2(u, v);
                         }
 #endif
                     }
@@ -594,10 +599,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                               : (((unsigned long long)__float_as_uint(best.t) << 32) | ((unsigned long long)(best.prim & 0x7FFFFFFFu) << 1) |
                                  (unsigned long long)(best.prim >> 31)));
             if (hit) atomicMin(&mKey[wave][slot], myKey);
-            if (hit && !isAny && mKey[wave][slot] == myKey) mUV[wave][slot] = make_float2(best.u, best.v);
+            __builtin_amdgcn_wave_barrier();
+            if (hit && !isAny && ((volatile unsigned long long *)mKey[wave])[slot] == myKey) mUV[wave][slot] = make_float2(best.u, best.v);
+            __builtin_amdgcn_wave_barrier();
             const uint32_t before = atomicSub(&mCount[wave][slot], 1u);
             if (before == 1u) {
-                const unsigned long long k = mKey[wave][slot];
+                const unsigned long long k = ((volatile unsigned long long *)mKey[wave])[slot];
                 const SegDev &sg = tbl->seg[segIdx >> 1];
                 if (isAny) {
                     if (k == kNoHitKey) {
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     h.prim = kMissPrim, h.t = tmax, h.u = 0.0f, h.v = 0.0f;
                     if (k != kNoHitKey) {
                         const uint32_t lo = (uint32_t)k;
-                        const float2 uv = mUV[wave][slot];
+                        const float2 uv = make_float2(((volatile float *)&mUV[wave][slot])[0], ((volatile float *)&mUV[wave][slot])[1]);
                         h.prim = (lo >> 1) | (lo << 31), h.t = __uint_as_float((uint32_t)(k >> 32)), h.u = uv.x, h.v = uv.y;
                     }
                     G(sg.hits)[local] = h;

@@ -1051,6 +1051,88 @@ def test_tree_cache_round_trip(tmp_path):
     assert c3.debug_trace(org, d).tobytes() == o2.debug_trace(org, d).tobytes()
 
 
+def test_tree_cache_rejects_damaged_files_and_keys_are_stable(tmp_path):
+    # (1) the key covers the scene, not the file — a full-length file with flipped bits, or one written by something else
+    # with out-of-range child / slot indices and a *matching* checksum, must be rejected (a rebuild), never uploaded; (2) the key must
+    # not depend on the unwritten alignment padding of the mesh blocks (vertex counts that are not multiples of four, odd index
+    # counts, after allocator churn).
+    import struct
+    sc = scenes.triangle_soup(6001, width=32, height=32, n_materials=3)     # 6003 vertices in the first mesh: 12 * nVerts is not a multiple of 16
+    assert sc.meshes[0].positions.shape[0] % 4 != 0
+    rng = np.random.default_rng(9)
+    org = rng.uniform(-1.2, 1.2, (4000, 3)).astype(np.float32)
+    d = rng.normal(size=(4000, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o = oracle_lib.engine()
+    sc.apply(o)
+    want = o.debug_trace(org, d).tobytes()
+    path = tmp_path / "scene.hrbvh"
+
+    def fresh(expect_cached):
+        e = core.create_engine()
+        e.set_scene_cache(path)
+        sc.apply(e)
+        assert (e.scene_info().refitted == 2) == expect_cached, e.scene_info().refitted
+        assert e.debug_trace(org, d).tobytes() == want
+        e.close()
+
+    fresh(False)                      # builds, writes the file
+    good = path.read_bytes()
+    # churn the allocator: contexts with other scenes come and go, so the next blocks land on recycled memory
+    for k in range(3):
+        t = core.create_engine()
+        scenes.triangle_soup(5000 + 777 * k, width=16, height=16, seed=scenes.SEED + 5 + k).apply(t)
+        t.close()
+    fresh(True)                       # same scene, recycled memory: the key still matches
+    assert path.read_bytes() == good  # (a hit does not rewrite the file)
+    header = 8 + 4 + 4 + 8 + 6 * 4 + 65 * 4
+    header += (-header) % 8           # the 64-bit checksum is 8-byte aligned
+    sum_off = header
+    payload_off = header + 8
+    (stored,) = struct.unpack_from("<Q", good, sum_off)
+    assert stored != 0
+    # (a) one flipped bit in the node array, same length: checksum mismatch
+    bad = bytearray(good)
+    bad[payload_off + 64 * 5 + 40] ^= 0x10
+    path.write_bytes(bytes(bad))
+    fresh(False)
+    # the rebuild wrote the file again: same scene key, same size (node order may differ from build to build, hits never do)
+    again = path.read_bytes()
+    assert again[:24] == good[:24] and len(again) == len(good) and again != bytes(bad)
+    good = again
+    (stored,) = struct.unpack_from("<Q", good, sum_off)
+    # (b) bytes appended
+    path.write_bytes(good + b"\0" * 64)
+    fresh(False)
+    # (c) a hostile file: child base of node 0 far out of range AND the checksum recomputed to match
+    lib = core.load_library()
+    bad = bytearray(good)
+    struct.pack_into("<I", bad, payload_off + 32 + 8, 0x0FFFFFF0)        # Node4::c.z (innerBase) of node 0
+    import ctypes as C
+    def checksum(b):
+        h = 0x9E3779B97F4A7C15
+        M = (1 << 64) - 1
+        n = len(b)
+        i = 0
+        while i + 8 <= n:
+            (w,) = struct.unpack_from("<Q", b, i)
+            h = ((h ^ w) * 0xFF51AFD7ED558CCD) & M
+            h ^= h >> 29
+            i += 8
+        tail = int.from_bytes(b[i:], "little") if i < n else 0
+        h = ((h ^ tail ^ n) * 0xC4CEB9FE1A85EC53) & M
+        return h ^ (h >> 32)
+    struct.pack_into("<Q", bad, sum_off, checksum(bytes(bad[payload_off:])))
+    path.write_bytes(bytes(bad))
+    fresh(False)                      # range check, not the checksum, stops this one
+    # (d) the same with a slot of the prim -> slot map out of range
+    bad = bytearray(good)
+    struct.pack_into("<I", bad, len(bad) - 4, 0x7FFFFFFF)
+    struct.pack_into("<Q", bad, sum_off, checksum(bytes(bad[payload_off:])))
+    path.write_bytes(bytes(bad))
+    fresh(False)
+
+
 def test_strided_and_interleaved_vertex_buffers(golden):
     # rlVertexAttribBuffer takes a byte stride (Mesh.cpp:104-132): attributes interleaved in one buffer, and padded planar
     # buffers, reach the device as they are and are read with their stride

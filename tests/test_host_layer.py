@@ -63,6 +63,16 @@ def test_reference_texture_loader_compiles_unchanged_against_the_layer(tmp_path)
            "-I" + os.path.join(ROOT, "include"), "-I/root/reference/3rdParty", str(ov / "Utility" / "TextureLoader.cpp")]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ov)
     assert out.returncode == 0, out.stderr[-3000:]
+    # ... and in that tree the layer's MultiScatterUtil reads the reference's own input, Resources/multiscatter_lut.tiff, through that
+    # kept loader (MultiScatterUtil.cpp:141-150 of the reference); device integration is only the fallback
+    obj = tmp_path / "msu.o"
+    cmd = ["g++", "-std=c++20", "-c", "-o", str(obj), "-include", os.path.join(ROOT, "oracle", "ref", "compat_std_math.h"), "-I" + str(ov),
+           "-I" + os.path.join(ROOT, "include"), "-I/root/reference/3rdParty", "-I" + os.path.join(HOST, "standalone", "HeatrayRenderer", "Scene"),
+           str(ov / "HeatrayRenderer" / "Materials" / "MultiScatterUtil.cpp")]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ov)
+    assert out.returncode == 0, out.stderr[-3000:]
+    syms = subprocess.run(["nm", "-C", str(obj)], capture_output=True, text=True).stdout
+    assert "U util::loadTexture" in syms and "hr_multiscatter_lut_generate" in syms, syms[-2000:]
 
 
 def test_polygon_aperture_is_uniform_on_the_polygon():
