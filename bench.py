@@ -52,6 +52,8 @@ WORKLOADS = {
     "c2p": dict(desc="c2 with 30% single-sided / alpha-masked (pass-through) materials, as glTF assets have them"),
     "c3": dict(desc="synthetic soup 1M tris + 2048x1024 HDRI + NEE, 1920x1080, 8 bounces"),
     "c5": dict(desc="soup 1M tris, 25% glass, 25% clearcoat, f/2.8 pentagon-bokeh DoF, 3840x2160, 16 bounces"),
+    # SURVEY 8d's coherent counterpart of the soup: an indexed, shared-vertex grid mesh
+    "terrain": dict(desc="indexed terrain grid mesh 1000x500 quads (1M tris, shared vertices) + 2048x1024 HDRI + NEE, 1920x1080, 8 bounces"),
 }
 
 
@@ -64,6 +66,8 @@ def build_scene(name, width, height, passes):
         return scenes.triangle_soup(50_000, width or 1920, height or 1080, bounces=8, passes=passes, env=False, passthrough_fraction=0.3)
     if name == "c3":
         return scenes.triangle_soup(1_000_000, width or 1920, height or 1080, bounces=8, passes=passes, env=True)
+    if name == "terrain":
+        return scenes.terrain(1000, 500, width or 1920, height or 1080, bounces=8, passes=passes, env=True)
     if name == "c5":
         sc = scenes.triangle_soup(1_000_000, width or 3840, height or 2160, bounces=16, passes=passes, env=True,
                                   glass_fraction=0.25, clearcoat_fraction=0.25)
@@ -144,9 +148,13 @@ def pmc_legs(args, keep_dir=None):
         return None
     out_root = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="hr_pmc_", dir="/tmp")
     os.makedirs(out_root, exist_ok=True)
+    # The children run the SAME configuration as the timed region — wake-up, W warm-up steps, K counted steps — and only the dispatches
+    # of their timed region are summed (the last `launches` k_trace dispatches and everything launched from the first of them on):
+    # busy fractions and bytes per ray then describe a warm device at the step count the line is quoted on, not a cold process's
+    # first milliseconds (on a fresh box those run up to a fifth slower).
     child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.join(ROOT, "bench.py"),
-             "--pmc-child", "--workload", args.workload, "--steps", str(args.steps), "--warmup", "0", "--cpu-seconds", "0", "--no-stats-pass",
-             "--no-wakeup", "--no-pmc", "--no-converge", "--estimator", args.estimator, "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
+             "--pmc-child", "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--no-stats-pass",
+             "--no-pmc", "--no-converge", "--estimator", args.estimator, "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
     env = dict(os.environ, TMPDIR="/tmp")
     res = {"kernels": {}, "passes": {}, "dir": out_root if keep_dir else None}
     t0 = time.perf_counter()
@@ -155,7 +163,7 @@ def pmc_legs(args, keep_dir=None):
         shutil.rmtree(d, ignore_errors=True)
         cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "-d", d, "-o", name, "--output-format", "csv", "--", *child]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=200)
         except (OSError, subprocess.TimeoutExpired) as e:
             res["passes"][name] = {"error": str(e)[:200]}
             continue
@@ -164,15 +172,25 @@ def pmc_legs(args, keep_dir=None):
             res["passes"][name] = {"error": f"rc {r.returncode}: " + r.stderr.decode(errors="replace")[-300:]}
             continue
         cj = json.loads(line[-1])
-        res["passes"][name] = {"rays": cj["extra"]["rays"], "steps": cj["steps"], "counters": ctrs}
+        n_trace = int(cj["extra"]["kernel_launches_rank0"]["trace"])
+        rows = []
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
-                    k = _short_kernel(row["Kernel_Name"])
-                    kk = res["kernels"].setdefault(k, {})
-                    kk[row["Counter_Name"]] = kk.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                    disp = kk.setdefault("_dispatches_" + row["Counter_Name"], set())
-                    disp.add(row["Dispatch_Id"])
+                    rows.append((int(row["Dispatch_Id"]), _short_kernel(row["Kernel_Name"]), row["Counter_Name"], float(row["Counter_Value"])))
+        trace_ids = sorted({r_[0] for r_ in rows if r_[1] == "k_trace"})
+        first = trace_ids[-n_trace] if 0 < n_trace <= len(trace_ids) else (trace_ids[0] if trace_ids else 0)
+        # the timed region starts with the ray generation of its first macro step, launched right before that k_trace
+        gens = [r_[0] for r_ in rows if r_[1] == "k_raygen" and r_[0] < first and r_[0] > (trace_ids[-n_trace - 1] if n_trace < len(trace_ids) else -1)]
+        start = min(gens) if gens else first
+        res["passes"][name] = {"rays": cj["extra"]["rays"], "steps": cj["steps"], "warmup": cj["warmup"], "counters": ctrs, "k_trace_launches_counted": n_trace,
+                               "dispatches_in_process": len({r_[0] for r_ in rows}), "dispatches_counted": len({r_[0] for r_ in rows if r_[0] >= start})}
+        for disp_id, k, ctr, val in rows:
+            if disp_id < start:
+                continue
+            kk = res["kernels"].setdefault(k, {})
+            kk[ctr] = kk.get(ctr, 0.0) + val
+            kk.setdefault("_dispatches_" + ctr, set()).add(disp_id)
         if not keep_dir:
             shutil.rmtree(d, ignore_errors=True)
     for k in res["kernels"].values():
@@ -185,7 +203,7 @@ def pmc_legs(args, keep_dir=None):
     return res if ok else {"failed": True, **res}
 
 
-def convergence_leg(core, sc, dev, stream, cap, n_runs):
+def convergence_leg(core, sc, dev, stream, cap, n_runs, budget_s=None):
     """BASELINE metric 2 (heatray_amd/convergence.py): err(n) is read off the accumulation buffer after every render_pass
     WITHOUT draining the pipeline — the buffer always holds complete passes, in order, and its alpha says how many."""
     import torch
@@ -207,6 +225,8 @@ def convergence_leg(core, sc, dev, stream, cap, n_runs):
     results, curves, t0 = [], [], time.perf_counter()
     chunk = 64
     for run in range(n_runs):
+        if budget_s is not None and run >= 3 and time.perf_counter() - t0 + t_ref > budget_s:
+            break  # (out of time: the statistic is then over the runs made, and the line says how many)
         eng.set_seq_offsets(cv.offsets_table(eng, run, sc.width, sc.height))
         eng.clear()
         torch.cuda.synchronize()
@@ -236,6 +256,7 @@ def convergence_leg(core, sc, dev, stream, cap, n_runs):
     med = {str(n): float(np.median([c[n] for c in curves if n in c])) for n in ns}
     converged = [r for r in results if r is not None]
     return {"p50": cv.p50(results, cap) if len(converged) * 2 > len(results) else None, "threshold_rel_l2": cv.THRESHOLD, "runs": results, "cap": cap,
+            "runs_made": len(results), "runs_asked": n_runs,
             "median_err_at_pass": med,
             "reference_passes": cv.REFERENCE_PASSES, "reference_render_s": t_ref, "runs_s": t_runs,
             "note": "p50 is null when fewer than half of the runs reached the threshold within the cap", "definition": "min n with ||I_n - I_ref|| / ||I_ref|| <= 0.02 on RGB/A; 16 runs = Sobol sequence index 0..15 of the "
@@ -253,8 +274,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--shard-of", type=int, default=0, help="tuning aid, single process: render only rank 0's tiles of a W-way "
                     "sharded frame (no collective); the JSON line is marked emulated and is not a benchmark result")
-    ap.add_argument("--converge", action="store_true", help="passes-to-converge p50 (BASELINE metric 2) over all 16 runs (default: 3 of them): an "
-                    "8192-pass reference render + the runs; N = 1 only")
+    ap.add_argument("--converge", action="store_true", help="passes-to-converge p50 (BASELINE metric 2): no time budget for the leg (all --converge-runs "
+                    "runs whatever they take); N = 1 only")
+    ap.add_argument("--converge-budget", type=float, default=200.0, help="wall-time budget in seconds of the convergence leg of the default run (reference "
+                    "render + runs; the leg stops early after >= 3 runs when it is used up and reports the number of runs made)")
     ap.add_argument("--estimator", default="reference", choices=["reference", "env_mis", "all_lights"], help="estimator of the timed region and of the convergence "
                     "leg: the reference's (BASELINE metric), or importance-sampled environment + one-sample MIS (include/hrcore.h)")
     ap.add_argument("--no-converge", action="store_true", help="skip the live passes-to-converge leg (the committed measurement is quoted, marked as such)")
@@ -475,8 +498,8 @@ def main():
                     per_ray = kt_c["FETCH_SIZE"] * 1024.0 / rays_f + kt_c["WRITE_SIZE"] * 1024.0 / rays_w + 0.5 * 48.0
                     per_ray_all = (sum(k.get("FETCH_SIZE", 0.0) for k in pmc["kernels"].values()) * 1024.0 / rays_f +
                                    sum(k.get("WRITE_SIZE", 0.0) for k in pmc["kernels"].values()) * 1024.0 / rays_w)
-                    src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, three child passes of this command ({args.steps} steps, "
-                           f"warm-up 0) run before the timed region, {pmc['seconds']:.0f} s")
+                    src = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, child passes of this command (wake-up, {args.warmup} warm-up steps, "
+                           f"{args.steps} counted steps: only the dispatches of the child's timed region are summed), {pmc['seconds']:.0f} s")
                 sq = pmc["passes"].get("sq", {})
                 if "rays" in sq and "SQ_INSTS_VALU" in kt_c:
                     valu_per_ray = {"k_trace": kt_c["SQ_INSTS_VALU"] / sq["rays"],
@@ -531,7 +554,8 @@ def main():
                             "valu_busy": ku.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_cus * 4.0) / cyc,
                             "ta_wave_loads_per_ray": ku.get("TA_FLAT_READ_WAVEFRONTS_sum", 0.0) / pmc["passes"]["units"]["rays"],
                             "definition": "busy cycles of the CU's texture addresser (TA_TA_BUSY_sum / CUs) and of the VALUs (SQ_ACTIVE_INST_VALU x 4 / SIMDs) "
-                                          "over the cycles k_trace ran (GRBM_GUI_ACTIVE / 8 XCDs), summed over every launch of a counter pass of this command: "
+                                          "over the cycles k_trace ran (GRBM_GUI_ACTIVE / 8 XCDs), summed over the k_trace launches of the TIMED region of a counter pass "
+                                          "that runs this command's own configuration (wake-up, warm-up, same step count: a warm device): "
                                           "the two units that bind the kernel (scattered 16-B-per-lane loads cost one TA cycle per lane and instruction, "
                                           "tools/calib_tcp.hip)"}
             vt = cpu
@@ -574,26 +598,28 @@ def main():
             if world == 1:
                 assert int(shown.view(torch.uint8).reshape(sc.height, sc.width, 4)[..., 3].min().item()) == 255
 
-        # BASELINE metric 2, measured live: the full leg (--converge: 16 runs) takes ~2.5 min on c3, the default run does 3 of the 16
-        # runs (the runs differ by a few passes in 2900: profiles/r1h_converge_c3.json) so that the line's number is this run's own
+        # BASELINE metric 2, measured live, as defined: p50 over ALL 16 runs (Sobol sequence index 0..15 of the SequenceOffsets table),
+        # each against the one 8192-pass reference image of its estimator (~2 min for the reference's estimator on c3, ~1.2 min for
+        # HR_ESTIMATOR_ALL_LIGHTS).  --converge-budget bounds the leg's wall time: past it (and after at least 3 runs) the leg stops
+        # and the line says over how many runs the statistic is.
         conv = None
         if world == 1 and not emulated and not args.no_converge and not args.pmc_child:
-            n_runs = args.converge_runs if args.converge else min(3, args.converge_runs)
-            conv = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
+            n_runs = args.converge_runs
+            conv = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs, budget_s=None if args.converge else args.converge_budget)
             conv["measured_live"] = True
-            conv["runs_of_16"] = n_runs
+            conv["runs_of_16"] = conv["runs_made"]
             conv["estimator"] = args.estimator
             if args.estimator == "reference":
-                keys = ("p50", "runs", "median_err_at_pass", "reference_render_s", "runs_s")
+                keys = ("p50", "runs", "runs_made", "median_err_at_pass", "reference_render_s", "runs_s")
                 if args.converge_mis:
                     # the same leg with the importance-sampled environment + MIS estimator (its own 8192-pass reference image)
                     sc.options.estimator = ffi.HR_ESTIMATOR_ENV_MIS
-                    conv_mis = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
+                    conv_mis = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs, budget_s=None if args.converge else args.converge_budget)
                     conv["env_mis"] = {k: conv_mis[k] for k in keys}
                 # ... and, in every run, with the opt-in estimator that samples an analytic light AND the environment at every vertex
                 # (HR_ESTIMATOR_ALL_LIGHTS: the product's answer to metric 2; the reference-faithful estimator stays the default)
                 sc.options.estimator = ffi.HR_ESTIMATOR_ALL_LIGHTS
-                conv_all = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs)
+                conv_all = convergence_leg(core, sc, dev, stream, args.converge_cap, n_runs, budget_s=None if args.converge else 0.6 * args.converge_budget)
                 sc.options.estimator = ffi.HR_ESTIMATOR_REFERENCE
                 conv["all_lights"] = {k: conv_all[k] for k in keys}
         else:
@@ -605,7 +631,7 @@ def main():
 
         mrays = total_rays / elapsed / 1e6
         out = {
-            "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3") else f"Mrays/s ({args.workload})",
+            "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3", "terrain") else f"Mrays/s ({args.workload})",
             "value": mrays, "unit": "Mrays/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
             # untimed device wake-up BEFORE the W warm-up steps (clock ramp / first touch of the pass slots on a freshly started box)
             "wakeup_passes": n_wake, "wakeup_s": wake_s,
