@@ -166,7 +166,7 @@ __global__ void k_scene_consts(const uint32_t *__restrict__ bounds, SceneConsts 
     c.diag = sqrt_(ex * ex + ey * ey + ez * ez);
     c.pad = 1e-5f * c.diag;
     c.eps = 1e-4f * c.diag;
-    c.areaSum = 0.0f, c.pad0 = c.pad1 = c.pad2 = 0u;
+    c.areaSum = 0.0f, c.triAreaSum = 0.0f, c.pad1 = c.pad2 = 0u;
     // frame grid of the 32-byte nodes: every (padded) node box starts at or above gridLo; 2^14 power-of-two cells cover the scene
     for (int k = 0; k < 3; ++k) {
         c.gridLo[k] = c.lo[k] - 2.0f * c.pad;
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
 }
 
 // sum over the workgroup, then ONE float atomic (heuristic only: the order of the additions does not matter)
-HRD void blockAreaAdd(float area, SceneConsts *consts)
+HRD void blockAreaAdd(float area, SceneConsts *consts, bool toTriangles = false)
 {
     __shared__ float part[4];
 #pragma unroll
@@ -631,7 +631,7 @@ HRD void blockAreaAdd(float area, SceneConsts *consts)
     __syncthreads();
     if (threadIdx.x == 0) {
         const float t = (part[0] + part[1]) + (part[2] + part[3]);
-        if (t > 0.0f) atomicAdd(&consts->areaSum, t);
+        if (t > 0.0f) atomicAdd(toTriangles ? &consts->triAreaSum : &consts->areaSum, t);
     }
 }
 
@@ -716,6 +716,25 @@ __global__ __launch_bounds__(256) void k_area_sum(const Box6 *__restrict__ nodeB
 void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts)
 {
     if (n) hipLaunchKernelGGL(k_area_sum, dim3((n + 255) / 256), dim3(256), 0, st, nodeBox, n, consts);
+}
+// sum of the triangles' own areas, 0.5 |e1 x e2| (leaf-order array; unused slots of the 32-byte node formats carry prim id ~0)
+__global__ __launch_bounds__(256) void k_tri_area_sum(const Tri *__restrict__ leafTris, uint32_t n, SceneConsts *__restrict__ consts)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float area = 0.0f;
+    if (i < n) {
+        const float4 p = leafTris[i].p, q = leafTris[i].q, r = leafTris[i].r;
+        if (__float_as_uint(r.y) != 0xFFFFFFFFu) {
+            const v3 e1(p.w, q.x, q.y), e2(q.z, q.w, r.x);
+            const float a = 0.5f * length(cross(e1, e2));
+            area = (a == a && a < 3.0e38f) ? a : 0.0f;
+        }
+    }
+    blockAreaAdd(area, consts, true);
+}
+void launchTriAreaSum(hipStream_t st, const Tri *leafTris, uint32_t nSlots, SceneConsts *consts)
+{
+    if (nSlots) hipLaunchKernelGGL(k_tri_area_sum, dim3((nSlots + 255) / 256), dim3(256), 0, st, leafTris, nSlots, consts);
 }
 
 int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, const SceneConsts *dConsts,

@@ -119,7 +119,8 @@ struct SceneConsts {
     float lo[3], hi[3];
     float diag, pad, eps;
     float areaSum; // sum of the node boxes' surface areas after the last build / refit (tree-quality heuristic only)
-    uint32_t pad0, pad1;
+    float triAreaSum; // sum of the triangles' areas (invariant under rigid motion, scales with the scene: what areaSum is compared with)
+    uint32_t pad1;
     float gridLo[3], gridCell[3]; // frame grid of the 32-byte nodes (hr_types.h)
     int32_t gridExpM7[3];
     uint32_t pad2;
@@ -154,6 +155,7 @@ void launchTexLodScale(hipStream_t st, TexDesc *table, int n);
 void launchTexDensity(hipStream_t st, const Tri *leafTris, uint32_t nSlots, const TriAttr *attrs, float *out);
 void launchHashWords(hipStream_t st, const void *words, size_t nWords, unsigned long long seed, unsigned long long *out);
 void launchAreaSum(hipStream_t st, const Box6 *nodeBox, uint32_t n, SceneConsts *consts);
+void launchTriAreaSum(hipStream_t st, const Tri *leafTris, uint32_t nSlots, SceneConsts *consts);
 
 // environment importance table (HR_ESTIMATOR_ENV_MIS): scratch and outputs are caller-owned device arrays
 void launchEnvGuides(hipStream_t st, const float *rowCdf, const float *colCdf, int w, int h, uint16_t *rowGuide, uint16_t *colGuide);

@@ -499,6 +499,28 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #endif
 
         const bool isAny = (segIdx & 1) != 0;
+#if HR_ANY_UNORDERED
+        // A wave works through consecutive items of the launch's index space, so its rays are nearly always all of one kind; when every
+        // ray it holds is an occlusion ray, the node steps of this round are the unordered ones (hr_trace.h::nodeStep4Any)
+        const bool allAny = __ballot(item != 0xFFFFFFFFu && !isAny) == 0ull;
+        if (allAny) {
+#pragma unroll
+            for (int rep = 0; rep < HR_NODE_STEPS; ++rep) {
+                if (cur >= 0 && cur != kSentinel) {
+                    if (STATS) ++nvA;
+#ifdef HR_TAILPROF
+                    ++mySteps;
+#endif
+                    const RayK rk{idx, idy, idz, oix, oiy, oiz};
+                    nodeStep4Any(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
+                }
+                if (cur < 0 && pend == 0) {
+                    pend = cur;
+                    HR_POP();
+                }
+            }
+        } else
+#endif
         // ---------------- inner-node steps for every lane that holds an inner node
 #pragma unroll
         for (int rep = 0; rep < HR_NODE_STEPS; ++rep) {

@@ -275,6 +275,72 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
 
 #endif
 
+#ifndef HR_ANY_UNORDERED
+#define HR_ANY_UNORDERED 0 // EXPERIMENT, measured and NOT the default: see below
+#endif
+#if !HR_NODE32
+// One step at the 4-wide node `cur` for an OCCLUSION ray: whether something occludes it does not depend on the order the children
+// are visited in, so the four entry distances need not be packed into keys and sorted; the hit child with the lowest slot is
+// continued with, the others are pushed in slot order.  Parity-green (the whole GPU suite) and SLOWER: k_trace 9.85 against 9.42 ms
+// per launch (c3, 128 steps: 1707 vs 1769 Mrays/s) with 227.9 instead of 225.8 VALU wave-instructions per ray
+// (profiles/r3k_anyhit_unordered_ab.txt): what the sorting network costs is less than the second copy of the six-times unrolled
+// step loop, the vote that selects it and the boolean bookkeeping cost in registers and instructions; front-to-back order also lets
+// an occluded ray find its occluder 0.6 % of a visit earlier on average.  Kept buildable (-DHR_ANY_UNORDERED=1) for the record.
+HRD void nodeStep4Any(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim)
+{
+    const Node4 &n = nodes[cur];
+    const float4 a = n.a;
+    const uint4 qb = n.b, qc = n.c;
+    const uint32_t meta = __float_as_uint(a.w);
+    const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
+    const int innerBase = (int)qc.z, leafKey = (int)qc.w;
+    const float bx = __uint_as_float((meta & 0xFFu) << 23) * rk.idx;
+    const float by = __uint_as_float(((meta >> 8) & 0xFFu) << 23) * rk.idy;
+    const float bz = __uint_as_float(((meta >> 16) & 0xFFu) << 23) * rk.idz;
+    const float ax = __builtin_fmaf(a.x, rk.idx, -rk.oix), ay = __builtin_fmaf(a.y, rk.idy, -rk.oiy), az = __builtin_fmaf(a.z, rk.idz, -rk.oiz);
+    const uint32_t nX = rk.idx < 0.0f ? qb.w : qb.x, fX = rk.idx < 0.0f ? qb.x : qb.w;
+    const uint32_t nY = rk.idy < 0.0f ? qc.x : qb.y, fY = rk.idy < 0.0f ? qb.y : qc.x;
+    const uint32_t nZ = rk.idz < 0.0f ? qc.y : qb.z, fZ = rk.idz < 0.0f ? qb.z : qc.y;
+    bool hit[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float tnx = __builtin_fmaf((float)byteOf(nX, c), bx, ax), tfx = __builtin_fmaf((float)byteOf(fX, c), bx, ax);
+        const float tny = __builtin_fmaf((float)byteOf(nY, c), by, ay), tfy = __builtin_fmaf((float)byteOf(fY, c), by, ay);
+        const float tnz = __builtin_fmaf((float)byteOf(nZ, c), bz, az), tfz = __builtin_fmaf((float)byteOf(fZ, c), bz, az);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
+        hit[c] = tn <= tf && (uint32_t)c < nValid;
+    }
+    const int r0 = (0u < nInner ? innerBase : leafKey), r1 = (1u < nInner ? innerBase : leafKey) + 1, r2 = (2u < nInner ? innerBase : leafKey) + 2,
+              r3 = (3u < nInner ? innerBase : leafKey) + 3;
+    // the lowest hit slot continues; a higher hit slot is pushed when a lower one was hit too
+    const bool push3 = hit[3] && (hit[0] || hit[1] || hit[2]), push2 = hit[2] && (hit[0] || hit[1]), push1 = hit[1] && hit[0];
+    const bool any = hit[0] || hit[1] || hit[2] || hit[3];
+    const int next = hit[0] ? r0 : (hit[1] ? r1 : (hit[2] ? r2 : r3));
+    if (sp <= kStackLDS - 3) {
+        stackLane[sp * 64] = r3;
+        sp += push3 ? 1 : 0;
+        stackLane[sp * 64] = r2;
+        sp += push2 ? 1 : 0;
+        stackLane[sp * 64] = r1;
+        sp += push1 ? 1 : 0;
+        const bool empty = !any && sp == 0;
+        sp -= (!any && sp > 0) ? 1 : 0;
+        const int popped = stackLane[(sp < kStackLDS - 1 ? sp : kStackLDS - 1) * 64];
+        cur = any ? next : (empty ? kSentinel : popped);
+    } else {
+        if (push3) HR_PUSH(r3);
+        if (push2) HR_PUSH(r2);
+        if (push1) HR_PUSH(r1);
+        if (any) {
+            cur = next;
+        } else {
+            HR_POP();
+        }
+    }
+}
+#endif
+
 // Per-ray constants of the slab test: 1 / d and the ray origin over d (relative to the frame grid's origin for 32-byte nodes)
 HRD RayK rayFrame(const SceneDev &S, v3 o, float idx, float idy, float idz)
 {

@@ -426,3 +426,29 @@ def stacked_sheets(n_sheets=120, width=64, height=36, bounces=3, passes=8, alpha
     o.focus_distance = 4.0
     o.fstop = host.FSTOP_DISABLED
     return sc
+
+
+def instanced(n_side=4, slices=180, width=1920, height=1080, bounces=8, passes=32, spacing=1.0, radius=0.4):
+    """n_side^2 rigid, non-overlapping objects (lat/long spheres with a ripple, one submesh and one material each) on a grid over a
+    ground quad: the per-primitive transform model of OpenRL (rl.h:301-303, Scene.cpp:38-49) — each object has its own
+    worldFromEntity, and an edit moves ONE of them.  4 x 4 x slices=180 is 1.05 M triangles."""
+    rng = SplitMix64(SEED ^ 0x1257)
+    sc = Scene(f"instanced{n_side}x{n_side}", width=width, height=height)
+    sc.materials = _material_palette(rng, n_side * n_side + 1)
+    p, n, uv, idx = uv_sphere(slices, slices, radius)
+    ripple = (1.0 + 0.04 * np.sin(9.0 * p[:, 0:1] / radius) * np.cos(7.0 * p[:, 1:2] / radius)).astype(F)
+    p = (p * ripple).astype(F)
+    half = 0.5 * (n_side - 1) * spacing
+    for k in range(n_side * n_side):
+        gx, gz = k % n_side, k // n_side
+        sc.meshes.append(MeshData(p, n, idx, uvs=uv, world=_translate(gx * spacing - half, radius * 1.1, gz * spacing - half), material_id=k))
+    g = half + spacing
+    gp, gn, gi = _quad((-g, 0, g), (g, 0, g), (g, 0, -g), (-g, 0, -g))
+    sc.meshes.append(MeshData(gp, gn, gi, material_id=n_side * n_side))
+    sc.lights.add_directional(color=(1, 1, 1), illuminance=683.0 * math.pi, phi=math.radians(30.0), theta=math.radians(60.0))
+    sc.env_pixels = synthetic_hdri()
+    o = sc.options
+    o.max_ray_depth, o.max_render_passes = bounces, passes
+    o.fstop = host.FSTOP_DISABLED
+    _camera_for(sc, np.array([-g, 0.0, -g]), np.array([g, 2.2 * radius, g]))
+    return sc

@@ -141,6 +141,10 @@ typedef struct hr_scene_info {
     uint32_t bvh_levels; /* levels of inner nodes of the acceleration structure (0 for the oracle's brute force / a leaf root) */
     uint32_t refitted;   /* 1: the last commit kept the tree's topology and refitted its boxes (transform-only edits);
                           * 2: the tree came from the cache file (hr_scene_cache) */
+    float box_area_ratio; /* quality of a refitted tree: (sum of its node boxes' areas / sum of its triangles' areas) relative to the
+                           * value right after the last full build (1 after a build; a refit whose ratio would exceed 1.25 rebuilds
+                           * instead); 0: unknown */
+    uint32_t reserved;
 } hr_scene_info;
 int hr_scene_get_info(hr_ctx *ctx, hr_scene_info *out);
 
