@@ -373,7 +373,7 @@ def main():
     sc.options.estimator = {"reference": ffi.HR_ESTIMATOR_REFERENCE, "env_mis": ffi.HR_ESTIMATOR_ENV_MIS, "all_lights": ffi.HR_ESTIMATOR_ALL_LIGHTS}[args.estimator]
     stream = torch.cuda.current_stream().cuda_stream
     eng_rank = args.shard_rank if emulated else rank
-    eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, time_kernels=True)
+    eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, time_kernels=os.environ.get("HR_BENCH_TIME_KERNELS", "1") != "0")
     sc.apply(eng)  # tables and LUT are generated on the device
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
@@ -433,7 +433,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = eng.stats()
-    kt = eng.kernel_times()
+    kt = eng.kernel_times() if os.environ.get("HR_BENCH_TIME_KERNELS", "1") != "0" else {k: (0.0, 0) for k in ("raygen", "trace", "shade", "resolve")}
     rays = torch.tensor([float(st.rays_closest + st.rays_any), float(st.paths), float(st.rays_closest)], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if exchange:

@@ -679,9 +679,11 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         // Paths per macro step worth launching for.  A trace launch ends in a tail of a few long rays (0.5-0.7 ms whatever it
         // carries) and every pass costs depth + 2 dependent launches, so passes requested back to back are collected and injected
         // together: 9 passes of a 1080p frame per step measured 1715 against 1607 Mrays/s (128 passes) and 1488 against 1400
-        // (20 passes) for one at a time on two pipeline groups (profiles/r2b_batch_sweep*.txt).  A caller that asks for pixels
-        // after every pass (hr_readback) completes what is pending, so batching never delays a displayed frame.
-        const long long target = 9ll * 1920ll * 1080ll;
+        // (20 passes) for one at a time on two pipeline groups (profiles/r2b_batch_sweep*.txt).  Round 3, with the small launches
+        // dealt out statically and the shading stage split: 11-14 passes per step are another 3-4 % over 9 at 20 passes and 2 % at
+        // 128 (profiles/r3n_batch_sweep.txt); 12 it is (120 pass slots of a 1080p frame: 53 GB of the 288).  A caller that asks for
+        // pixels after every pass (hr_readback) completes what is pending, so batching never delays a displayed frame.
+        const long long target = 12ll * 1920ll * 1080ll;
         const long long own = c->queueCapacity ? c->queueCapacity : 1;
         long long b = (target + own - 1) / own;
         c->injectBatch = (int)(b < 1 ? 1 : (b > HR_BATCH_CAP ? HR_BATCH_CAP : b));
