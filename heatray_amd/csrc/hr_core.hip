@@ -1654,8 +1654,12 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         if (ps.everResolved) HIP_TRY(c, hipStreamWaitEvent(G.stream, ps.evResolved, 0)); // the pass buffer is free again
         ps.active = true, ps.finished = false, ps.group = g, ps.step = 0, ps.nIter = pp.max_ray_depth + 1, ps.pp = pp;
         ps.order = c->injected++;
-        HIP_TRY(c, hipMemsetAsync(ps.ctr, 0, sizeof(Counters), G.stream));
         injectedSlots[nInjected++] = slot;
+    }
+    for (int j0 = 0; j0 < nInjected; j0 += kMaxBatch) { // the injected passes' counters back to zero, one launch
+        CounterList cl{};
+        for (int j = j0; j < nInjected && cl.n < kMaxBatch; ++j) cl.ctr[cl.n++] = c->slots[injectedSlots[j]].ctr;
+        launchZeroCounters(cfg, cl);
     }
     // Pass-through rays (back faces of single-sided materials, alpha masks: physicallyBased.rlsl:70-108) are not bounded by
     // maxRayDepth, so in such scenes a pass runs until its closest-hit queue is empty.  The queue lengths come from the snapshot

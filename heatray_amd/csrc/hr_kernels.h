@@ -82,6 +82,13 @@ struct PassBufList {
     const float *buf[kMaxBatch]; // pass samples, added to the frame in this order
     const float *bufB[kMaxBatch]; // second partial sum of a pass sample (HR_ESTIMATOR_ALL_LIGHTS), or null
 };
+// the per-stage counters of the passes injected by one macro step, cleared with ONE launch (a hipMemsetAsync per pass is a fill kernel
+// and a kernel boundary each: 12 of them delayed a step's ray generation by ~0.1 ms)
+struct CounterList {
+    int32_t n;
+    Counters *ctr[kMaxBatch];
+};
+void launchZeroCounters(const LaunchCfg &cfg, const CounterList &list);
 void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, const SegList &segs, const FrameDev &fr, Stats *stats);
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &bufs);
 void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *frame, float *packed, int unpack, float *full);

@@ -137,6 +137,17 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
     if (laneId() == 0 && n) atomicAdd(&stats->paths, (unsigned long long)n);
 }
 
+// one workgroup per injected pass: its Counters block (a few hundred words) back to zero
+__global__ __launch_bounds__(256) void k_zero_counters(CounterList list)
+{
+    uint32_t *w = reinterpret_cast<uint32_t *>(list.ctr[blockIdx.x]);
+    for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += 256) w[i] = 0u;
+}
+void launchZeroCounters(const LaunchCfg &cfg, const CounterList &list)
+{
+    if (list.n > 0) hipLaunchKernelGGL(k_zero_counters, dim3(list.n), dim3(256), 0, cfg.stream, list);
+}
+
 // ------------------------------------------------------------------------------------------ resolve
 // The finished passes' samples are added one after the other, in pass order (float addition order is part of the contract)
 __global__ __launch_bounds__(kBlock) void k_resolve(FrameDev fr, PassBufList bufs)
