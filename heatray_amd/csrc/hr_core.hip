@@ -117,6 +117,7 @@ struct hr_ctx {
         hipStream_t stream = nullptr;
         StepTable *dTables = nullptr;   // ring of device step tables
         StepTable *hTables = nullptr;   // pinned staging ring
+        unsigned long long *dPool = nullptr; // steal pool of this group's trace launches (all-zero between launches)
         hipEvent_t tableCopied[4] = {nullptr, nullptr, nullptr, nullptr};
         bool tableUsed[4] = {false, false, false, false};
         unsigned long long stepCounter = 0;
@@ -257,7 +258,7 @@ struct hr_ctx {
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
-    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1;
+    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1, tuneSteal = 1;
     LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass, tuneSplitShade == 0}; }
 };
 
@@ -281,6 +282,7 @@ struct hr_ctx {
     HIP_TRY(ctx, hipSetDevice((ctx)->device))
 
 static const int kTableRing = 4;
+static const uint32_t kStealPoolCap = 1u << 20; // entries of a group's steal pool (8 MB)
 static int drainPipeline(hr_ctx *c);
 // finish every enqueued pass and wait for the device: required before anything the in-flight kernels read changes
 static int quiesce(hr_ctx *c)
@@ -342,7 +344,7 @@ static void freeQueues(hr_ctx *c)
 {
     for (hr_ctx::PassSlot &ps : c->slots) {
         for (int i = 0; i < 2; ++i) hipFree(ps.q[i].A), hipFree(ps.q[i].B), hipFree(ps.q[i].C), hipFree(ps.q[i].D);
-        hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C);
+        hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C), hipFree(ps.sq.M);
         hipFree(ps.hits), hipFree(ps.hitIdx), hipFree(ps.passbuf);
         if (ps.evFinal) hipEventDestroy(ps.evFinal);
         if (ps.evResolved) hipEventDestroy(ps.evResolved);
@@ -361,7 +363,7 @@ static void slotBudget(hr_ctx *c)
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
         const size_t k = c->allLightsUsed ? 4 : 1;
-        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 * k + hitRecordSize() + 4) + fbBytes * k + sizeof(Counters);
+        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + (HR_STEAL ? 52 : 48) * k + hitRecordSize() + 4) + fbBytes * k + sizeof(Counters);
         const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
         c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
     }
@@ -430,7 +432,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade), get("guard=", c->tuneGuardPct);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade), get("guard=", c->tuneGuardPct), get("steal=", c->tuneSteal);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -449,6 +451,10 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             groupsOk = groupsOk && hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, c->tunePrio ? greatest : 0) == hipSuccess;
         }
         groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
+#if HR_STEAL
+        groupsOk = groupsOk && hipMalloc(&G.dPool, sizeof(unsigned long long) * kStealPoolCap) == hipSuccess &&
+                   hipMemset(G.dPool, 0, sizeof(unsigned long long) * kStealPoolCap) == hipSuccess;
+#endif
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipEventCreateWithFlags(&G.evUser, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
@@ -502,6 +508,7 @@ int hr_ctx_destroy(hr_ctx *c)
             if (e) hipEventDestroy(e);
         if (G.stream) hipStreamDestroy(G.stream);
         hipFree(G.dTables);
+        hipFree(G.dPool);
         if (G.hTables) hipHostFree(G.hTables);
         if (G.evUser) hipEventDestroy(G.evUser);
         for (hipEvent_t e : G.tableCopied)
@@ -1112,6 +1119,7 @@ int hr_scene_commit(hr_ctx *c)
         c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = ext;
         c->hScene.nTris = (int)nTris, c->hScene.nNodes = c->tree.nNodes, c->hScene.rootLeafCount = c->tree.rootLeafCount;
         c->hScene.rayEps = k.eps; // 1e-4 |diagonal|, SURVEY §8a a6
+        c->hScene.slotOfPrim = c->tree.slotOfPrim;
         for (int q = 0; q < 3; ++q) c->hScene.gridLo[q] = k.gridLo[q], c->hScene.gridCell[q] = k.gridCell[q], c->hScene.gridExpM7[q] = k.gridExpM7[q];
         for (int q = 0; q < 3; ++q) c->info.aabb_min[q] = k.lo[q], c->info.aabb_max[q] = k.hi[q];
         c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)c->tree.nNodes, c->info.ray_epsilon = k.eps;
@@ -1538,6 +1546,9 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
     if (e == hipSuccess) e = hipMalloc(&ps.sq.A, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.sq.B, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.sq.C, s16);
+#if HR_STEAL
+    if (e == hipSuccess) e = hipMalloc(&ps.sq.M, s16 / 4);
+#endif
     if (e == hipSuccess) e = hipMalloc(&ps.hits, cap * hitRecordSize());
     if (e == hipSuccess) e = hipMalloc(&ps.hitIdx, cap * sizeof(uint32_t));
     // (with HR_ESTIMATOR_ALL_LIGHTS the sample's second partial sum lies right behind the first: k_trace indexes one buffer)
@@ -1699,6 +1710,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
     tbl.fetchMax = c->tuneFetchMax > 0 ? c->tuneFetchMax : 1, tbl.fetchMin = c->tuneFetchMin > 0 ? c->tuneFetchMin : 1;
     tbl.staticPerWave = c->tuneStaticDeal, tbl.hasGlass = c->hasGlass ? 1 : 0;
+    tbl.poolTail = tbl.poolHead = tbl.idleSeen = 0, tbl.pool = G.dPool, tbl.pad3 = 0;
+    tbl.poolCap = (HR_STEAL && c->tuneSteal && c->tuneSplitShade) ? kStealPoolCap : 0u; // (the single shading kernel of shade=0 does not know the merge records)
     int injectedSegs[kMaxSegs];
     int nInjectedSegs = 0;
     for (int k = 0; k < n; ++k) {

@@ -54,6 +54,9 @@ struct SegDev {
     int32_t pad;
 };
 
+#ifndef HR_STEAL
+#define HR_STEAL 0 // EXPERIMENT (round 3, measured a loss, hr_render.hip): cross-wave steal pool in k_trace's drain phase
+#endif
 #ifndef HR_MAX_SEGS
 #define HR_MAX_SEGS 320
 #endif
@@ -67,6 +70,13 @@ struct StepTable {
     int32_t fetchMin;      // ... shrinking to this near the end of the pool (guided self-scheduling: short tail)
     int32_t staticPerWave; // launches of at most this many rays per resident wave are dealt out statically (k_trace)
     int32_t hasGlass;      // some material of the scene is glass (else the glass hit list is never appended to)
+    // Steal pool of the launch (k_trace, drain phase): subtrees that busy waves hand to waves that have run out of work.  Entries
+    // [poolHead, poolTail) are claimable; an entry is (work item + 1) << 32 | node reference, 0 while not yet written.
+    uint32_t poolTail, poolHead; // (one aligned 8-byte word: read together)
+    uint32_t idleSeen;     // some wave has run out of work: donations start
+    uint32_t poolCap;      // entries of `pool`; 0: no stealing in this launch
+    unsigned long long *pool;
+    unsigned long long pad3;
     SegDev seg[kMaxSegs];
 };
 

@@ -271,6 +271,13 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
 #define HR_TAIL_ROUNDS 3
 #endif
 static const unsigned long long kNoHitKey = ~0ull;
+// HR_STEAL (hr_kernels.h): drain phase, waves that have run out of work take subtrees of other waves' rays from a global pool.
+// EXPERIMENT of round 3, parity-green on the whole GPU suite and much slower (see the comment at the pool code): off by default.
+static const uint32_t kStealLow = 192;  // busy waves top the pool up while fewer than this many entries wait in it
+static const int kStealGive = 16;       // entries a wave adds per round at most
+static const int kStealTries = 6;       // polls of an empty pool (a few microseconds apart) before a wave gives up and exits
+static const uint32_t kSharedMark = 0xFFFFFFFFu; // u and v words of a hit record that is still in merge (key) format
+static const uint32_t kOccluded = 0x80000000u;   // flag bit of an occlusion ray's merge word (ShadowQueue::M)
 
 #ifdef HR_TAILPROF
 // Experiment builds only: when does the work queue run dry, when does the launch end, how long is the longest ray?
@@ -289,6 +296,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     __shared__ uint32_t mCount[kTraceWaves][64];         // fragments still traversing
     __shared__ float2 mUV[kTraceWaves][64];              // barycentrics that belong to mKey
     __shared__ uint32_t mDonor[kTraceWaves][64];         // k-th donating lane of this round
+#if HR_STEAL
+    __shared__ uint32_t mGlobal[kTraceWaves][64];        // the slot's ray is also traversed by other waves (steal pool): results merge in global memory
+#endif
 #endif
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
@@ -345,6 +355,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #if HR_TAIL_SHARE
     uint32_t slot = lane;  // merge slot of the ray (fragment) this lane holds during the drain phase
     bool draining = false; // wave-uniform: the merge slots are initialised
+#if HR_STEAL
+    bool toldIdle = false; // wave-uniform: this wave has announced that it ran out of work (steal pool)
+#endif
 #endif
 #ifdef HR_TAILPROF
     const unsigned long long tStart = wall_clock64();
@@ -439,6 +452,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 slot = lane;
                 mKey[wave][lane] = kNoHitKey;
                 mCount[wave][lane] = (item != 0xFFFFFFFFu) ? 1u : 0u;
+#if HR_STEAL
+                mGlobal[wave][lane] = 0u;
+#endif
             }
             if (item != 0xFFFFFFFFu) { // what the other fragments of this ray have found so far bounds this one too
                 const unsigned long long k = mKey[wave][slot];
@@ -499,11 +515,156 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 idleMask = __ballot(idle);
             }
             }
+#if HR_STEAL
+            // ---------------- steal pool.  Within a wave the idle lanes take over subtrees (above); across waves nothing did: a wave's
+            // rays still in flight when the queue runs dry are 3600 node steps of work on average and 9900 at worst, so waves finish
+            // spread over the whole drain (0.45 ms of a 1080p launch) and the chip is half empty for that long.  Therefore: once some
+            // wave has run out of work, busy waves keep a small global pool of their oldest stack entries topped up, and a wave with
+            // nothing left takes entries from it instead of exiting.  A ray traversed by several waves merges its result in global
+            // memory: closest-hit rays by an atomic minimum on the 64-bit key (t, triangle, face) kept in the ray's hit record
+            // — k_shade_sort turns it into a hit record and recomputes the barycentrics, the same arithmetic on the same triangle —
+            // occlusion rays by a counter of the groups still traversing (ShadowQueue::M), whose last one adds the light's sample.
+            // MEASURED (profiles/r3s_steal_pool_ab.txt, c3): bit-exact, and a large loss.  Compiled in but switched off it costs 7-10 %
+            // (101 instead of 94 VGPRs: four instead of five waves per SIMD, or spills when five are forced); switched on, 20 passes
+            // run at 1075 instead of 1640 Mrays/s and a 1/8 shard at 0.43 of its rate: a handed-over subtree is a few dozen node
+            // steps, less than the reload of its ray, the merge atomics and the pool traffic cost, and thousands of waves polling
+            // and topping up one pool keep each other busy.  Not built further; -DHR_STEAL=1 builds it.
+            if (tbl->poolCap != 0u) {
+                // what other waves have found for this lane's ray since
+                if (item != 0xFFFFFFFFu && mGlobal[wave][slot] != 0u) {
+                    const SegDev &sgm = tbl->seg[segIdx >> 1];
+                    if (segIdx & 1) {
+                        if (__hip_atomic_load(&sgm.sq.M[local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kOccluded) cur = kSentinel, sp = 0, pend = 0;
+                    } else {
+                        const unsigned long long gk = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&sgm.hits[local]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (gk != kNoHitKey) {
+                            const float ts = __uint_as_float((uint32_t)(gk >> 32));
+                            tlim = ts < tlim ? ts : tlim;
+                        }
+                    }
+                }
+                const uint32_t idleSeen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tbl->idleSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                const bool canDonate = item != 0xFFFFFFFFu && sp >= 2 && sp <= kStackLDS; // (keeps an entry for itself)
+                const unsigned long long donMask = __ballot(canDonate);
+                if (idleSeen != 0u && donMask != 0ull && nIdle == 0) {
+                    const unsigned long long ht = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&tbl->poolTail), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t tailNow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ht), headNow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ht >> 32));
+                    const uint32_t nCan = (uint32_t)__popcll(donMask);
+                    const uint32_t nGive = nCan < (uint32_t)kStealGive ? nCan : (uint32_t)kStealGive;
+                    if (tailNow - headNow < kStealLow && tailNow + nGive <= tbl->poolCap) { // (wave-uniform)
+                        const uint32_t rank = (uint32_t)__popcll(donMask & ltMask);
+                        const bool gives = canDonate && rank < nGive;
+                        uint32_t base = 0;
+                        if (lane == (uint32_t)(__ffsll((long long)donMask) - 1)) base = atomicAdd(&tbl->poolTail, nGive);
+                        base = (uint32_t)__shfl((int)base, __ffsll((long long)donMask) - 1);
+                        const bool fits = base + nGive <= tbl->poolCap; // (entries beyond the capacity are never claimed)
+                        const SegDev &sgd = tbl->seg[segIdx >> 1];
+                        // (1) the ray's merge record exists before anybody else can see one of its subtrees
+                        bool first = false;
+                        if (gives && fits) first = atomicExch(&mGlobal[wave][slot], 1u) == 0u; // (one lane per ray of this wave)
+                        if (first) {
+                            if (segIdx & 1) {
+                                atomicExch(&sgd.sq.M[local], 1u); // this wave's group
+                            } else {
+                                atomicExch(reinterpret_cast<unsigned long long *>(&sgd.hits[local]), ((volatile unsigned long long *)mKey[wave])[slot]);
+                                reinterpret_cast<uint32_t *>(&sgd.hits[local])[2] = kSharedMark;
+                                reinterpret_cast<uint32_t *>(&sgd.hits[local])[3] = kSharedMark;
+                            }
+                        }
+                        // (everything shared between waves here is written by device-scope atomics, which execute at the memory side: what
+                        // has to be ordered is their completion, not a cache write-back)
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (gives && fits && (segIdx & 1)) atomicAdd(&sgd.sq.M[local], 1u); // the subtree handed over is one more group
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        // (2) publish: the OLDEST stack entry (the farthest, usually largest subtree), like the hand-over inside the wave
+                        if (gives && fits) {
+                            const int node = stackLane[0];
+                            __hip_atomic_store(&tbl->pool[base + rank], ((unsigned long long)(item + 1u) << 32) | (unsigned long long)(uint32_t)node, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            sp -= 1;
+                            if (sp > 0) stackLane[0] = stackLane[sp * 64];
+                        } else if (gives && base + rank < tbl->poolCap) {
+                            // (a reservation that ran over the end of the pool is abandoned; its slots inside the pool say so)
+                            __hip_atomic_store(&tbl->pool[base + rank], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            }
+#endif
         }
 #endif
         if (nIdle == 64) { // nothing in flight (finished rays were retired at the end of the previous round)
-            if (exhausted) break;
-            continue;
+            if (!exhausted) continue;
+#if HR_TAIL_SHARE && HR_STEAL
+            // ---------------- out of work: take subtrees from the steal pool, or leave
+            if (tbl->poolCap == 0u) break;
+            if (!toldIdle) {
+                toldIdle = true;
+                if (lane == 0) atomicExch(&tbl->idleSeen, 1u);
+            }
+            uint32_t got = 0, gotBase = 0;
+            for (int attempt = 0; attempt < kStealTries && got == 0u; ++attempt) {
+                if (lane == 0) {
+                    const unsigned long long ht = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&tbl->poolTail), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    uint32_t tailNow = (uint32_t)ht;
+                    const uint32_t headNow = (uint32_t)(ht >> 32);
+                    tailNow = tailNow < tbl->poolCap ? tailNow : tbl->poolCap;
+                    if (headNow < tailNow) {
+                        const uint32_t n = tailNow - headNow < 64u ? tailNow - headNow : 64u;
+                        if (atomicCAS(&tbl->poolHead, headNow, headNow + n) == headNow) got = n, gotBase = headNow;
+                    }
+                }
+                got = (uint32_t)__shfl((int)got, 0), gotBase = (uint32_t)__shfl((int)gotBase, 0);
+                if (got == 0u) __builtin_amdgcn_s_sleep(100);
+            }
+            if (got == 0u) break;
+            mCount[wave][lane] = 0u, mGlobal[wave][lane] = 0u, mKey[wave][lane] = kNoHitKey;
+            unsigned long long e = 0ull;
+            if (lane < got) {
+                do { // (the entry was reserved before it was written: its donor is a running wave, this wait is short)
+                    e = __hip_atomic_load(&tbl->pool[gotBase + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (e == 0ull) __builtin_amdgcn_s_sleep(2);
+                } while (e == 0ull);
+                __hip_atomic_store(&tbl->pool[gotBase + lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the pool is all-zero again when the launch ends
+            }
+            if (lane < got && (uint32_t)(e >> 32) != 0xFFFFFFFFu) { // (not an abandoned slot)
+                item = (uint32_t)(e >> 32) - 1u;
+                int sI = 0, sHiB = nSeg2 - 1;
+                while (sI < sHiB) {
+                    const int mid = (sI + sHiB + 1) >> 1;
+                    if (item >= segStart[mid])
+                        sI = mid;
+                    else
+                        sHiB = mid - 1;
+                }
+                segIdx = sI;
+                local = item - segStart[sI];
+                const SegDev &sg = tbl->seg[sI >> 1];
+                float4 a, b;
+                if (sI & 1) {
+                    a = G(sg.sq.A)[local], b = G(sg.sq.B)[local];
+                    skipPrim = __float_as_uint(b.w);
+                } else {
+                    a = G(sg.qin.A)[local], b = G(sg.qin.B)[local];
+                    skipPrim = (uint32_t)G(sg.qin.D)[local].z;
+                }
+                o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
+                tmax = a.w, tlim = a.w;
+                idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
+                {
+                    const RayK f = rayFrame(S, o, idx, idy, idz);
+                    oix = f.oix, oiy = f.oiy, oiz = f.oiz;
+                }
+                best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
+                sp = 0, pend = 0, cur = (int)(uint32_t)e;
+                slot = lane;
+                mCount[wave][lane] = 1u, mGlobal[wave][lane] = 1u;
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue; // (the drain block above picks up what the others have found so far; then the node steps)
+#else
+            break;
+#endif
         }
 #ifdef HR_TAILPROF
         if (exhausted) drainIters += 1, drainLanes += (unsigned long long)(64 - nIdle);
@@ -639,6 +800,27 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
             if (before == 1u) {
                 const unsigned long long k = ((volatile unsigned long long *)mKey[wave])[slot];
                 const SegDev &sg = tbl->seg[segIdx >> 1];
+#if HR_STEAL
+                const bool shared = ((volatile uint32_t *)mGlobal[wave])[slot] != 0u;
+                if (shared) {
+                    // this wave's group of the ray is done; other waves hold (or held) the rest
+                    if (isAny) {
+                        if (k != kNoHitKey) atomicOr(&sg.sq.M[local], kOccluded);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        const uint32_t was = atomicSub(&sg.sq.M[local], 1u);
+                        if ((was & 0x3FFFFFFFu) == 1u && (was & kOccluded) == 0u && k == kNoHitKey) { // the last group, and nobody found an occluder
+                            const float4 c = G(sg.sq.C)[local];
+                            HR_GLOBAL float *px = G(sg.passbuf) + (size_t)__float_as_uint(c.w) * 4;
+                            px[0] = px[0] + c.x;
+                            px[1] = px[1] + c.y;
+                            px[2] = px[2] + c.z;
+                            ++nacc;
+                        }
+                    } else if (k != kNoHitKey) {
+                        atomicMin(reinterpret_cast<unsigned long long *>(&sg.hits[local]), k);
+                    }
+                } else
+#endif
                 if (isAny) {
                     if (k == kNoHitKey) {
                         const float4 c = G(sg.sq.C)[local];
@@ -1006,7 +1188,35 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
         int cls = -1; // 0: PBR hit, 1: glass hit
         if (live) {
             const SegDev &sg = tbl->seg[sI];
-            const uint32_t hp = G(sg.hits)[li].prim;
+            uint32_t hp = G(sg.hits)[li].prim;
+#if HR_STEAL
+            if (__float_as_uint(G(sg.hits)[li].u) == kSharedMark) {
+                // The ray was traversed by several waves (k_trace's steal pool): its record still holds the merged 64-bit key
+                // (t, triangle, face).  Turn it into a hit record; the barycentrics are those of the triangle test itself — the same
+                // operations on the same operands as in the traversal, so the same bits.
+                const unsigned long long key = *reinterpret_cast<const HR_GLOBAL unsigned long long *>(G(sg.hits) + li);
+                HitRec h;
+                h.prim = kMissPrim, h.t = G(sg.qin.A)[li].w, h.u = 0.0f, h.v = 0.0f;
+                if (key != kNoHitKey) {
+                    const uint32_t lo = (uint32_t)key, prim = lo >> 1;
+                    const float4 a = G(sg.qin.A)[li], b = G(sg.qin.B)[li];
+                    const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
+                    const HR_GLOBAL Tri &tr = G(S.tris)[G(S.slotOfPrim)[prim]];
+                    const float4 tp = tr.p, tq = tr.q, trr = tr.r;
+                    const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
+                    const v3 pvec = cross(d, e2);
+                    const float det = dot(e1, pvec);
+                    const float inv = 1.0f / det;
+                    const v3 tvec = o - v0;
+                    const float u = dot(tvec, pvec) * inv;
+                    const v3 qvec = cross(tvec, e1);
+                    const float v = dot(d, qvec) * inv;
+                    h.prim = (lo >> 1) | (lo << 31), h.t = __uint_as_float((uint32_t)(key >> 32)), h.u = u, h.v = v;
+                }
+                G(sg.hits)[li] = h;
+                hp = h.prim;
+            }
+#endif
             if (hp == kMissPrim) {
                 // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
                 const uint32_t meta = (uint32_t)G(sg.qin.D)[li].x;

@@ -100,8 +100,11 @@ struct RayQueue {
 };
 // Occlusion (NEE) rays: A = (origin.xyz, tmax)  B = (dir.xyz, srcPrim bits)
 //   C = (value.rgb, pixel bits): the clamped radiance the light shader adds when the ray is unoccluded
+//   M = merge word of a ray whose subtrees have been handed to other waves (k_trace's steal pool): groups of lanes still
+//       traversing parts of it | occluded << 31.  Written only for such rays; never initialised for the others.
 struct ShadowQueue {
     float4 *A, *B, *C;
+    uint32_t *M;
 };
 // closest-hit record: prim | frontCCW << 31 (prim == 0x7FFFFFFF: miss), t, u, v
 static const uint32_t kMissPrim = 0x7FFFFFFFu;
@@ -137,6 +140,8 @@ struct SceneDev {
     int32_t blockCoords[32];
     // HR_TEXTURE_LOD_CONE: per triangle (prim id) 0.5 * log2(uv area / world area), or null
     const float *texDensity;
+    // prim id -> position in `tris` (k_shade_sort recomputes the barycentrics of a hit whose ray was traversed by several waves)
+    const uint32_t *slotOfPrim;
 };
 
 // ---- counters ---------------------------------------------------------------------------------
