@@ -273,11 +273,13 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
 static const unsigned long long kNoHitKey = ~0ull;
 // HR_STEAL (hr_kernels.h): drain phase, waves that have run out of work take subtrees of other waves' rays from a global pool.
 // EXPERIMENT of round 3, parity-green on the whole GPU suite and much slower (see the comment at the pool code): off by default.
+#if HR_STEAL
 static const uint32_t kStealLow = 192;  // busy waves top the pool up while fewer than this many entries wait in it
 static const int kStealGive = 16;       // entries a wave adds per round at most
 static const int kStealTries = 6;       // polls of an empty pool (a few microseconds apart) before a wave gives up and exits
 static const uint32_t kSharedMark = 0xFFFFFFFFu; // u and v words of a hit record that is still in merge (key) format
 static const uint32_t kOccluded = 0x80000000u;   // flag bit of an occlusion ray's merge word (ShadowQueue::M)
+#endif
 
 #ifdef HR_TAILPROF
 // Experiment builds only: when does the work queue run dry, when does the launch end, how long is the longest ray?
