@@ -913,6 +913,7 @@ __global__ __launch_bounds__(256) void k_env_lum(TexDesc t, float *__restrict__ 
         const v4 c = texel(t, (int)(i % (uint32_t)t.w), (int)(i / (uint32_t)t.w));
         l = (c.x * 0.33f + c.y * 0.59f) + c.z * 0.11f; // utility.rlsl:163-166 luminosity
         l = l > 0.0f ? l : 0.0f;
+        l = l < 1e30f ? l : 1e30f; // (an infinite texel must not turn the normalisation into Inf / Inf)
         lum[i] = l;
     }
 #pragma unroll
@@ -984,14 +985,17 @@ __global__ void k_env_marginal(const unsigned long long *__restrict__ rowSum, in
     *meanLum = (((float)t / 1048576.0f) * norm) / ((float)w * sumC);
 }
 // one workgroup per row: conditional CDF over the columns (chunked scan with a carry) and the texel probabilities
+// The probability of a texel is what sampleEnv() really draws it with: the float CDF steps the two searches invert,
+// (rowCdf[j + 1] - rowCdf[j]) x (colCdf[i + 1] - colCdf[i]) — not the exact ratio of the integer weights, which a float CDF of a map
+// with a 2^20 : 1 weight range cannot resolve for dim texels (the balance heuristic needs the density samples are drawn with).
 __global__ __launch_bounds__(256) void k_env_cols(const uint32_t *__restrict__ wq, const unsigned long long *__restrict__ rowSum,
-                                                  const unsigned long long *__restrict__ total, int w, float *__restrict__ colCdf,
+                                                  const float *__restrict__ rowCdf, int w, float *__restrict__ colCdf,
                                                   float *__restrict__ prob)
 {
     __shared__ unsigned long long waveSum[4];
     __shared__ unsigned long long carry;
     const int j = blockIdx.x;
-    const float fr = (float)rowSum[j], ft = (float)*total;
+    const float fr = (float)rowSum[j], pRow = rowCdf[j + 1] - rowCdf[j];
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1009,8 +1013,9 @@ __global__ __launch_bounds__(256) void k_env_cols(const uint32_t *__restrict__ w
         unsigned long long before = carry;
         for (uint32_t k = 0; k < wave; ++k) before += waveSum[k];
         if (i < w) {
-            colCdf[(size_t)j * (w + 1) + i] = (float)(before + inc - v) / fr;
-            prob[(size_t)j * w + i] = (float)v / ft;
+            const float cThis = (float)(before + inc - v) / fr, cNext = (i == w - 1) ? 1.0f : (float)(before + inc) / fr;
+            colCdf[(size_t)j * (w + 1) + i] = cThis;
+            prob[(size_t)j * w + i] = pRow * (cNext - cThis);
         }
         __syncthreads();
         if (threadIdx.x == 255) carry = before + inc;
@@ -1024,13 +1029,13 @@ void launchEnvTable(hipStream_t st, const TexDesc &tex, float *lum, float *dil, 
                     uint32_t *maxBits, float *rowCdf, float *colCdf, float *prob, float *meanLum)
 {
     const int w = tex.w, h = tex.h;
-    const uint32_t n = (uint32_t)(w * h), g = (n + 255) / 256;
+    const uint32_t n = (uint32_t)((size_t)w * (size_t)h), g = (n + 255) / 256;
     hipMemsetAsync(maxBits, 0, 4, st);
     hipLaunchKernelGGL(k_env_lum, dim3(g), dim3(256), 0, st, tex, lum, maxBits);
     hipLaunchKernelGGL(k_env_dilate, dim3(g), dim3(256), 0, st, lum, dil, w, h);
     hipLaunchKernelGGL(k_env_rows, dim3(h), dim3(256), 0, st, dil, w, h, maxBits, wq, rowSum);
     hipLaunchKernelGGL(k_env_marginal, dim3(1), dim3(1), 0, st, rowSum, w, h, maxBits, rowCdf, total, meanLum);
-    hipLaunchKernelGGL(k_env_cols, dim3(h), dim3(256), 0, st, wq, rowSum, total, w, colCdf, prob);
+    hipLaunchKernelGGL(k_env_cols, dim3(h), dim3(256), 0, st, wq, rowSum, rowCdf, w, colCdf, prob);
 }
 
 // Guide tables of the two inverse-CDF searches (hr_shade.h::sampleEnv): guide[k] = the largest index whose CDF value is <= k / K.

@@ -951,6 +951,44 @@ template <int MODE> struct ShaderT {
             }
         }
     }
+    // HR_ESTIMATOR_ENV_MIS / HR_ESTIMATOR_ALL_LIGHTS on glass (include/hrcore.h; the reference lobe-samples the map here: glass.rlsl:83-129
+    // -> :47-81): the reflection's next-event ray towards the environment comes from the visible-normal lobe or from the map's importance
+    // table, half the time each, balance heuristic; BRDF x cos as glass.rlsl:104-109 has it for an analytic light (D G2 / (4 N.I) x
+    // baseColor), lobe density D G1 / (4 N.I); selection variable: sequence ID + depth + 5.  Same operations as the oracle's.
+    HRD void envMisGlass(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 weight, v3 baseColor, float roughnessAlpha, float envProbability, v2 rand,
+                         const m3 &frame, Ray &nee, Ray &next) const
+    {
+        const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        v3 O, H;
+        if (sel.x < 0.5f) {
+            H = mul(frame, sampleVisibleGGX(mulT(frame, I), rand.x, rand.y, roughnessAlpha));
+            O = normalize(2.0f * saturate(dot(I, H)) * H - I);
+        } else {
+            O = sampleEnv(rand.x, rand.y);
+            H = normalize(I + O);
+        }
+        float NdotO = dot(N, O);
+        if (!(NdotO > 0.0f)) return;
+        NdotO = saturate(NdotO);
+        const float NdotH = saturate(dot(N, H));
+        const float D = D_GGX(NdotH, roughnessAlpha);
+        const float G2 = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha), G1 = G1_Smith_GGX(NdotI, roughnessAlpha);
+        const float specular = (D * G2) / greaterThanZero(4.0f * NdotI);
+        const float pLobe = (D * G1) / greaterThanZero(4.0f * NdotI), pMap = envPdf(O);
+        v3 reflectance = specular * baseColor;
+        reflectance = reflectance * weight;
+        reflectance = reflectance / greaterThanZero(0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / envProbability;
+        if (dot(reflectance, reflectance) > 0.0f) {
+            Ray r = createRay(in, P);
+            r.d = O;
+            r.weight = reflectance;
+            r.occlusionTest = true;
+            r.missKind = MISS_ENV, r.missIdx = 0;
+            r.extraT = 0.0f;
+            emit(r, nee, next);
+        }
+    }
     HRD void directSpecularGlassSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 weight, v3 baseColor, float roughnessAlpha,
                                        float materialRoughnessAlpha, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next,
                                        ExtraRay &nee2) const // :83-129
@@ -985,13 +1023,20 @@ template <int MODE> struct ShaderT {
             }
         }
         if (both) {
-            if (S.lights.env_enabled)
-                indirectSpecularGlassSample(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, 1.0f, rand, frame, MISS_ENV, nee,
-                                            next);
+            if (S.lights.env_enabled) {
+                if (envMis())
+                    envMisGlass(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, 1.0f, rand, frame, nee, next);
+                else
+                    indirectSpecularGlassSample(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, 1.0f, rand, frame, MISS_ENV,
+                                                nee, next);
+            }
         } else if (ls.type != LIGHT_TYPE_ENVIRONMENT) {
         } else if (ls.probability > 0.0f) {
-            indirectSpecularGlassSample(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, ls.probability, rand, frame,
-                                        MISS_ENV, nee, next);
+            if (envMis())
+                envMisGlass(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, ls.probability, rand, frame, nee, next);
+            else
+                indirectSpecularGlassSample(in, P, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, ls.probability, rand, frame,
+                                            MISS_ENV, nee, next);
         }
     }
     HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, ExtraRay &nee2) // :138-280

@@ -315,8 +315,9 @@ typedef struct hr_pass_params {
  * (lightSampling.rlsl:75-77, microfacet.rlsl:94-96).
  * HR_ESTIMATOR_ENV_MIS: that one ray is drawn either from the BRDF lobe or from a luminance x solid-angle
  * distribution over the environment map's texels (half the time each) and weighted with the balance heuristic (the one-sample
- * MIS estimator): same expectation, far less variance under small bright sources.  PBR materials only; everything else —
- * ray budget, light pick, lobe pick, analytic lights, glass — is the reference's. */
+ * MIS estimator): same expectation, far less variance under small bright sources.  PBR materials, and the reflection branch of
+ * glass (its next-event ray towards the map: glass.rlsl:83-129; BRDF x cos as :104-109 has it for analytic lights); everything
+ * else — ray budget, light pick, lobe pick, analytic lights, glass transmission — is the reference's. */
 #define HR_ESTIMATOR_REFERENCE 0
 #define HR_ESTIMATOR_ENV_MIS 1
 /* HR_ESTIMATOR_ALL_LIGHTS: HR_ESTIMATOR_ENV_MIS without the reference's remaining large variance term, the random choice of ONE
@@ -329,7 +330,7 @@ typedef struct hr_pass_params {
  * No two rays of a launch may write the same pixel, so the pass's sample is kept as four partial sums (everything of the
  * reference path + the first environment ray; the analytic-light ray; the second and third environment ray), added in this
  * order when the pass resolves.  Up to three more occlusion rays per path.  Glass vertices send the analytic-light ray and the
- * (lobe-sampled) environment ray as well.  Own oracle
+ * MIS-weighted environment ray as well.  Own oracle
  * contract (bit-exact) and known-answer tests, like ENV_MIS. */
 #define HR_ESTIMATOR_ALL_LIGHTS 2
 

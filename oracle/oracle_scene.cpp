@@ -52,6 +52,7 @@ void buildEnvTable(Context &ctx)
             const vec4 c = texel(T, i, j);
             float l = (c.x * 0.33f + c.y * 0.59f) + c.z * 0.11f; // utility.rlsl:163-166 luminosity
             l = l > 0.0f ? l : 0.0f;
+            l = l < 1e30f ? l : 1e30f; // (an infinite texel must not turn the normalisation into Inf / Inf)
             lum[(size_t)j * w + i] = l;
             maxLum = l > maxLum ? l : maxLum;
         }
@@ -102,11 +103,20 @@ void buildEnvTable(Context &ctx)
         for (int i = 0; i < w; ++i) {
             E.colCdf[(size_t)j * (w + 1) + i] = (float)a / (float)rowSum[j];
             a += wq[(size_t)j * w + i];
-            E.prob[(size_t)j * w + i] = (float)wq[(size_t)j * w + i] / (float)total;
         }
         E.colCdf[(size_t)j * (w + 1) + w] = 1.0f;
     }
     E.rowCdf[h] = 1.0f;
+    // The probability of a texel is what sampleEnv() really draws it with: the float CDF steps the two searches invert — not the
+    // exact ratio of the integer weights, which a float CDF cannot resolve for dim texels of a map with a 2^20 : 1 weight range
+    // (the balance heuristic needs the density the samples are drawn with).
+    for (int j = 0; j < h; ++j) {
+        const float pRow = E.rowCdf[j + 1] - E.rowCdf[j];
+        for (int i = 0; i < w; ++i) {
+            const float cThis = E.colCdf[(size_t)j * (w + 1) + i], cNext = E.colCdf[(size_t)j * (w + 1) + i + 1];
+            E.prob[(size_t)j * w + i] = pRow * (cNext - cThis);
+        }
+    }
     // mean luminosity over the sphere from the same integers: sum(weight) / sum(cos) — rows in order, one float addition per row
     float sumC = 0.0f;
     for (int j = 0; j < h; ++j) sumC = sumC + cos_((((float)j + 0.5f) / (float)h - 0.5f) * kPI);

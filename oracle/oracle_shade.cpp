@@ -939,6 +939,45 @@ struct Shader {
             }
         }
     }
+    // HR_ESTIMATOR_ENV_MIS / HR_ESTIMATOR_ALL_LIGHTS on glass (this repo's contract, include/hrcore.h; the reference lobe-samples the
+    // map here: glass.rlsl:83-129 -> :47-81): the reflection's next-event ray towards the environment is drawn from the visible-normal
+    // lobe or from the map's importance table, half the time each, and weighted with the balance heuristic.  BRDF x cos is the one
+    // glass.rlsl itself uses for an analytic light (:104-109: D G2 / (4 N.I) x baseColor, no Fresnel factor: the reflection branch was
+    // chosen with the Fresnel probability), the lobe's density D G1 / (4 N.I).  Own selection variable: sequence ID + depth + 5.
+    void envMisGlass(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 weight, vec3 baseColor, float roughnessAlpha, float envProbability,
+                     vec2 rand, const mat3 &frame, Ray &nee, Ray &next)
+    {
+        const vec2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
+        vec3 O, H;
+        if (sel.x < 0.5f) {
+            H = mul(frame, sampleVisibleGGX(mulT(frame, I), rand.x, rand.y, roughnessAlpha));
+            O = normalize(2.0f * saturate(dot(I, H)) * H - I);
+        } else {
+            O = sampleEnv(rand.x, rand.y);
+            H = normalize(I + O);
+        }
+        float NdotO = dot(N, O);
+        if (!(NdotO > 0.0f)) return;
+        NdotO = saturate(NdotO);
+        const float NdotH = saturate(dot(N, H));
+        const float D = D_GGX(NdotH, roughnessAlpha);
+        const float G2 = G2_Smith_GGX(NdotO, NdotI, roughnessAlpha), G1 = G1_Smith_GGX(NdotI, roughnessAlpha);
+        const float specular = (D * G2) / greaterThanZero(4.0f * NdotI);
+        const float pLobe = (D * G1) / greaterThanZero(4.0f * NdotI), pMap = envPdf(O);
+        vec3 reflectance = specular * baseColor;
+        reflectance = reflectance * weight;
+        reflectance = reflectance / greaterThanZero(0.5f * pLobe + 0.5f * pMap);
+        reflectance = reflectance / envProbability;
+        if (dot(reflectance, reflectance) > 0.0f) {
+            Ray r = createRay(in, P, prim);
+            r.d = O;
+            r.weight = reflectance;
+            r.occlusionTest = true;
+            r.missKind = MISS_ENV, r.missIdx = 0;
+            r.extraT = 0.0f;
+            emit(r, nee, next);
+        }
+    }
     void directSpecularGlassSample(const Ray &in, vec3 P, int prim, vec3 N, vec3 I, float NdotI, vec3 weight, vec3 baseColor, float roughnessAlpha,
                                    float materialRoughnessAlpha, float lightProbability, vec2 rand, const mat3 &frame, Ray &nee,
                                    Ray &next, Ray &nee2) // :83-129
@@ -973,13 +1012,20 @@ struct Shader {
             }
         }
         if (both) {
-            if (ctx.lights.env_enabled)
-                indirectSpecularGlassSample(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, 1.0f, rand, frame,
-                                            MISS_ENV, nee, next);
+            if (ctx.lights.env_enabled) {
+                if (envMis())
+                    envMisGlass(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, 1.0f, rand, frame, nee, next);
+                else
+                    indirectSpecularGlassSample(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, 1.0f, rand, frame,
+                                                MISS_ENV, nee, next);
+            }
         } else if (ls.type != LIGHT_TYPE_ENVIRONMENT) {
         } else if (ls.probability > 0.0f) {
-            indirectSpecularGlassSample(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, ls.probability, rand,
-                                        frame, MISS_ENV, nee, next);
+            if (envMis())
+                envMisGlass(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, ls.probability, rand, frame, nee, next);
+            else
+                indirectSpecularGlassSample(in, P, prim, N, I, NdotI, weight, baseColor, roughnessAlpha, materialRoughnessAlpha, ls.probability, rand,
+                                            frame, MISS_ENV, nee, next);
         }
     }
     void glass(const Ray &in, const Hit &h, const hr_material &M, Ray &nee, Ray &next, Ray &nee2) // :138-280

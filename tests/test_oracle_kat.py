@@ -645,6 +645,56 @@ def test_env_mis_estimator_is_unbiased_and_quieter(roughness, metallic):
     assert float((img[..., 0] / img[..., 3]).mean()) == pytest.approx(truth, rel=0.05)
 
 
+def glass_plane(estimator, env, passes, sun_light=None, size=8):
+    sc = scenes.Scene("glass_plane", width=size, height=size, use_multiscatter_lut=False)
+    p, n, uv, i = scenes.plane_strip(2000, 2000)
+    sc.materials[0] = host.bake_glass(base_color=(0.9, 0.9, 0.9), roughness=0.5, ior=1.5, density=0.0)
+    sc.meshes.append(scenes.MeshData(p, n, i, uvs=uv, mode=ffi.HR_TRIANGLE_STRIP, material_id=0))
+    sc.env_pixels = env
+    if sun_light is not None:
+        sc.lights.directional.append(sun_light)
+    o = sc.options
+    # depth 0: the camera ray's vertex is all there is — its reflection branch sends the next-event ray, nothing is transmitted on
+    o.max_ray_depth, o.aspect_ratio, o.fstop, o.focal_length = 0, 1.0, host.FSTOP_DISABLED, 4000.0
+    o.max_channel_value = 1e9
+    o.view_matrix = host.orbit_view_matrix(10.0, 0.3, 0.9)
+    o.max_render_passes = passes
+    o.estimator = estimator
+    return sc
+
+
+@pytest.mark.parametrize("estimator", [ffi.HR_ESTIMATOR_ENV_MIS, ffi.HR_ESTIMATOR_ALL_LIGHTS])
+def test_env_mis_on_glass_a_small_sun_in_the_map_lights_like_the_equivalent_directional_light(estimator):
+    # Glass under the new estimators draws its environment next-event ray from the map's importance table too (it used to
+    # lobe-sample the map).  Independent statement of what that must give: a small, very bright sun in an otherwise black map lights the
+    # reflection lobe like a directional light of the same irradiance from the same direction, whose value glass.rlsl:104-109 gives in
+    # closed form (D G2 / (4 N.I) x baseColor) and the reference-faithful estimator evaluates without any sampling of directions.
+    w, h = 512, 256
+    env = np.zeros((h, w, 3), dtype=F)
+    j0, i0, L = 200, 300, 40000.0
+    env[j0:j0 + 2, i0:i0 + 2] = L
+    irr = 0.0
+    for j in range(j0, j0 + 2):
+        el = ((j + 0.5) / h - 0.5) * math.pi
+        irr += 2 * L * (2 * math.pi / w) * (math.pi / h) * math.cos(el)       # radiance x solid angle of the row's two texels
+    el_c, az_c = ((j0 + 1.0) / h - 0.5) * math.pi, ((i0 + 1.0) / w - 0.5) * 2 * math.pi
+    to_sun = np.array([math.cos(el_c) * math.sin(az_c), math.sin(el_c), -math.cos(el_c) * math.cos(az_c)], dtype=F)
+    # (only the Fresnel fraction of the samples, ~7 % at this angle, takes the reflection branch at all: many passes)
+    passes = 16384
+    img, _ = render(glass_plane(estimator, env, passes), passes)
+    sun = float((img[..., 0] / img[..., 3]).mean())
+    img, _ = render(glass_plane(ffi.HR_ESTIMATOR_REFERENCE, None, passes, sun_light=(to_sun, np.full(3, irr, dtype=F))), passes)
+    lamp = float((img[..., 0] / img[..., 3]).mean())
+    assert lamp > 0.0
+    assert sun == pytest.approx(lamp, rel=0.05), (sun, lamp)
+    # ... and the map sampler is what finds it: the reference estimator, lobe-sampling the same map, is far noisier per pixel
+    img, _ = render(glass_plane(ffi.HR_ESTIMATOR_REFERENCE, env, passes), passes)
+    ref = img[..., 0] / img[..., 3]
+    img, _ = render(glass_plane(estimator, env, passes), passes)
+    new = img[..., 0] / img[..., 3]
+    assert float(new.std() / new.mean()) < 0.5 * float(ref.std() / max(ref.mean(), 1e-30))
+
+
 def test_env_mis_estimator_white_furnace_and_fallbacks():
     # uniform environment: expectation E x albedo for both estimators (the reference one is exact per sample here, the MIS one in the mean)
     env = np.full((8, 16, 3), 0.8, dtype=F)
