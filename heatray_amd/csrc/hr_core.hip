@@ -773,20 +773,49 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     // layout of the device block: every attribute as the caller holds it (its stride included), then the indices
     size_t bytesOf[6] = {0, 0, 0, 0, 0, 0}, total = 0;
     std::vector<float> tight[6]; // only for strides that are not a multiple of four bytes (re-packed on the host)
+    // One interleaved vertex buffer (every attribute a pointer into the same array of `stride`-byte vertices, as glTF loaders hand
+    // them over) is uploaded ONCE and addressed with per-attribute offsets; uploading it once per attribute with its full stride
+    // cost 3-6 x the device memory and PCIe traffic.
+    const char *ilo = nullptr, *ihi = nullptr;
+    int isb = 0;
+    bool interleaved = true;
+    int nAttr = 0;
     for (int a = 0; a < 6; ++a) {
         if (!src[a]) continue;
-        g.has[a] = true;
-        int sb = strideB[a] == 0 ? comps[a] * (int)sizeof(float) : strideB[a];
-        if (sb < comps[a] * (int)sizeof(float) && sb != 0) FAIL(c, HR_ERR_INVALID, "attribute stride smaller than the attribute");
-        if (sb % 4 != 0) {
-            tight[a].resize((size_t)g.nVerts * comps[a]);
-            for (int i = 0; i < g.nVerts; ++i) std::memcpy(&tight[a][(size_t)i * comps[a]], (const char *)src[a] + (size_t)i * sb, comps[a] * sizeof(float));
-            sb = comps[a] * (int)sizeof(float);
+        ++nAttr;
+        const char *p0 = (const char *)src[a], *p1 = p0 + comps[a] * sizeof(float);
+        if (strideB[a] <= 0 || strideB[a] % 4 != 0 || (isb != 0 && strideB[a] != isb)) interleaved = false;
+        isb = strideB[a];
+        ilo = (!ilo || p0 < ilo) ? p0 : ilo;
+        ihi = (!ihi || p1 > ihi) ? p1 : ihi;
+    }
+    interleaved = interleaved && nAttr >= 2 && (size_t)(ihi - ilo) <= (size_t)isb;
+    if (interleaved) {
+        const size_t span = (size_t)(g.nVerts - 1) * (size_t)isb + (size_t)(ihi - ilo);
+        for (int a = 0; a < 6; ++a) {
+            if (!src[a]) continue;
+            g.has[a] = true;
+            g.stride[a] = isb / 4;
+            g.off[a] = (size_t)((const char *)src[a] - ilo);
+            bytesOf[a] = 0;
         }
-        g.stride[a] = sb / 4;
-        bytesOf[a] = (size_t)(g.nVerts - 1) * sb + comps[a] * sizeof(float);
-        g.off[a] = total;
-        total += (bytesOf[a] + 15) & ~(size_t)15;
+        total = (span + 15) & ~(size_t)15;
+    } else {
+        for (int a = 0; a < 6; ++a) {
+            if (!src[a]) continue;
+            g.has[a] = true;
+            int sb = strideB[a] == 0 ? comps[a] * (int)sizeof(float) : strideB[a];
+            if (sb < comps[a] * (int)sizeof(float) && sb != 0) FAIL(c, HR_ERR_INVALID, "attribute stride smaller than the attribute");
+            if (sb % 4 != 0) {
+                tight[a].resize((size_t)g.nVerts * comps[a]);
+                for (int i = 0; i < g.nVerts; ++i) std::memcpy(&tight[a][(size_t)i * comps[a]], (const char *)src[a] + (size_t)i * sb, comps[a] * sizeof(float));
+                sb = comps[a] * (int)sizeof(float);
+            }
+            g.stride[a] = sb / 4;
+            bytesOf[a] = (size_t)(g.nVerts - 1) * sb + comps[a] * sizeof(float);
+            g.off[a] = total;
+            total += (bytesOf[a] + 15) & ~(size_t)15;
+        }
     }
     g.off[6] = total;
     total += ((size_t)g.nIdx * 4 + 15) & ~(size_t)15;
@@ -796,8 +825,12 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     // recycled device memory there made the key differ from run to run)
     HIP_TRY(c, hipMemsetAsync(g.dBlock, 0, total ? total : 16, c->stream));
     int rc = HR_OK;
-    for (int a = 0; a < 6 && rc == HR_OK; ++a)
-        if (g.has[a]) rc = stagedUpload(c, g.dBlock + g.off[a], tight[a].empty() ? (const char *)src[a] : (const char *)tight[a].data(), bytesOf[a]);
+    if (interleaved) {
+        rc = stagedUpload(c, g.dBlock, ilo, (size_t)(g.nVerts - 1) * (size_t)isb + (size_t)(ihi - ilo));
+    } else {
+        for (int a = 0; a < 6 && rc == HR_OK; ++a)
+            if (g.has[a]) rc = stagedUpload(c, g.dBlock + g.off[a], tight[a].empty() ? (const char *)src[a] : (const char *)tight[a].data(), bytesOf[a]);
+    }
     if (rc == HR_OK && g.nIdx) rc = stagedUpload(c, g.dBlock + g.off[6], (const char *)d->indices, (size_t)g.nIdx * 4);
     if (rc != HR_OK) {
         hipFree(g.dBlock);
@@ -813,7 +846,8 @@ int hr_geom_remove(hr_ctx *c, hr_geom_id id)
 {
     ENTER(c);
     if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive) FAIL(c, HR_ERR_INVALID, "bad geom id");
-    HIP_TRY(c, hipStreamSynchronize(c->stream)); // an upload of this mesh may still be in flight
+    for (int k = 0; k < 2; ++k) // an upload of this mesh may still be in flight (nothing to wait for when the staging ring is idle)
+        if (c->stageBusy[k] && hipEventQuery(c->stageEv[k]) != hipSuccess) HIP_TRY(c, hipEventSynchronize(c->stageEv[k]));
     hipFree(c->geoms[id].dBlock);
     c->geoms[id] = Geom();
     c->committed = false, c->topologyDirty = true;
@@ -832,7 +866,8 @@ int hr_geom_set_transform(hr_ctx *c, hr_geom_id id, const float m[16])
 int hr_scene_clear(hr_ctx *c)
 {
     ENTER(c);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; ++k)
+        if (c->stageBusy[k] && hipEventQuery(c->stageEv[k]) != hipSuccess) HIP_TRY(c, hipEventSynchronize(c->stageEv[k]));
     for (Geom &g : c->geoms) hipFree(g.dBlock);
     c->geoms.clear();
     c->committed = false, c->topologyDirty = true;
