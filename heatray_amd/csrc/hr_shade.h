@@ -890,12 +890,14 @@ template <int MODE> struct ShaderT {
                 }
             } else if (probability.x <= diffuseProbability) {
                 directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next);
-            } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
-                directSpecularSample(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                     clearCoatRoughness, clearCoatProbability, probability.y, rand, frame, nee, next);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
-                directSpecularSample(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability, probability.y,
-                                     rand, frame, nee, next);
+                // clearcoat and specular lobe: the same function on the lobe's own parameters (physicallyBased.rlsl:253-272) — selected
+                // first and called once, so that lanes of both lobes run together and the code exists once
+                const bool coat = probability.x <= (diffuseProbability + clearCoatProbability);
+                const v3 lN = coat ? clearCoatN : N, lC = coat ? v3(clearCoatScale) : Cspec;
+                const float lNdotV = coat ? clearCoatNdotV : NdotV, lAlpha = coat ? clearCoatRoughnessAlpha : roughnessAlpha,
+                            lRough = coat ? clearCoatRoughness : roughness, lProb = coat ? clearCoatProbability : specularProbability;
+                directSpecularSample(in, sf.P, lN, V, lNdotV, lC, lAlpha, M.multiscatter_lut, lRough, lProb, probability.y, rand, frame, nee, next);
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330
@@ -911,12 +913,12 @@ template <int MODE> struct ShaderT {
             dummyNee.valid = false;
             if (probability.x <= diffuseProbability) {
                 indirectDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, 1.0f, rand, frame, MISS_NONE, dummyNee, next);
-            } else if (probability.x <= (diffuseProbability + clearCoatProbability)) {
-                indirectSpecularSample(in, sf.P, clearCoatN, V, clearCoatNdotV, v3(clearCoatScale), clearCoatRoughnessAlpha, M.multiscatter_lut,
-                                       clearCoatRoughness, clearCoatProbability, 1.0f, rand, frame, MISS_NONE, dummyNee, next);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
-                indirectSpecularSample(in, sf.P, N, V, NdotV, Cspec, roughnessAlpha, M.multiscatter_lut, roughness, specularProbability, 1.0f, rand,
-                                       frame, MISS_NONE, dummyNee, next);
+                const bool coat = probability.x <= (diffuseProbability + clearCoatProbability); // (:305-327, as above)
+                const v3 lN = coat ? clearCoatN : N, lC = coat ? v3(clearCoatScale) : Cspec;
+                const float lNdotV = coat ? clearCoatNdotV : NdotV, lAlpha = coat ? clearCoatRoughnessAlpha : roughnessAlpha,
+                            lRough = coat ? clearCoatRoughness : roughness, lProb = coat ? clearCoatProbability : specularProbability;
+                indirectSpecularSample(in, sf.P, lN, V, lNdotV, lC, lAlpha, M.multiscatter_lut, lRough, lProb, 1.0f, rand, frame, MISS_NONE, dummyNee, next);
             }
         }
     }
