@@ -560,10 +560,11 @@ template <int MODE> struct ShaderT {
         }
     }
 
+    // (`ls` = computeLightSample(N, lightProbability, P), lightSampling.rlsl:11-161: evaluated by the caller, once for whichever lobe the
+    // vertex samples, so that the light pick — a loop over up to fifteen lights — exists and runs once per wave, not once per lobe)
     HRD void directDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float lightProbability, v2 rand, const m3 &frame,
-                                 Ray &nee, Ray &next) const // :52-98
+                                 const LightSample &ls, Ray &nee, Ray &next) const // :52-98
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -638,9 +639,9 @@ template <int MODE> struct ShaderT {
         return specular;
     }
     HRD void directSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
-                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next) const // :153-220
+                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, const LightSample &ls, Ray &nee,
+                                  Ray &next) const // :153-220
     {
-        LightSample ls = computeLightSample(N, lightProbability, P);
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
             if (NdotO > 0.0f) {
@@ -888,16 +889,22 @@ template <int MODE> struct ShaderT {
                             keep(out, nee4);
                     }
                 }
-            } else if (probability.x <= diffuseProbability) {
-                directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, nee, next);
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
-                // clearcoat and specular lobe: the same function on the lobe's own parameters (physicallyBased.rlsl:253-272) — selected
-                // first and called once, so that lanes of both lobes run together and the code exists once
-                const bool coat = probability.x <= (diffuseProbability + clearCoatProbability);
-                const v3 lN = coat ? clearCoatN : N, lC = coat ? v3(clearCoatScale) : Cspec;
-                const float lNdotV = coat ? clearCoatNdotV : NdotV, lAlpha = coat ? clearCoatRoughnessAlpha : roughnessAlpha,
-                            lRough = coat ? clearCoatRoughness : roughness, lProb = coat ? clearCoatProbability : specularProbability;
-                directSpecularSample(in, sf.P, lN, V, lNdotV, lC, lAlpha, M.multiscatter_lut, lRough, lProb, probability.y, rand, frame, nee, next);
+                // diffuse, clearcoat or specular lobe (physicallyBased.rlsl:246-272).  The light is picked about the lobe's normal, once;
+                // clearcoat and specular are the same function on the lobe's own parameters — selected first and called once, so that
+                // lanes of both lobes run together and the code exists once
+                const bool diffuse = probability.x <= diffuseProbability;
+                const bool coat = !diffuse && probability.x <= (diffuseProbability + clearCoatProbability);
+                const v3 lN = coat ? clearCoatN : N;
+                const LightSample ls = computeLightSample(lN, probability.y, sf.P);
+                if (diffuse) {
+                    directDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, probability.y, rand, frame, ls, nee, next);
+                } else {
+                    const v3 lC = coat ? v3(clearCoatScale) : Cspec;
+                    const float lNdotV = coat ? clearCoatNdotV : NdotV, lAlpha = coat ? clearCoatRoughnessAlpha : roughnessAlpha,
+                                lRough = coat ? clearCoatRoughness : roughness, lProb = coat ? clearCoatProbability : specularProbability;
+                    directSpecularSample(in, sf.P, lN, V, lNdotV, lC, lAlpha, M.multiscatter_lut, lRough, lProb, probability.y, rand, frame, ls, nee, next);
+                }
             }
         }
         if (in.depth < pp.max_ray_depth) { // :277-330
