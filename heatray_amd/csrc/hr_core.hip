@@ -34,7 +34,8 @@ struct Geom {
     int mode = HR_TRIANGLES;
     float world[16];
     int frontFaceCW = 0, isOccluder = 1, material = 0;
-    char *dBlock = nullptr;
+    char *dBlock = nullptr;   // inside chunk `chunk` of the context's mesh arena
+    int chunk = -1;
     size_t blockBytes = 0;
     size_t off[7] = {0, 0, 0, 0, 0, 0, 0}; // byte offsets of pos, nrm, uv, tan, bit, col, idx in the block
     bool has[6] = {false, false, false, false, false, false};
@@ -149,6 +150,48 @@ struct hr_ctx {
     uint32_t *dZero = nullptr;    // a zero word (occlusion count of a pass's first step)
     Counters *dCounters = nullptr; // one per pass slot, contiguous (copied to the host in one piece in pass-through scenes)
 
+    // Mesh blocks come out of a grow-only arena: a hipMalloc per submesh is a device-wide synchronisation of ~0.1 ms each, which adds
+    // up for the scenes the reference loads (hundreds of submeshes).  A chunk is released when the last mesh in it has been removed.
+    struct MeshChunk {
+        char *base = nullptr;
+        size_t cap = 0, used = 0;
+        int live = 0;
+    };
+    std::vector<MeshChunk> meshChunks;
+    char *meshAlloc(size_t bytes, int *chunkOut)
+    {
+        const size_t need = (bytes + 255) & ~(size_t)255;
+        for (int pass = 0; pass < 2; ++pass) {
+            if (!meshChunks.empty()) {
+                MeshChunk &k = meshChunks.back();
+                if (k.base && k.cap - k.used >= need) {
+                    char *p = k.base + k.used;
+                    k.used += need, k.live += 1;
+                    *chunkOut = (int)meshChunks.size() - 1;
+                    return p;
+                }
+            }
+            MeshChunk k;
+            k.cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
+            if (hipMalloc((void **)&k.base, k.cap) != hipSuccess) return nullptr;
+            meshChunks.push_back(k);
+        }
+        return nullptr;
+    }
+    void meshRelease(int chunk)
+    {
+        if (chunk < 0 || chunk >= (int)meshChunks.size()) return;
+        MeshChunk &k = meshChunks[chunk];
+        if (--k.live <= 0 && k.base) {
+            hipFree(k.base);
+            k.base = nullptr, k.cap = k.used = 0, k.live = 0; // (the slot stays: other meshes refer to chunks by index)
+        }
+    }
+    void meshReleaseAll()
+    {
+        for (MeshChunk &k : meshChunks) hipFree(k.base);
+        meshChunks.clear();
+    }
     // scene (host mirror)
     std::vector<Geom> geoms;
     std::vector<Texture> textures;
@@ -489,7 +532,7 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->fbInternal);
     if (c->pinned) hipHostFree(c->pinned);
     hipFree(c->dDisplay);
-    for (Geom &g : c->geoms) hipFree(g.dBlock);
+    c->meshReleaseAll();
     for (int k = 0; k < 2; ++k) {
         if (c->stage[k]) hipHostFree(c->stage[k]);
         if (c->stageEv[k]) hipEventDestroy(c->stageEv[k]);
@@ -820,7 +863,8 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     g.off[6] = total;
     total += ((size_t)g.nIdx * 4 + 15) & ~(size_t)15;
     g.blockBytes = total;
-    HIP_TRY(c, hipMalloc((void **)&g.dBlock, total ? total : 16));
+    g.dBlock = c->meshAlloc(total ? total : 16, &g.chunk);
+    if (!g.dBlock) FAIL(c, HR_ERR_DEVICE, "out of device memory for a mesh block");
     // (the 16-byte alignment padding behind each range is never uploaded, yet the tree cache's content hash covers the whole block:
     // recycled device memory there made the key differ from run to run)
     HIP_TRY(c, hipMemsetAsync(g.dBlock, 0, total ? total : 16, c->stream));
@@ -833,7 +877,7 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     }
     if (rc == HR_OK && g.nIdx) rc = stagedUpload(c, g.dBlock + g.off[6], (const char *)d->indices, (size_t)g.nIdx * 4);
     if (rc != HR_OK) {
-        hipFree(g.dBlock);
+        c->meshRelease(g.chunk);
         return rc;
     }
     c->geoms.push_back(g);
@@ -848,7 +892,7 @@ int hr_geom_remove(hr_ctx *c, hr_geom_id id)
     if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive) FAIL(c, HR_ERR_INVALID, "bad geom id");
     for (int k = 0; k < 2; ++k) // an upload of this mesh may still be in flight (nothing to wait for when the staging ring is idle)
         if (c->stageBusy[k] && hipEventQuery(c->stageEv[k]) != hipSuccess) HIP_TRY(c, hipEventSynchronize(c->stageEv[k]));
-    hipFree(c->geoms[id].dBlock);
+    c->meshRelease(c->geoms[id].chunk);
     c->geoms[id] = Geom();
     c->committed = false, c->topologyDirty = true;
     return HR_OK;
@@ -868,7 +912,7 @@ int hr_scene_clear(hr_ctx *c)
     ENTER(c);
     for (int k = 0; k < 2; ++k)
         if (c->stageBusy[k] && hipEventQuery(c->stageEv[k]) != hipSuccess) HIP_TRY(c, hipEventSynchronize(c->stageEv[k]));
-    for (Geom &g : c->geoms) hipFree(g.dBlock);
+    c->meshReleaseAll();
     c->geoms.clear();
     c->committed = false, c->topologyDirty = true;
     return HR_OK;
