@@ -51,12 +51,12 @@ def test_plain_start_with_two_gpus_launches_ranks_and_fails_loudly_without_devic
 
 @pytest.mark.gpu
 def test_two_rank_rehearsal_on_one_device():
-    r = _run(["--gpus", "2", "--quick", "--steps", "6", "--warmup", "1", "--workload", "c2", "--width", "512", "--height", "288"],
+    r = _run(["--gpus", "2", "--quick", "--steps", "70", "--warmup", "1", "--workload", "c2", "--width", "512", "--height", "288"],  # (two exchanges on the way + the final one)
              env={"HR_BENCH_ONE_DEVICE": "1"}, timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout.decode(errors="replace")[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["rehearsal_one_device"] is True and d["steps"] == 6
+    assert d["n_gpus"] == 2 and d["rehearsal_one_device"] is True and d["steps"] == 70
     assert "REHEARSAL" in d["metric"]
     assert d["value"] > 0 and d["extra"]["rays"] > 0
