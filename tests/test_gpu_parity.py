@@ -993,6 +993,9 @@ def test_hundred_random_edit_steps_refit_and_rebuild(golden):
             assert bool(gi.refitted) == expect_refit, (step, kind)
         refits += int(gi.refitted)
         rebuilds += int(not gi.refitted)
+        # the tree-quality figure the guard acts on: 1 right after a build, at most the guard's 1.25 for a tree that was kept
+        if gi.n_triangles > 4:
+            assert (abs(gi.box_area_ratio - 1.0) < 1e-3) if not gi.refitted else (0.0 < gi.box_area_ratio <= 1.25 * 1.001), (step, kind, gi.refitted, gi.box_area_ratio)
         lo, hi = np.array(gi.aabb_min), np.array(gi.aabb_max)
         org = rng.uniform(lo - 0.2, hi + 0.2, (n_rays, 3)).astype(np.float32)
         tgt = rng.uniform(lo, hi, (n_rays, 3))
