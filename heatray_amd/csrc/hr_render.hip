@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const
 //
 //   k_shade_sort            one lane per closest-hit ray: a ray that hit nothing runs its defaultPrimitive's shader right here (the
 //                           environment lookup; nothing at all for rl_NullPrimitive); a ray that hit something is appended to its
-//                           pass's hit list — PBR hits from the front, glass hits from the back.  40 VGPRs, bandwidth-bound.
+//                           pass's hit list — PBR hits from the front, glass hits from the back.  52 VGPRs, bandwidth-bound.
 //   k_shade_hit<MODE, 0>    physicallyBased.rlsl on the PBR hit lists: every lane of every wave runs the material shader
 //   k_shade_hit<MODE, 1>    glass.rlsl on the glass hit lists (launched only when the scene has a glass material)
 //
