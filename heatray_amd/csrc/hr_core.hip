@@ -6,6 +6,7 @@
 #include "hr_kernels.h"
 #include "hr_trace.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -144,6 +145,7 @@ struct hr_ctx {
     // Passes requested but not yet injected: when a shard is small (multi-GPU tiles, small frames) several passes are
     // injected per macro step so that every launch still carries about a full 1080p pass worth of rays.
     std::deque<hr_pass_params> pendingInject;
+    unsigned long long oldestWaitingNs = 0; // steady-clock time of the oldest pass request not yet completed by a drain (0: none)
     int injectBatch = 1;
     int lastDepth = -1;
     unsigned long long injected = 0;
@@ -1926,6 +1928,7 @@ static int drainPipeline(hr_ctx *c)
     int rc = resolveReady(c);
     if (rc) return rc;
     if (occupiedSlots(c) > 0) FAIL(c, HR_ERR_DEVICE, "internal: finished passes left unresolved");
+    c->oldestWaitingNs = 0;
     // whatever the caller does next on its stream (clear, scene edits, new tables) has to be seen by the groups
     for (int g = 0; g < kMaxGroups; ++g) c->groups[g].needUserSync = true;
     return HR_OK;
@@ -1989,6 +1992,8 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
             }
     }
     c->pendingInject.push_back(*pp);
+    if (c->oldestWaitingNs == 0)
+        c->oldestWaitingNs = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     // a macro step is launched once enough passes are waiting to fill it; each group holds batch x stages passes
     const int stages = stagesOf(c, *pp);
     const int batch = batchFor(c, stages);
@@ -2073,8 +2078,26 @@ int hr_readback_progressive(hr_ctx *c, const float **rgba, int32_t *w, int32_t *
     ENTER(c);
     if (c->W <= 0 || !rgba) FAIL(c, HR_ERR_INVALID, "no frame");
     const size_t bytes = (size_t)c->W * c->H * 4 * sizeof(float);
+    // Passes wait to be injected a batch at a time (hr_frame_pass_batch) and advance one stage per macro step, and macro steps are
+    // driven by the passes that follow.  A caller that issues a pass per displayed frame — the viewer at its refresh rate — must not
+    // wait for a batch to fill, nor for ten more passes to push this one through its stages: when the oldest unfinished request is
+    // more than 4 ms old AND no group has work in flight on the device, everything requested is completed now (enqueued, not waited
+    // for).  A caller that issues passes faster than the device renders them never meets both conditions for long: its passes keep
+    // travelling in full batches through a full pipeline.
+    int rc = HR_OK;
+    if (c->oldestWaitingNs != 0 && (!c->pendingInject.empty() || occupiedSlots(c) > 0)) {
+        const unsigned long long now = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        if (now - c->oldestWaitingNs > 4000000ull) {
+            bool idle = true;
+            for (int g = 0; g < c->nGroups && idle; ++g) idle = hipStreamQuery(c->groups[g].stream) == hipSuccess;
+            if (idle) {
+                rc = drainPipeline(c);
+                if (rc) return rc;
+            }
+        }
+    }
     // no drain: the resolves enqueued so far are ordered before this copy on the ctx stream
-    int rc = ensureLagged(c, c->progFrame, bytes, false);
+    rc = ensureLagged(c, c->progFrame, bytes, false);
     if (rc) return rc;
     const int k = beginLagged(c->progFrame);
     HIP_TRY(c, hipMemcpyAsync(c->progFrame.pinned[k], c->fb(), bytes, hipMemcpyDeviceToHost, c->stream));

@@ -1214,6 +1214,27 @@ def test_progressive_readback_never_drains_and_holds_complete_passes(golden, mon
     assert n == 0
 
 
+def test_a_slow_caller_does_not_wait_for_a_batch_to_fill(golden):
+    # Passes are injected a batch at a time (12 x 1080p paths per macro step; 32 passes on a frame this small).  A caller that issues
+    # ONE pass and then only asks for pixels — the viewer at its refresh rate — must still get that pass: with an idle device,
+    # hr_readback_progressive launches what is waiting instead of leaving it queued until a batch is full.
+    import time
+    sc = scenes.multi_material(64, 48, bounces=4, passes=64)
+    g, o = core.create_engine(), oracle_lib.engine()
+    for eng in (g, o):
+        sc.apply(eng, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    assert g.pass_batch(sc.options.max_ray_depth) > 1
+    for k in range(3):                                       # one pass per "frame", three frames
+        g.render_pass(sc.options.pass_params(k))
+        o.render_pass(sc.options.pass_params(k))
+        t0, n, buf = time.perf_counter(), 0, None
+        while n < k + 1 and time.perf_counter() - t0 < 5.0:
+            buf, n = g.readback_progressive()
+            time.sleep(0.002)
+        assert n == k + 1, f"pass {k} was still waiting for a batch after 5 s"
+        assert buf.tobytes() == o.readback().tobytes()
+
+
 def test_large_scene_3m_triangles(golden):
     # maximum-size end of the range (tools/big_scene_check.py goes to 30 M): device LBVH + collapse of 3 M triangles, hits against
     # the oracle's own tree and a render, bit for bit
