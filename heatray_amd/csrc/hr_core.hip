@@ -344,6 +344,20 @@ static int quiesce(hr_ctx *c)
     } while (0)
 
 static int occupiedSlots(const hr_ctx *c, int group = -1);
+// Batching and the pass pipeline are driven by the passes that follow.  A caller that issues ONE pass per displayed frame (the viewer
+// at its refresh rate) must not wait for a batch to fill, nor for ten more passes to push this one through its stages: when the oldest
+// unfinished request is more than 4 ms old AND no group has work in flight on the device, everything requested is completed now
+// (enqueued, not waited for).  A caller that issues passes faster than the device renders them never meets both conditions for long:
+// its passes keep travelling in full batches through a full pipeline.  Called by the progressive (display) read-backs.
+static int completeForSlowCaller(hr_ctx *c)
+{
+    if (c->oldestWaitingNs == 0 || (c->pendingInject.empty() && occupiedSlots(c) == 0)) return HR_OK;
+    const unsigned long long now = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (now - c->oldestWaitingNs <= 4000000ull) return HR_OK;
+    for (int g = 0; g < c->nGroups; ++g)
+        if (hipStreamQuery(c->groups[g].stream) != hipSuccess) return HR_OK;
+    return drainPipeline(c);
+}
 static void freeLagged(hr_ctx::Lagged &L)
 {
     for (int k = 0; k < 3; ++k) {
@@ -662,7 +676,9 @@ int hr_display_readback(hr_ctx *c, const hr_display_params *params, int32_t form
         c->displayBytes = need;
     }
     if (format & HR_DISPLAY_PROGRESSIVE) { // lagged, like hr_readback_progressive
-        int rc = ensureLagged(c, c->progDisplay, need, true);
+        int rc = completeForSlowCaller(c);
+        if (rc) return rc;
+        rc = ensureLagged(c, c->progDisplay, need, true);
         if (rc) return rc;
         const int k = beginLagged(c->progDisplay);
         rc = hr_display(c, params, format, c->progDisplay.dev[k]);
@@ -2078,24 +2094,8 @@ int hr_readback_progressive(hr_ctx *c, const float **rgba, int32_t *w, int32_t *
     ENTER(c);
     if (c->W <= 0 || !rgba) FAIL(c, HR_ERR_INVALID, "no frame");
     const size_t bytes = (size_t)c->W * c->H * 4 * sizeof(float);
-    // Passes wait to be injected a batch at a time (hr_frame_pass_batch) and advance one stage per macro step, and macro steps are
-    // driven by the passes that follow.  A caller that issues a pass per displayed frame — the viewer at its refresh rate — must not
-    // wait for a batch to fill, nor for ten more passes to push this one through its stages: when the oldest unfinished request is
-    // more than 4 ms old AND no group has work in flight on the device, everything requested is completed now (enqueued, not waited
-    // for).  A caller that issues passes faster than the device renders them never meets both conditions for long: its passes keep
-    // travelling in full batches through a full pipeline.
-    int rc = HR_OK;
-    if (c->oldestWaitingNs != 0 && (!c->pendingInject.empty() || occupiedSlots(c) > 0)) {
-        const unsigned long long now = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-        if (now - c->oldestWaitingNs > 4000000ull) {
-            bool idle = true;
-            for (int g = 0; g < c->nGroups && idle; ++g) idle = hipStreamQuery(c->groups[g].stream) == hipSuccess;
-            if (idle) {
-                rc = drainPipeline(c);
-                if (rc) return rc;
-            }
-        }
-    }
+    int rc = completeForSlowCaller(c);
+    if (rc) return rc;
     // no drain: the resolves enqueued so far are ordered before this copy on the ctx stream
     rc = ensureLagged(c, c->progFrame, bytes, false);
     if (rc) return rc;
