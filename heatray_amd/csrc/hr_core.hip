@@ -303,7 +303,7 @@ struct hr_ctx {
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
-    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1, tuneSteal = 1;
+    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1, tuneSteal = 1, tuneFetchPrimary = 256, tuneFetchGate = 8;
     LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass, tuneSplitShade == 0}; }
 };
 
@@ -491,7 +491,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade), get("guard=", c->tuneGuardPct), get("steal=", c->tuneSteal);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade), get("guard=", c->tuneGuardPct), get("steal=", c->tuneSteal), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -1807,7 +1807,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
     tbl.fetchMax = c->tuneFetchMax > 0 ? c->tuneFetchMax : 1, tbl.fetchMin = c->tuneFetchMin > 0 ? c->tuneFetchMin : 1;
     tbl.staticPerWave = c->tuneStaticDeal, tbl.hasGlass = c->hasGlass ? 1 : 0;
-    tbl.poolTail = tbl.poolHead = tbl.idleSeen = 0, tbl.pool = G.dPool, tbl.pad3 = 0;
+    tbl.poolTail = tbl.poolHead = tbl.idleSeen = 0, tbl.pool = G.dPool;
+    tbl.primaryFromSeg = n, tbl.fetchMaxPrimary = ((c->tuneFetchPrimary > 0 ? c->tuneFetchPrimary : 1) & 0xFFFF) | ((c->tuneFetchGate & 0xFFFF) << 16); // (primaryFromSeg is set below, once the injected passes' places in the table are known)
     tbl.poolCap = (HR_STEAL && c->tuneSteal && c->tuneSplitShade) ? kStealPoolCap : 0u; // (the single shading kernel of shade=0 does not know the merge records)
     int injectedSegs[kMaxSegs];
     int nInjectedSegs = 0;
@@ -1841,6 +1842,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         for (int j = 0; j < nInjected; ++j)
             if (order[k] == injectedSlots[j]) injectedSegs[nInjectedSegs++] = k;
     }
+    if (nInjectedSegs > 0) tbl.primaryFromSeg = injectedSegs[0]; // (the table is in pass order: the passes injected now are its last entries)
     StepTable *dTbl = G.dTables + ring;
     const size_t tblBytes = offsetof(StepTable, seg) + (size_t)n * sizeof(SegDev);
     HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, tblBytes, hipMemcpyHostToDevice, G.stream));

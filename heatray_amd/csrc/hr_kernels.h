@@ -76,7 +76,8 @@ struct StepTable {
     uint32_t idleSeen;     // some wave has run out of work: donations start
     uint32_t poolCap;      // entries of `pool`; 0: no stealing in this launch
     unsigned long long *pool;
-    unsigned long long pad3;
+    int32_t primaryFromSeg;  // passes [primaryFromSeg, nSeg) were injected this step: their closest-hit queues hold camera rays
+    int32_t fetchMaxPrimary; // chunk size of the work fetch inside that (coherent) part of the index space: low 16 bits; high 16 bits: how many such chunks per resident wave the part must hold for it to be used
     SegDev seg[kMaxSegs];
 };
 

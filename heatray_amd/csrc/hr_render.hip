@@ -312,6 +312,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     const unsigned long long ltMask = (1ull << lane) - 1ull;
     const int kRefill = tbl->refillLanes, kTriPhase = tbl->triPhaseLanes;
     const uint32_t fetchMax = (uint32_t)tbl->fetchMax, fetchMin = (uint32_t)tbl->fetchMin;
+    // Camera rays are coherent: a wave that works through a LONGER run of consecutive pixels refills its idle lanes with neighbours of
+    // the rays it still holds, so its lanes keep walking the same part of the tree (a launch of camera rays alone: 9.3 instead of 11.0 ms
+    // with 256- instead of 64-ray chunks); the incoherent rays of later stages gain nothing from that and balance better in small chunks
+    // (profiles/r3am_fetch_chunks.txt).  The passes injected this step are the last entries of the table.
+    // (only when every resident wave gets at least eight such chunks: with fewer — a tile shard — the coarser grain costs more in balance
+    // than the coherence brings)
+    const uint32_t primaryStart = tbl->primaryFromSeg < tbl->nSeg ? segStart[2 * tbl->primaryFromSeg] : 0xFFFFFFFFu;
+    const uint32_t fmPrimary = (uint32_t)tbl->fetchMaxPrimary & 0xFFFFu, fmGate = (uint32_t)tbl->fetchMaxPrimary >> 16;
+    const bool longRuns = primaryStart < total && (unsigned long long)(total - primaryStart) >= (unsigned long long)fmGate * fmPrimary * gridDim.x * kTraceWaves;
+    const uint32_t fetchMaxPrimary = (longRuns && fmPrimary > fetchMax) ? fmPrimary : fetchMax;
     const uint32_t wavesTimes2 = 2u * gridDim.x * kTraceWaves;
     uint32_t lastBase = 0; // wave-uniform: where the global cursor stood at this wave's previous reservation
 
@@ -385,7 +395,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     }
                     // chunk ~ (work left) / (2 x waves), from the cursor value this wave saw last (any size is valid)
                     uint32_t chunk = (total - lastBase) / wavesTimes2;
-                    chunk = chunk > fetchMax ? fetchMax : (chunk < fetchMin ? fetchMin : chunk);
+                    const uint32_t fm = lastBase >= primaryStart ? fetchMaxPrimary : fetchMax;
+                    chunk = chunk > fm ? fm : (chunk < fetchMin ? fetchMin : chunk);
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&tbl->traceHead, chunk);
                     base = __shfl(base, 0);
