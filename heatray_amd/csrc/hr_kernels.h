@@ -60,7 +60,8 @@ struct SegDev {
 #ifndef HR_MAX_SEGS
 #define HR_MAX_SEGS 320
 #endif
-static const int kMaxSegs = HR_MAX_SEGS; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
+static const int kMaxSegs = HR_MAX_SEGS;
+static const int kTraceHeadsMax = 64; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
 struct StepTable {
     uint32_t traceHead; // work cursor of the persistent trace kernel (reset with every table upload)
     int32_t nSeg;
@@ -77,6 +78,13 @@ struct StepTable {
     uint32_t poolCap;      // entries of `pool`; 0: no stealing in this launch
     unsigned long long *pool;
     int32_t primaryFromSeg;  // passes [primaryFromSeg, nSeg) were injected this step: their closest-hit queues hold camera rays
+    // The work cursor of k_trace, in up to kTraceHeadsMax copies: the index space of a launch is cut into 2^headsLog2 equal ranges, each with a
+    // cursor on a cache line of its own.  ONE cursor serialises at ~12 ns per atomic: a launch of 25 M camera rays in 64-ray chunks
+    // needs 390 k of them, 4.7 ms of a 10 ms launch.  Workgroups start at range (blockIdx mod the number of ranges) — workgroups b and b + 8 share
+    // an XCD, so an XCD's L2 sees two ranges — and move on to the next range when theirs is used up.
+    uint32_t heads[kTraceHeadsMax * 32];
+    uint32_t headsLog2; // 2^headsLog2 ranges are in use (HR_TUNE heads=)
+    uint32_t padH[31];
     int32_t fetchMaxPrimary; // chunk size of the work fetch inside that (coherent) part of the index space: low 16 bits; high 16 bits: how many such chunks per resident wave the part must hold for it to be used
     SegDev seg[kMaxSegs];
 };

@@ -322,7 +322,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     const uint32_t fmPrimary = (uint32_t)tbl->fetchMaxPrimary & 0xFFFFu, fmGate = (uint32_t)tbl->fetchMaxPrimary >> 16;
     const bool longRuns = primaryStart < total && (unsigned long long)(total - primaryStart) >= (unsigned long long)fmGate * fmPrimary * gridDim.x * kTraceWaves;
     const uint32_t fetchMaxPrimary = (longRuns && fmPrimary > fetchMax) ? fmPrimary : fetchMax;
-    const uint32_t wavesTimes2 = 2u * gridDim.x * kTraceWaves;
+    const uint32_t headsLog2 = tbl->headsLog2, nHeads = 1u << headsLog2;
+    const uint32_t wavesTimes2PerRange = ((2u * gridDim.x * kTraceWaves) >> headsLog2) + 1u;
+    uint32_t home = blockIdx.x & (nHeads - 1u); // wave-uniform: the range of the index space this wave fetches from
     uint32_t lastBase = 0; // wave-uniform: where the global cursor stood at this wave's previous reservation
 
     // ---- per-lane traversal state (one ray per lane, refilled from the work pool when a lane finishes)
@@ -393,14 +395,29 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #endif
                         break;
                     }
-                    // chunk ~ (work left) / (2 x waves), from the cursor value this wave saw last (any size is valid)
-                    uint32_t chunk = (total - lastBase) / wavesTimes2;
-                    const uint32_t fm = lastBase >= primaryStart ? fetchMaxPrimary : fetchMax;
-                    chunk = chunk > fm ? fm : (chunk < fetchMin ? fetchMin : chunk);
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&tbl->traceHead, chunk);
-                    base = __shfl(base, 0);
-                    if (base >= total) {
+                    // the next chunk of this wave's current range, or of the next range that still has work (hr_kernels.h: StepTable::heads)
+                    bool got = false;
+                    uint32_t base = 0, hi = 0;
+                    for (uint32_t tries = 0; tries < nHeads; ++tries) {
+                        const uint32_t rLo = (uint32_t)(((unsigned long long)total * home) >> headsLog2);
+                        const uint32_t rHi = (uint32_t)(((unsigned long long)total * (home + 1u)) >> headsLog2);
+                        // chunk ~ (work left in the range) / (2 x the waves that started on it), from the cursor value this wave saw last
+                        const uint32_t left = (lastBase >= rLo && lastBase < rHi) ? rHi - lastBase : rHi - rLo;
+                        uint32_t chunk = left / wavesTimes2PerRange;
+                        const uint32_t fm = (tries == 0 && lastBase >= primaryStart) ? fetchMaxPrimary : fetchMax;
+                        chunk = chunk > fm ? fm : (chunk < fetchMin ? fetchMin : chunk);
+                        uint32_t off = 0;
+                        if (lane == 0) off = atomicAdd(&tbl->heads[home * 32u], chunk);
+                        off = __shfl(off, 0);
+                        if (off < rHi - rLo) {
+                            base = rLo + off;
+                            hi = (off + chunk < rHi - rLo) ? base + chunk : rHi;
+                            got = true;
+                            break;
+                        }
+                        home = (home + 1u) & (nHeads - 1u);
+                    }
+                    if (!got) {
                         exhausted = true;
 #ifdef HR_TAILPROF
                         tExh = wall_clock64();
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     }
                     lastBase = base;
                     poolLo = base;
-                    poolHi = (base + chunk < total) ? base + chunk : total;
+                    poolHi = hi;
                 }
                 const uint32_t avail = poolHi - poolLo;
                 const uint32_t rank = (uint32_t)__popcll(idleMask & ltMask);
