@@ -210,7 +210,17 @@ def convergence_leg(core, sc, dev, stream, cap, n_runs, budget_s=None):
     from heatray_amd import convergence as cv
     passes_before = sc.options.max_render_passes
     sc.options.max_render_passes = cv.REFERENCE_PASSES          # sample tables long enough for the reference render
-    eng = core.create_engine(device_id=dev.index, stream=stream)
+    # One pass per pipeline step for this engine: the library otherwise collects 12 passes of a 1080p frame per step, the buffer
+    # would then advance 12 passes at a time and err(n) could only be read at multiples of 12.
+    tune_before = os.environ.get("HR_TUNE")
+    os.environ["HR_TUNE"] = (tune_before + "," if tune_before else "") + "batch=1"
+    try:
+        eng = core.create_engine(device_id=dev.index, stream=stream)
+    finally:
+        if tune_before is None:
+            del os.environ["HR_TUNE"]
+        else:
+            os.environ["HR_TUNE"] = tune_before
     sc.apply(eng)
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
     eng.bind_external_frame(fb.data_ptr())
