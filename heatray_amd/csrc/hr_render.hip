@@ -304,6 +304,15 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #endif
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
+#if HR_LDS_NODES && !HR_NODE32
+    __shared__ uint4 topLds[HR_LDS_NODES * 3];
+    const int topCount = S.nNodes < HR_LDS_NODES ? S.nNodes : HR_LDS_NODES;
+    for (int i = (int)threadIdx.x; i < topCount * 3; i += kTraceBlock) topLds[i] = reinterpret_cast<const uint4 *>(nodes)[(i / 3) * 4 + i % 3];
+    // (buildSegStarts below ends with a workgroup barrier)
+#else
+    const uint4 *topLds = nullptr;
+    const int topCount = 0;
+#endif
     buildSegStarts(tbl, segStart, false);
     const int nSeg2 = 2 * tbl->nSeg;
     const uint32_t total = segStart[nSeg2];
@@ -740,7 +749,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #if HR_NODE32
                 nodeStep4(nodes, cur, sp, stackLane, ovf, rk, gk, tmin, tlim);
 #else
-                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny);
+                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny, topLds, topCount);
 #endif
             }
             // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already

@@ -20,6 +20,9 @@ namespace hr {
 #define HR_STACK_LDS 16
 #endif
 static const int kStackLDS = HR_STACK_LDS; // entries per lane kept in LDS
+#ifndef HR_LDS_NODES
+#define HR_LDS_NODES 0 // nodes of the top of the tree a k_trace workgroup copies to LDS (experiment)
+#endif
 // A 4-wide node pushes up to 3 entries and the ray descends one level, so a path through L inner levels holds at most 3 L
 // entries.  The collapse opens the child with the largest area, so an unopened sibling sits only ONE binary level deeper:
 // along such a path the 4-wide depth equals the binary depth, and that is bounded by the key length of the radix tree:
@@ -208,11 +211,24 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
 // One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that
 // is hit and push the others farthest first (so the nearer one pops first); pop when nothing is hit.
 HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim,
-                   bool anyHit = false)
+                   bool anyHit = false, const uint4 *topLds = nullptr, int topCount = 0)
 {
-    const Node4 &n = nodes[cur];
-    const float4 a = n.a;
-    const uint4 qb = n.b, qc = n.c;
+    float4 a;
+    uint4 qb, qc;
+#if HR_LDS_NODES
+    if (cur < topCount) {
+        // the first nodes of the array are the top of the tree (level order): the workgroup holds a copy of their 48 used bytes in LDS,
+        // read without the texture addresser
+        const uint4 t0 = topLds[cur * 3], t1 = topLds[cur * 3 + 1], t2 = topLds[cur * 3 + 2];
+        a = make_float4(__uint_as_float(t0.x), __uint_as_float(t0.y), __uint_as_float(t0.z), __uint_as_float(t0.w));
+        qb = t1, qc = t2;
+    } else
+#endif
+    {
+        const Node4 &n = nodes[cur];
+        a = n.a;
+        qb = n.b, qc = n.c;
+    }
     const uint32_t meta = __float_as_uint(a.w);
     const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
     const int innerBase = (int)qc.z, leafKey = (int)qc.w;
