@@ -98,6 +98,11 @@ struct hr_ctx {
         int group = 0;           // pipeline group (worker stream) the pass runs on
         hipEvent_t evFinal = nullptr;    // recorded on the worker stream after the pass's last stage
         hipEvent_t evResolved = nullptr; // recorded on the caller's stream after the pass buffer was added to the frame
+        // Passes that finish in one macro step, and passes one k_resolve launch adds, share ONE recorded event (a record or a wait is a
+        // packet of ~4-8 us on its stream: twelve of each per batch delayed the resolve of a batch by 0.1 ms and its next injection by as
+        // much).  The slot that owns the recorded event may be reused later; whoever waits has enqueued the wait before that (same call).
+        hipEvent_t finalEv = nullptr;    // the event to wait on for this pass's last stage (some slot's evFinal)
+        hipEvent_t resolvedEv = nullptr; // ... for the launch that added this pass buffer to the frame (some slot's evResolved)
         int step = 0, nIter = 0;
         unsigned long long order = 0; // injection order (passes resolve in this order)
         hr_pass_params pp{};
@@ -1705,12 +1710,17 @@ static int resolveReady(hr_ctx *c)
             bufs.buf[bufs.n++] = next->passbuf;
         }
         if (bufs.n == 0) return HR_OK;
-        for (int k = 0; k < bufs.n; ++k) HIP_TRY(c, hipStreamWaitEvent(c->stream, ready[k]->evFinal, 0));
+        for (int k = 0; k < bufs.n; ++k) {
+            bool seen = false;
+            for (int j = 0; j < k; ++j) seen = seen || ready[j]->finalEv == ready[k]->finalEv;
+            if (!seen) HIP_TRY(c, hipStreamWaitEvent(c->stream, ready[k]->finalEv, 0));
+        }
         c->timeBegin(HR_KERNEL_RESOLVE, c->stream);
         launchResolve(cfg, fr, bufs);
         c->timeEnd(c->stream);
+        HIP_TRY(c, hipEventRecord(ready[bufs.n - 1]->evResolved, c->stream));
         for (int k = 0; k < bufs.n; ++k) {
-            HIP_TRY(c, hipEventRecord(ready[k]->evResolved, c->stream));
+            ready[k]->resolvedEv = ready[bufs.n - 1]->evResolved;
             ready[k]->finished = false, ready[k]->everResolved = true;
             ready[k]->resolvedAt = c->nextResolveOrder;
             c->nextResolveOrder++;
@@ -1732,6 +1742,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         G.needUserSync = false;
     }
     int injectedSlots[kMaxSegs];
+    hipEvent_t waited[kMaxSegs];
     int nInjected = 0;
     for (int k = 0; k < nInject; ++k) {
         const hr_pass_params pp = c->pendingInject.front();
@@ -1759,7 +1770,12 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             int rc = allocSlot(c, ps);
             if (rc) return rc;
         }
-        if (ps.everResolved) HIP_TRY(c, hipStreamWaitEvent(G.stream, ps.evResolved, 0)); // the pass buffer is free again
+        if (ps.everResolved) { // the pass buffer is free again once the launch that resolved it has run
+            bool seen = false;
+            for (int j = 0; j < nInjected; ++j) seen = seen || waited[j] == ps.resolvedEv;
+            if (!seen) HIP_TRY(c, hipStreamWaitEvent(G.stream, ps.resolvedEv, 0));
+        }
+        waited[nInjected] = ps.everResolved ? ps.resolvedEv : nullptr;
         ps.active = true, ps.finished = false, ps.group = g, ps.step = 0, ps.nIter = pp.max_ray_depth + 1, ps.pp = pp;
         ps.order = c->injected++;
         injectedSlots[nInjected++] = slot;
@@ -1778,6 +1794,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         if (N >= 2 && G.statusUsed[(N - 2) % kTableRing]) {
             const int ring = (int)((N - 2) % kTableRing);
             HIP_TRY(c, hipEventSynchronize(G.statusEv[ring]));
+            hr_ctx::PassSlot *endedEarly[kMaxSlots];
+            int nEndedEarly = 0;
             const uint32_t *snap = G.hQCount + (size_t)ring * kMaxSlots * kMaxBounceSlots;
             for (int i = 0; i < kMaxSlots; ++i) {
                 hr_ctx::PassSlot &ps = c->slots[i];
@@ -1786,9 +1804,14 @@ static int macroStep(hr_ctx *c, int g, int nInject)
                 const bool empty = st >= 2 && snap[(size_t)i * kMaxBounceSlots + ((st - 1) % kMaxBounceSlots)] == 0u;
                 if (empty) {
                     ps.active = false, ps.finished = true;
-                    HIP_TRY(c, hipEventRecord(ps.evFinal, G.stream));
+                    endedEarly[nEndedEarly++] = &ps;
                 }
             }
+            hr_ctx::PassSlot *owner = nullptr; // the newest of them: it is resolved last, so its event outlives the others' waits
+            for (int k = 0; k < nEndedEarly; ++k)
+                if (!owner || endedEarly[k]->order > owner->order) owner = endedEarly[k];
+            if (owner) HIP_TRY(c, hipEventRecord(owner->evFinal, G.stream));
+            for (int k = 0; k < nEndedEarly; ++k) endedEarly[k]->finalEv = owner->evFinal;
         }
     }
     // table of the group's in-flight passes, oldest first
@@ -1864,15 +1887,19 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     c->timeBegin(HR_KERNEL_SHADE, G.stream);
     launchShade(cfg, c->dScene, dTbl, c->dStats);
     c->timeEnd(G.stream);
+    hr_ctx::PassSlot *ended[kMaxSegs];
+    int nEnded = 0;
     for (int k = 0; k < n; ++k) {
         hr_ctx::PassSlot &ps = c->slots[order[k]];
         if (!c->hasPassthrough && ps.step >= ps.nIter) {
             ps.active = false, ps.finished = true;
-            HIP_TRY(c, hipEventRecord(ps.evFinal, G.stream));
+            ended[nEnded++] = &ps;
         } else {
             ps.step++;
         }
     }
+    if (nEnded > 0) HIP_TRY(c, hipEventRecord(ended[nEnded - 1]->evFinal, G.stream)); // one event for the passes whose last stage this step was
+    for (int k = 0; k < nEnded; ++k) ended[k]->finalEv = ended[nEnded - 1]->evFinal;
     if (c->hasPassthrough) { // snapshot of the queue lengths after this step, read two steps from now
         uint32_t *dst = G.hQCount + (size_t)ring * kMaxSlots * kMaxBounceSlots;
         HIP_TRY(c, hipMemcpy2DAsync(dst, sizeof(uint32_t) * kMaxBounceSlots, &c->dCounters[0].qCount[0], sizeof(Counters),
