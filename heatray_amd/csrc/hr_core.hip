@@ -261,6 +261,7 @@ struct hr_ctx {
     struct Timed {
         int kind;
         hipEvent_t e0, e1;
+        bool e0Shared; // e0 is the e1 of the entry before (timeNext): one record between two kernels enqueued back to back
     };
     std::vector<Timed> pending;
     std::vector<hipEvent_t> eventPool;
@@ -280,9 +281,17 @@ struct hr_ctx {
     void timeBegin(int kind, hipStream_t st)
     {
         if (!timeKernels) return;
-        Timed t{kind, getEvent(), getEvent()};
+        Timed t{kind, getEvent(), getEvent(), false};
         hipEventRecord(t.e0, st);
         pending.push_back(t);
+    }
+    // The kernel timed last ends and the next one begins at ONE event (a record is a packet of several microseconds between the two)
+    void timeNext(int kind, hipStream_t st)
+    {
+        if (!timeKernels) return;
+        const hipEvent_t mid = pending.back().e1;
+        hipEventRecord(mid, st);
+        pending.push_back(Timed{kind, mid, getEvent(), true});
     }
     void timeEnd(hipStream_t st)
     {
@@ -301,14 +310,15 @@ struct hr_ctx {
                 kernelMs[t.kind] += ms;
                 kernelLaunches[t.kind] += 1;
             }
-            eventPool.push_back(t.e0), eventPool.push_back(t.e1);
+            if (!t.e0Shared) eventPool.push_back(t.e0);
+            eventPool.push_back(t.e1);
         }
         pending.clear();
     }
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
-    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1, tuneSteal = 1, tuneFetchPrimary = 128, tuneFetchGate = 8, tuneHeads = 5;
+    int tuneTri = 2, tuneRefill = 8, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1, tuneSteal = 1, tuneFetchPrimary = 128, tuneFetchGate = 8, tuneHeads = 5, tuneSlowMs = 4;
     LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass, tuneSplitShade == 0}; }
 };
 
@@ -358,7 +368,7 @@ static int completeForSlowCaller(hr_ctx *c)
 {
     if (c->oldestWaitingNs == 0 || (c->pendingInject.empty() && occupiedSlots(c) == 0)) return HR_OK;
     const unsigned long long now = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (now - c->oldestWaitingNs <= 4000000ull) return HR_OK;
+    if (c->tuneSlowMs <= 0 || now - c->oldestWaitingNs <= 1000000ull * (unsigned long long)c->tuneSlowMs) return HR_OK; // (HR_TUNE slow=0: never, for tests of the lag itself)
     for (int g = 0; g < c->nGroups; ++g)
         if (hipStreamQuery(c->groups[g].stream) != hipSuccess) return HR_OK;
     return drainPipeline(c);
@@ -496,7 +506,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade), get("guard=", c->tuneGuardPct), get("steal=", c->tuneSteal), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade), get("guard=", c->tuneGuardPct), get("steal=", c->tuneSteal), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -1874,17 +1884,23 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     HIP_TRY(c, hipEventRecord(G.tableCopied[ring], G.stream));
     G.tableUsed[ring] = true;
     if (c->pending.size() > 8192) c->drainTimes();
+    bool timing = false; // (the kernels of a step are enqueued back to back: n + 1 timing events for n kernels)
     for (int j0 = 0; j0 < nInjectedSegs; j0 += kMaxBatch) { // one launch for the passes injected this step
         SegList segs{};
         for (int j = j0; j < nInjectedSegs && segs.n < kMaxBatch; ++j) segs.seg[segs.n++] = injectedSegs[j];
-        c->timeBegin(HR_KERNEL_RAYGEN, G.stream);
+        if (timing)
+            c->timeNext(HR_KERNEL_RAYGEN, G.stream);
+        else
+            c->timeBegin(HR_KERNEL_RAYGEN, G.stream);
+        timing = true;
         launchRaygen(cfg, c->dScene, dTbl, segs, fr, c->dStats);
-        c->timeEnd(G.stream);
     }
-    c->timeBegin(HR_KERNEL_TRACE, G.stream);
+    if (timing)
+        c->timeNext(HR_KERNEL_TRACE, G.stream);
+    else
+        c->timeBegin(HR_KERNEL_TRACE, G.stream);
     launchTrace(cfg, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
-    c->timeEnd(G.stream);
-    c->timeBegin(HR_KERNEL_SHADE, G.stream);
+    c->timeNext(HR_KERNEL_SHADE, G.stream);
     launchShade(cfg, c->dScene, dTbl, c->dStats);
     c->timeEnd(G.stream);
     hr_ctx::PassSlot *ended[kMaxSegs];
