@@ -701,7 +701,9 @@ def test_full_size_config2_properties(golden):
                                   "fmin=16,fmax=256,refill=16,tri=8,blocks=3", "groups=4,batch=16",
                                   # round 3's knobs: the single shading kernel of rounds 1-2, every launch through the work cursor, every
                                   # launch dealt out statically
-                                  "shade=0", "sdeal=0,batch=3", "sdeal=1000000,groups=1"])
+                                  "shade=0", "sdeal=0,batch=3", "sdeal=1000000,groups=1",
+                                  # the work fetch: one cursor / 64 range cursors, camera rays in long / short chunks
+                                  "sdeal=0,heads=0,fprim=256,fgate=0", "sdeal=0,heads=6,fprim=32,fgate=0,fmin=16,batch=7"])
 def test_pipeline_scheduling_is_result_invariant(golden, monkeypatch, tune):
     # passes in flight on several streams, several passes per launch, chunked work fetch: the HDR buffer must not
     # depend on any of it (resolves happen in pass order; no float atomics)
