@@ -21,3 +21,18 @@ for w in 1 2 4 8; do echo "== W=$w steps=128"; tools/shards.sh $w 128 "" | tail 
 echo "shards done"
 python3 tools/commit_time.py > gpurun_out/r3z_commit_time.txt 2>&1
 tail -5 gpurun_out/r3z_commit_time.txt
+# fuzz campaign, leak check, throughput of the three estimators
+{
+  echo "== round 3 final build: fuzz campaign, leak check, estimator throughput (c3, 64 steps)"
+  HR_FUZZ_SEEDS=600 timeout -k 10 400 python3 -m pytest tests/test_gpu_fuzz.py -m gpu -q 2>&1 | tail -2
+  echo "HR_FUZZ_SEEDS=600 python -m pytest tests/test_gpu_fuzz.py -m gpu"
+  timeout -k 10 200 python3 tools/leak_check.py 2>&1 | tail -2
+  for est in reference env_mis all_lights; do
+    python3 bench.py --quick --steps 64 --warmup 12 --estimator $est > gpurun_out/est.json 2>/dev/null && python3 - $est <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/est.json"))
+print(f"{sys.argv[1]} {d['value']:.1f} Mrays/s {d['ms_per_step']:.3f} ms/pass {d['extra']['rays_per_path']:.2f} rays/path")
+PY
+  done
+} > gpurun_out/r3z_fuzz_leak_estimators.txt 2>&1
+echo "fuzz/leak/estimators done"
