@@ -27,7 +27,10 @@ static const int kStackLDS = HR_STACK_LDS; // entries per lane kept in LDS
 // entries.  The collapse opens the child with the largest area, so an unopened sibling sits only ONE binary level deeper:
 // along such a path the 4-wide depth equals the binary depth, and that is bounded by the key length of the radix tree:
 // 30 Morton bits + 28 index bits (n < 2^28) = 58 levels.
-static const int kMaxTreeLevels = 58;
+#ifndef HR_TREE_LEVELS
+#define HR_TREE_LEVELS 58
+#endif
+static const int kMaxTreeLevels = HR_TREE_LEVELS;
 static const int kStackOvf = 3 * kMaxTreeLevels + 2 - HR_STACK_LDS; // private overflow area (scratch; touched by 0.1 % of node steps on c3)
 static const int kSentinel = 0x7FFFFFFF;
 static const int kRefillLanes = 24; // refill a wave from the work pool once this many lanes are idle
