@@ -1835,7 +1835,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     const int ring = (int)(G.stepCounter++ % kTableRing);
     if (G.tableUsed[ring]) HIP_TRY(c, hipEventSynchronize(G.tableCopied[ring])); // staging entry free again (4 steps old)
     StepTable &tbl = G.hTables[ring];
-    tbl.traceHead = 0;
+    tbl.reserved0 = 0;
     std::memset(tbl.heads, 0, sizeof(tbl.heads));
     tbl.headsLog2 = (uint32_t)(c->tuneHeads < 0 ? 0 : (c->tuneHeads > 6 ? 6 : c->tuneHeads));
     tbl.nSeg = n;

@@ -63,7 +63,7 @@ struct SegDev {
 static const int kMaxSegs = HR_MAX_SEGS;
 static const int kTraceHeadsMax = 64; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
 struct StepTable {
-    uint32_t traceHead; // work cursor of the persistent trace kernel (reset with every table upload)
+    uint32_t reserved0; // (round 1-2: the single work cursor of k_trace; now `heads` below)
     int32_t nSeg;
     int32_t refillLanes;   // refill a wave from the work pool once this many lanes are idle
     int32_t triPhaseLanes; // run the triangle phase once this many lanes are blocked on a postponed leaf
