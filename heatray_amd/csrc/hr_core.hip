@@ -1217,6 +1217,7 @@ int hr_scene_commit(hr_ctx *c)
             // the traversal stack holds at most 3 entries per level of inner nodes (hr_trace.h)
             if (3 * cs.br.levels > kStackLDS + kStackOvf) FAIL(c, HR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
             if (cs.br.triSlots >= (1u << 28)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: triangle slots do not fit a 28-bit leaf reference");
+            if ((unsigned long long)cs.br.nNodes >= (1ull << 26)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: k_trace addresses nodes by a 32-bit byte offset (2^26 nodes of 64 bytes)");
             freeTree(c);
             c->tree = cs.br, cs.keepBuild = true;
             c->treeTris = nTris;

@@ -228,7 +228,8 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
     } else
 #endif
     {
-        const Node4 &n = nodes[cur];
+        // (a 32-bit byte offset from the wave-uniform base: one shift, and the load takes base + offset itself; node indices are < 2^26)
+        const Node4 &n = *reinterpret_cast<const Node4 *>(reinterpret_cast<const char *>(nodes) + (size_t)((uint32_t)cur << 6));
         a = n.a;
         qb = n.b, qc = n.c;
     }
