@@ -286,7 +286,7 @@ def main():
                     "sharded frame (no collective); the JSON line is marked emulated and is not a benchmark result")
     ap.add_argument("--converge", action="store_true", help="passes-to-converge p50 (BASELINE metric 2): no time budget for the leg (all --converge-runs "
                     "runs whatever they take); N = 1 only")
-    ap.add_argument("--converge-budget", type=float, default=200.0, help="wall-time budget in seconds of the convergence leg of the default run (reference "
+    ap.add_argument("--converge-budget", type=float, default=150.0, help="wall-time budget in seconds of the convergence leg of the default run (reference "
                     "render + runs; the leg stops early after >= 3 runs when it is used up and reports the number of runs made)")
     ap.add_argument("--estimator", default="reference", choices=["reference", "env_mis", "all_lights"], help="estimator of the timed region and of the convergence "
                     "leg: the reference's (BASELINE metric), or importance-sampled environment + one-sample MIS (include/hrcore.h)")
