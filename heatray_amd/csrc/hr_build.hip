@@ -332,6 +332,9 @@ HRD int deltaKey(const uint32_t *keys, int n, int i, int j)
     return __clz((int)(a ^ b));
 }
 
+#ifndef HR_COLLAPSE_DP
+#define HR_COLLAPSE_DP 1 // collapse the binary tree to 4-wide nodes by minimal summed node area (0: open the largest child twice, rounds 1-3a)
+#endif
 #ifndef HR_ROTATE_SWEEPS
 #define HR_ROTATE_SWEEPS 0 // tree-rotation sweeps over the binary tree before the collapse (experiment knob)
 #endif
@@ -369,8 +372,13 @@ __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ key
 
 // One bottom-up round: a node whose children were finished in an EARLIER launch gets its box.
 // stamp[i] = round in which node i was finished (0 = not yet); visibility comes from the kernel boundary.
+HRD float boxArea(const Box6 &b);
+// ... and the costs of the collapse to a 4-wide tree (k_collapse4): cost[i] = (C1, C2, C3, C4), Ck = the least sum of the surface areas of
+// the 4-wide nodes that can represent the subtree of binary node i when it may occupy up to k child slots of its 4-wide parent
+// (k = 1: it is a child itself, a node of its own; k >= 2: it may be opened and its two children share the slots).  A triangle costs
+// nothing: it is a child slot wherever it ends up.  Surface area = the probability that a ray visits the node (SAH).
 __global__ __launch_bounds__(256) void k_refit_round(const KNode *__restrict__ nodes, int nInternal, const Box6 *__restrict__ leafBox,
-                                                     Box6 *__restrict__ nodeBox, uint32_t *__restrict__ stamp, uint32_t round)
+                                                     Box6 *__restrict__ nodeBox, uint32_t *__restrict__ stamp, uint32_t round, float4 *__restrict__ cost)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nInternal || stamp[i] != 0u) return;
@@ -387,10 +395,19 @@ __global__ __launch_bounds__(256) void k_refit_round(const KNode *__restrict__ n
         u.hi[c] = fmax_(a.hi[c], b.hi[c]);
     }
     nodeBox[i] = u;
+    if (cost) {
+        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        const float4 cl = k.left < 0 ? z : cost[k.left], cr = k.right < 0 ? z : cost[k.right];
+        const float h2 = cl.x + cr.x;
+        const float h3 = fmin_(cl.x + cr.y, cl.y + cr.x);
+        const float h4 = fmin_(cl.x + cr.z, fmin_(cl.y + cr.y, cl.z + cr.x));
+        const float c1 = boxArea(u) + h4;
+        const float c2 = fmin_(c1, h2), c3 = fmin_(c2, h3), c4 = fmin_(c3, h4);
+        cost[i] = make_float4(c1, c2, c3, c4);
+    }
     stamp[i] = round;
 }
 
-HRD float boxArea(const Box6 &b);
 // Tree rotations (Kensler 2008) on the binary tree before it is collapsed: node N with children L, R may exchange R with one of
 // L's children (or L with one of R's) when that shrinks the surface area of the rebuilt child — the LBVH splits by Morton prefix,
 // blind to the boxes, and a rotation repairs the worst of it.  One launch handles the nodes of ONE stamp value (the round of the
@@ -556,13 +573,48 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
                                                    const Box6 *__restrict__ nodeBox, int *__restrict__ binOf, uint32_t levelStart,
                                                    uint32_t levelEnd, uint32_t *__restrict__ counter, uint32_t *__restrict__ leafCounter,
                                                    const Tri *__restrict__ sorted, Tri *__restrict__ finalTris, Node4 *__restrict__ out,
-                                                   Box6 *__restrict__ nodeBoxOut, const SceneConsts *__restrict__ consts)
+                                                   Box6 *__restrict__ nodeBoxOut, const SceneConsts *__restrict__ consts, const float4 *__restrict__ cost)
 {
     const uint32_t i = levelStart + blockIdx.x * 256 + threadIdx.x;
     if (i >= levelEnd) return;
     const int b = binOf[i];
     int cand[4];
     int n = 2;
+#if !HR_NODE32
+    if (cost) {
+        // The children that minimise the summed area of the nodes below (k_refit_round's costs): binary node b is opened over four slots;
+        // a child with a budget of k slots stays one child (a node of its own, or a triangle) unless opening it over those slots is cheaper.
+        auto costOf = [&](int ref, int k) -> float {
+            if (ref < 0) return 0.0f;
+            const float4 c = cost[ref];
+            return k == 1 ? c.x : (k == 2 ? c.y : (k == 3 ? c.z : c.w));
+        };
+        int stackRef[4], stackK[4], sp = 0;
+        n = 0;
+        stackRef[sp] = b, stackK[sp] = 4, ++sp;
+        bool first = true;
+        while (sp > 0) {
+            --sp;
+            const int ref = stackRef[sp], k = stackK[sp];
+            const bool open = first || (ref >= 0 && k >= 2 && costOf(ref, k) < costOf(ref, 1));
+            first = false;
+            if (!open) {
+                cand[n++] = ref;
+                continue;
+            }
+            const int L = knodes[ref].left, R = knodes[ref].right;
+            int bestL = 1;
+            float best = costOf(L, 1) + costOf(R, k - 1);
+            for (int jl = 2; jl < k; ++jl) {
+                const float c = costOf(L, jl) + costOf(R, k - jl);
+                if (c < best) best = c, bestL = jl;
+            }
+            stackRef[sp] = R, stackK[sp] = k - bestL, ++sp;
+            stackRef[sp] = L, stackK[sp] = bestL, ++sp;
+        }
+    } else
+#endif
+    {
     cand[0] = knodes[b].left, cand[1] = knodes[b].right;
     cand[2] = cand[3] = 0;
     for (int round = 0; round < ((HR_NODE32 == 2) ? 1 : 2); ++round) { // (one opening: three children)
@@ -578,6 +630,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
         const int ref = cand[pick];
         cand[pick] = knodes[ref].left;
         cand[n++] = knodes[ref].right;
+    }
     }
     // inner children first, triangles after them (the order of the children inside a node is free)
     int ord[4];
@@ -751,6 +804,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     KNode *knodes = nullptr;
     Box6 *leafBox = nullptr, *nodeBox = nullptr;
     Tri *sorted = nullptr;
+    float4 *dpCost = nullptr; // costs of the collapse (k_refit_round, k_collapse4)
     HR_CHECK(hipMalloc(&keysA, 4ull * n));
     HR_CHECK(hipMalloc(&keysB, 4ull * n));
     HR_CHECK(hipMalloc(&valsA, 4ull * n));
@@ -782,11 +836,14 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         HR_CHECK(hipMalloc(&nodeBox, sizeof(Box6) * (size_t)nInternal));
         HR_CHECK(hipMalloc(&stamp, 4ull * nInternal));
         HR_CHECK(hipMemsetAsync(stamp, 0, 4ull * nInternal, st));
+#if HR_COLLAPSE_DP && !HR_NODE32
+        HR_CHECK(hipMalloc(&dpCost, sizeof(float4) * (size_t)nInternal));
+#endif
         hipLaunchKernelGGL(k_karras, dim3(gi), dim3(256), 0, st, keysA, (int)n, knodes);
         // tree height <= 30 key bits + 28 index bits; check the root every 16 rounds
         uint32_t rootStamp = 0;
         for (uint32_t round = 1; round <= 64 && rootStamp == 0; ++round) {
-            hipLaunchKernelGGL(k_refit_round, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, stamp, round);
+            hipLaunchKernelGGL(k_refit_round, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, stamp, round, dpCost);
             if ((round & 15u) == 0u) {
                 HR_CHECK(hipMemcpyAsync(&rootStamp, stamp, 4, hipMemcpyDeviceToHost, st));
                 HR_CHECK(hipStreamSynchronize(st));
@@ -806,7 +863,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
             HR_CHECK(hipMemsetAsync(stamp, 0, 4ull * nInternal, st));
             rootStamp = 0;
             for (uint32_t round = 1; round <= 96 && rootStamp == 0; ++round) {
-                hipLaunchKernelGGL(k_refit_round, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, stamp, round);
+                hipLaunchKernelGGL(k_refit_round, dim3(gi), dim3(256), 0, st, knodes, nInternal, leafBox, nodeBox, stamp, round, dpCost);
                 if ((round & 15u) == 0u) {
                     HR_CHECK(hipMemcpyAsync(&rootStamp, stamp, 4, hipMemcpyDeviceToHost, st));
                     HR_CHECK(hipStreamSynchronize(st));
@@ -839,7 +896,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         for (int level = 0; level < 64 && levelEnd > levelStart; ++level) {
             const uint32_t cnt = levelEnd - levelStart;
             hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, total,
-                               total + 1, sorted, finalTris, out->nodes, out->nodeBox, dConsts);
+                               total + 1, sorted, finalTris, out->nodes, out->nodeBox, dConsts, dpCost);
             uint32_t newEnd = 0;
             HR_CHECK(hipMemcpyAsync(&newEnd, total, 4, hipMemcpyDeviceToHost, st));
             HR_CHECK(hipStreamSynchronize(st));
@@ -872,6 +929,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     if (knodes) hipFree(knodes);
     if (nodeBox) hipFree(nodeBox);
     if (stamp) hipFree(stamp);
+    if (dpCost) hipFree(dpCost);
     if (finalTris) hipFree(sorted);
     if (hipGetLastError() != hipSuccess) return 1;
     return rc;
