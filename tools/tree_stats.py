@@ -28,3 +28,15 @@ print("children per node:", {int(k): int((n_valid == k).sum()) for k in range(1,
 leaf_only = n_inner == 0
 print("nodes with triangles only:", int(leaf_only.sum()), " their children:", {int(k): int((n_valid[leaf_only] == k).sum()) for k in range(1, 5)})
 print("inner children per node:", {int(k): int((n_inner == k).sum()) for k in range(0, 5)})
+# share of the expected node visits (surface area = visit probability of a random ray) by level and by kind of node
+box_off = hdr + n_nodes * 64
+boxes = np.frombuffer(raw, dtype=np.float32, count=n_nodes * 6, offset=box_off).reshape(n_nodes, 6)
+ext = np.maximum(boxes[:, 3:6] - boxes[:, 0:3], 0)
+area = ext[:, 0] * ext[:, 1] + ext[:, 1] * ext[:, 2] + ext[:, 2] * ext[:, 0]
+tot = float(area.sum())
+print("share of summed node area: triangles-only nodes %.3f (two triangles %.3f, three %.3f, four %.3f)" % (
+    area[leaf_only].sum() / tot, area[leaf_only & (n_valid == 2)].sum() / tot, area[leaf_only & (n_valid == 3)].sum() / tot, area[leaf_only & (n_valid == 4)].sum() / tot))
+for L in range(levels):
+    a, b = level_start[L], level_start[L + 1]
+    if b > a:
+        print(f"level {L:2d}: {b - a:7d} nodes, area share {area[a:b].sum() / tot:.3f}")
