@@ -388,6 +388,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     unsigned long long tExh = 0;
     uint32_t mySteps = 0, maxSteps = 0;
     unsigned long long sumSteps = 0, nRays = 0, nGiven = 0, drainIters = 0, drainLanes = 0;
+    unsigned long long triPhases = 0, triLanes = 0, nodeRounds = 0, nodeLanes = 0; // (wave-level, counted by lane 0)
 #endif
     for (;;) {
         // ---------------- refill idle lanes (persistent threads with dynamic fetch)
@@ -735,6 +736,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
         // ---------------- inner-node steps for every lane that holds an inner node
 #pragma unroll
         for (int rep = 0; rep < HR_NODE_STEPS; ++rep) {
+#ifdef HR_TAILPROF
+            {
+                const unsigned long long m = __ballot(cur >= 0 && cur != kSentinel);
+                if (m) nodeRounds += 1, nodeLanes += (unsigned long long)__popcll(m);
+            }
+#endif
             if (cur >= 0 && cur != kSentinel) {
                 if (STATS) {
                     if (isAny)
@@ -764,6 +771,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
         const unsigned long long nodeMask = __ballot(cur >= 0 && cur != kSentinel);
         // (while draining, lane utilisation no longer matters: a waiting leaf is tested at once)
         if (blockedMask != 0ull && (__popcll(blockedMask) >= (exhausted ? 1 : kTriPhase) || nodeMask == 0ull)) {
+#ifdef HR_TAILPROF
+            triPhases += 1, triLanes += (unsigned long long)__popcll(__ballot(pend != 0));
+#endif
             if (pend != 0) {
                 const int enc = ~pend;
                 const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
@@ -921,6 +931,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
             atomicMax(&g_tailprof[7], drainIters);
             atomicAdd(&g_tailprof[16], drainLanes);
             atomicAdd(&g_tailprof[17], drainIters);
+            atomicAdd(&g_tailprof[20], triPhases);
+            atomicAdd(&g_tailprof[21], triLanes);
+            atomicAdd(&g_tailprof[22], nodeRounds);
+            atomicAdd(&g_tailprof[23], nodeLanes);
         }
         if (tExh && lane == 0) { // per-wave drain time in 0.05 ms buckets
             unsigned long long b = (tEnd - tExh) / 5000ull;

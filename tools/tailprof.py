@@ -34,4 +34,7 @@ for i in range(12, 20):                  # steady state: one trace launch per pa
         print("        subtrees handed over %d; waves by drain time (0.05 ms buckets, first 8): %s" % (v[6], " ".join(str(x) for x in v[8:16])))
         if v[19]:
             print("        shader clock during the launch: %.0f MHz" % (v[18] / (v[19] / 100.0)))
+        if v[20] and v[22]:
+            print("        node-step rounds %d with %.1f lanes of 64; triangle phases %d with %.1f lanes (%.2f phases and %.1f rounds per ray)" % (
+                v[22], v[23] / v[22], v[20], v[21] / v[20], v[20] / v[5] * 64, v[22] / v[5] * 64))
         print("        drain rounds of a wave: max %d, mean %.1f; lanes busy in a drain round: %.1f of 64" % (v[7], v[17] / 5120.0, v[16] / max(v[17], 1)))
