@@ -78,10 +78,11 @@ struct StepTable {
     uint32_t poolCap;      // entries of `pool`; 0: no stealing in this launch
     unsigned long long *pool;
     int32_t primaryFromSeg;  // passes [primaryFromSeg, nSeg) were injected this step: their closest-hit queues hold camera rays
-    // The work cursor of k_trace, in up to kTraceHeadsMax copies: the index space of a launch is cut into 2^headsLog2 equal ranges, each with a
-    // cursor on a cache line of its own.  ONE cursor serialises at ~12 ns per atomic: a launch of 25 M camera rays in 64-ray chunks
-    // needs 390 k of them, 4.7 ms of a 10 ms launch.  Workgroups start at range (blockIdx mod the number of ranges) — workgroups b and b + 8 share
-    // an XCD, so an XCD's L2 sees two ranges — and move on to the next range when theirs is used up.
+    // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
+    // kTraceHeadsMax), each with a cursor on a cache line of its own.  ONE cursor serialises at ~12 ns per atomic: a launch of 25 M camera
+    // rays in 64-ray chunks needs 390 k of them, 4.7 ms of a 10 ms launch.  A workgroup starts on range (blockIdx mod the number of ranges)
+    // — workgroups are dealt to the 8 XCDs round robin, so with 32 ranges an XCD starts on four of them — and moves on to the next range
+    // when its own is used up.  Zeroed on the host with every table upload.
     uint32_t heads[kTraceHeadsMax * 32];
     uint32_t headsLog2; // 2^headsLog2 ranges are in use (HR_TUNE heads=)
     uint32_t padH[31];
