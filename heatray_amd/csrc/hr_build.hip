@@ -166,20 +166,7 @@ __global__ void k_scene_consts(const uint32_t *__restrict__ bounds, SceneConsts 
     c.diag = sqrt_(ex * ex + ey * ey + ez * ez);
     c.pad = 1e-5f * c.diag;
     c.eps = 1e-4f * c.diag;
-    c.areaSum = 0.0f, c.triAreaSum = 0.0f, c.pad1 = c.pad2 = 0u;
-    // frame grid of the 32-byte nodes: every (padded) node box starts at or above gridLo; 2^14 power-of-two cells cover the scene
-    for (int k = 0; k < 3; ++k) {
-        c.gridLo[k] = c.lo[k] - 2.0f * c.pad;
-        const float span = (c.hi[k] - c.lo[k]) + 4.0f * c.pad;
-        float need = span * (1.0f / 16383.0f);
-        if (!(need > 1e-30f)) need = 1e-30f;
-        uint32_t bits = __float_as_uint(need), e = (bits >> 23) & 0xFFu;
-        if (bits & 0x007FFFFFu) e += 1;                               // round the cell up to a power of two
-        if (__uint_as_float(e << 23) * 16383.0f < span) e += 1;       // guard against the rounding of span / 16383
-        e = e < 9u ? 9u : (e > 240u ? 240u : e);
-        c.gridCell[k] = __uint_as_float(e << 23);
-        c.gridExpM7[k] = (int32_t)e - 7;
-    }
+    c.areaSum = 0.0f, c.triAreaSum = 0.0f, c.pad1 = 0u;
     *out = c;
     if (scene) scene->rayEps = c.eps;
 }
@@ -483,58 +470,6 @@ HRD uint32_t quantExponent(float ext)
     return e < 1u ? 1u : (e > 254u ? 254u : e);
 }
 
-#if HR_NODE32
-// Smallest r in [0, 15] such that ext / (cell * 2^(r - 7)) <= 127 (r = 15 always suffices: 127 * 2^8 cells > 2^14 + 1 cells)
-HRD uint32_t frameExponent(float ext, float cell)
-{
-    uint32_t r = 0;
-    float s = cell * (1.0f / 128.0f);
-    while (r < 15u && !(ext <= (float)kPlaneMax * s)) s = s + s, ++r;
-    return r;
-}
-// Pack a 32-byte node (hr_types.h): frame origin on the scene grid (at or below the node's box), per-axis scale, 7-bit child planes.
-HRD Node4 encodeNode4(const Box6 *cb, const Box6 &nb, int nValid, int nInner, uint32_t childBase, const SceneConsts *G)
-{
-    uint32_t g[3], r[3];
-    float org[3], inv[3];
-    for (int k = 0; k < 3; ++k) {
-        const float cell = G->gridCell[k];
-        float gf = floor_((nb.lo[k] - G->gridLo[k]) / cell);
-        gf = fmin_(fmax_(gf, 0.0f), 16383.0f);
-        if (G->gridLo[k] + gf * cell > nb.lo[k] && gf > 0.0f) gf -= 1.0f; // the rounding of (lo - gridLo) may have carried it one cell up
-        g[k] = (uint32_t)gf;
-        org[k] = G->gridLo[k] + gf * cell;
-        r[k] = frameExponent(nb.hi[k] - org[k], cell);
-        inv[k] = 1.0f / __uint_as_float((uint32_t)(G->gridExpM7[k] + (int32_t)r[k]) << 23);
-    }
-    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
-    constexpr int kPlaneBits = (HR_NODE32 == 2) ? 8 : 7;
-    for (int c = 0; c < kNodeWidth; ++c) {
-        for (int k = 0; k < 3; ++k) {
-            uint32_t lo7 = (uint32_t)kPlaneMax, hi7 = 0u; // no child: an inverted box, never hit
-            if (c < nValid) {
-                const float fl = floor_((cb[c].lo[k] - org[k]) * inv[k]);
-                const float fh = __builtin_ceilf((cb[c].hi[k] - org[k]) * inv[k]);
-                lo7 = (uint32_t)fmin_(fmax_(fl, 0.0f), (float)kPlaneMax);
-                hi7 = (uint32_t)fmin_(fmax_(fh, 0.0f), (float)kPlaneMax);
-            }
-            qlo[k] |= lo7 << (kPlaneBits * c);
-            qhi[k] |= hi7 << (kPlaneBits * c);
-        }
-    }
-    Node4 nd;
-#if HR_NODE32 == 2
-    nd.p = make_uint4(qlo[0] | ((g[2] & 255u) << 24), qlo[1] | (((g[2] >> 8) & 63u) << 24) | ((uint32_t)(nValid - 1) << 30),
-                      qlo[2] | (r[2] << 24) | ((uint32_t)nInner << 28), qhi[0]);
-    nd.q = make_uint4(qhi[1], qhi[2], g[0] | (g[1] << 14) | (r[0] << 28), (childBase & 0x0FFFFFFFu) | (r[1] << 28));
-    return nd;
-#endif
-    nd.p = make_uint4(qlo[0] | ((g[2] & 15u) << 28), qlo[1] | (((g[2] >> 4) & 15u) << 28), qlo[2] | (((g[2] >> 8) & 15u) << 28),
-                      qhi[0] | (((g[2] >> 12) & 3u) << 28) | ((uint32_t)(nValid - 1) << 30));
-    nd.q = make_uint4(qhi[1] | (r[2] << 28), qhi[2] | ((uint32_t)nInner << 28), g[0] | (g[1] << 14) | (r[0] << 28), (childBase & 0x0FFFFFFFu) | (r[1] << 28));
-    return nd;
-}
-#else
 // Quantise the child boxes of a node against the node's own box (origin + q * 2^e, 8 bits per plane, lo rounded down, hi rounded
 // up) and pack the 64-byte record (hr_types.h).  Shared by the collapse and by the refit.
 HRD Node4 encodeNode4(const Box6 *cb, const Box6 &nb, int nValid, int nInner, uint32_t innerBase, int leafKey)
@@ -567,7 +502,6 @@ HRD Node4 encodeNode4(const Box6 *cb, const Box6 &nb, int nValid, int nInner, ui
     nd.d = make_uint4(0u, 0u, 0u, 0u);
     return nd;
 }
-#endif
 
 __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ knodes, const Box6 *__restrict__ leafBox,
                                                    const Box6 *__restrict__ nodeBox, int *__restrict__ binOf, uint32_t levelStart,
@@ -580,7 +514,6 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
     const int b = binOf[i];
     int cand[4];
     int n = 2;
-#if !HR_NODE32
     if (cost) {
         // The children that minimise the summed area of the nodes below (k_refit_round's costs): binary node b is opened over four slots;
         // a child with a budget of k slots stays one child (a node of its own, or a triangle) unless opening it over those slots is cheaper.
@@ -613,11 +546,10 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
             stackRef[sp] = L, stackK[sp] = bestL, ++sp;
         }
     } else
-#endif
     {
     cand[0] = knodes[b].left, cand[1] = knodes[b].right;
     cand[2] = cand[3] = 0;
-    for (int round = 0; round < ((HR_NODE32 == 2) ? 1 : 2); ++round) { // (one opening: three children)
+    for (int round = 0; round < 2; ++round) {
         int pick = -1;
         float bestArea = -1.0f;
         for (int c = 0; c < n; ++c) {
@@ -642,12 +574,7 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
         if (cand[c] < 0) ord[nValid++] = cand[c];
     const int nLeaf = nValid - nInner;
     const uint32_t innerBase = nInner ? atomicAdd(counter, (uint32_t)nInner) : 0u;
-#if HR_NODE32
-    if (nLeaf) atomicAdd(leafCounter, (uint32_t)nLeaf);      // (only counted: a node's triangles live at W * node + W - 1 - slot)
-    const uint32_t leafBase = (uint32_t)kNodeWidth * i + (uint32_t)kNodeWidth - (uint32_t)nValid; // leafBase + (nValid - 1 - c) = W i + W - 1 - c
-#else
     const uint32_t leafBase = nLeaf ? atomicAdd(leafCounter, (uint32_t)nLeaf) : 0u;
-#endif
     Box6 cb[4];
     Box6 nb;
     for (int k = 0; k < 3; ++k) nb.lo[k] = __builtin_inff(), nb.hi[k] = -__builtin_inff();
@@ -664,13 +591,8 @@ __global__ __launch_bounds__(256) void k_collapse4(const KNode *__restrict__ kno
     }
     // child j >= nInner is triangle top - j with top = leafBase + nValid - 1: its reference ~(top - j) = ~top + j, so that a
     // child reference is `base + slot` for both kinds (base = innerBase or leafKey)
-#if HR_NODE32
-    (void)consts;
-    out[i] = encodeNode4(cb, nb, nValid, nInner, innerBase, consts);
-#else
     const int leafKey = ~((int)leafBase + nValid - 1);
     out[i] = encodeNode4(cb, nb, nValid, nInner, innerBase, leafKey);
-#endif
     nodeBoxOut[i] = nb;
 }
 
@@ -700,21 +622,10 @@ __global__ __launch_bounds__(256) void k_refit4(Node4 *__restrict__ nodes, Box6 
     if (i < levelEnd) {
         const float pad = consts->pad;
         const Node4 nd = nodes[i];
-#if HR_NODE32
-#if HR_NODE32 == 2
-        const int nInner = (int)((nd.p.z >> 28) & 3u);
-        const int nValid = (int)(nd.p.y >> 30) + 1;
-#else
-        const int nInner = (int)((nd.q.y >> 28) & 7u);
-        const int nValid = (int)(nd.p.w >> 30) + 1;
-#endif
-        const uint32_t innerBase = nd.q.w & 0x0FFFFFFFu;
-#else
         const uint32_t meta = __float_as_uint(nd.a.w);
         const int nInner = (int)((meta >> 24) & 7u), nValid = (int)(meta >> 27);
         const uint32_t innerBase = nd.c.z;
         const int leafKey = (int)nd.c.w;
-#endif
         Box6 cb[4];
         Box6 nb;
         for (int k = 0; k < 3; ++k) nb.lo[k] = __builtin_inff(), nb.hi[k] = -__builtin_inff();
@@ -723,21 +634,13 @@ __global__ __launch_bounds__(256) void k_refit4(Node4 *__restrict__ nodes, Box6 
                 cb[c] = nodeBox[innerBase + (uint32_t)c];
             } else {
                 v3 bl, bh;
-#if HR_NODE32
-                triBounds(tris[(uint32_t)kNodeWidth * i + (uint32_t)(kNodeWidth - 1) - (uint32_t)c], bl, bh);
-#else
                 triBounds(tris[~(leafKey + c)], bl, bh);
-#endif
                 cb[c].lo[0] = bl.x - pad, cb[c].lo[1] = bl.y - pad, cb[c].lo[2] = bl.z - pad;
                 cb[c].hi[0] = bh.x + pad, cb[c].hi[1] = bh.y + pad, cb[c].hi[2] = bh.z + pad;
             }
             for (int k = 0; k < 3; ++k) nb.lo[k] = fmin_(nb.lo[k], cb[c].lo[k]), nb.hi[k] = fmax_(nb.hi[k], cb[c].hi[k]);
         }
-#if HR_NODE32
-        nodes[i] = encodeNode4(cb, nb, nValid, nInner, innerBase, consts);
-#else
         nodes[i] = encodeNode4(cb, nb, nValid, nInner, innerBase, leafKey);
-#endif
         nodeBox[i] = nb;
         area = boxArea(nb);
     }
@@ -758,7 +661,7 @@ __global__ __launch_bounds__(256) void k_slot_of_prim(const Tri *__restrict__ le
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t prim = __float_as_uint(leafTris[i].r.y);
-    if (prim != 0xFFFFFFFFu) slotOfPrim[prim] = i; // (32-byte nodes: the triangle array has unused slots, filled with 0xFF bytes)
+    if (prim != 0xFFFFFFFFu) slotOfPrim[prim] = i; // (a slot a cached tree left unused carries prim id ~0)
 }
 
 __global__ __launch_bounds__(256) void k_area_sum(const Box6 *__restrict__ nodeBox, uint32_t n, SceneConsts *__restrict__ consts)
@@ -836,7 +739,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         HR_CHECK(hipMalloc(&nodeBox, sizeof(Box6) * (size_t)nInternal));
         HR_CHECK(hipMalloc(&stamp, 4ull * nInternal));
         HR_CHECK(hipMemsetAsync(stamp, 0, 4ull * nInternal, st));
-#if HR_COLLAPSE_DP && !HR_NODE32
+#if HR_COLLAPSE_DP
         HR_CHECK(hipMalloc(&dpCost, sizeof(float4) * (size_t)nInternal));
 #endif
         hipLaunchKernelGGL(k_karras, dim3(gi), dim3(256), 0, st, keysA, (int)n, knodes);
@@ -877,13 +780,7 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         }
 #endif
         const uint32_t nMax = (uint32_t)nInternal; // every 4-wide node stands for one binary inner node
-#if HR_NODE32
-        // a node's triangles live at 4 * node + 3 - slot: four slots per possible node, unused ones marked by 0xFF bytes (prim id -1)
-        HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)kNodeWidth * (size_t)nMax));
-        HR_CHECK(hipMemsetAsync(finalTris, 0xFF, sizeof(Tri) * (size_t)kNodeWidth * (size_t)nMax, st));
-#else
         HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)n));
-#endif
         int *binOf = nullptr;
         HR_CHECK(hipMalloc(&out->nodes, sizeof(Node4) * (size_t)nMax));
         HR_CHECK(hipMalloc(&out->nodeBox, sizeof(Box6) * (size_t)nMax));
@@ -919,9 +816,6 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
     }
     out->tris = finalTris ? finalTris : sorted;
     out->triSlots = n;
-#if HR_NODE32
-    if (finalTris) out->triSlots = (uint32_t)kNodeWidth * (uint32_t)out->nNodes;
-#endif
     HR_CHECK(hipMalloc(&out->slotOfPrim, 4ull * n));
     hipLaunchKernelGGL(k_slot_of_prim, dim3((out->triSlots + 255) / 256), dim3(256), 0, st, out->tris, out->triSlots, out->slotOfPrim);
     HR_CHECK(hipStreamSynchronize(st));

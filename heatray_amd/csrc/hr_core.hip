@@ -124,7 +124,6 @@ struct hr_ctx {
         hipStream_t stream = nullptr;
         StepTable *dTables = nullptr;   // ring of device step tables
         StepTable *hTables = nullptr;   // pinned staging ring
-        unsigned long long *dPool = nullptr; // steal pool of this group's trace launches (all-zero between launches)
         hipEvent_t tableCopied[4] = {nullptr, nullptr, nullptr, nullptr};
         bool tableUsed[4] = {false, false, false, false};
         unsigned long long stepCounter = 0;
@@ -157,8 +156,10 @@ struct hr_ctx {
     uint32_t *dZero = nullptr;    // a zero word (occlusion count of a pass's first step)
     Counters *dCounters = nullptr; // one per pass slot, contiguous (copied to the host in one piece in pass-through scenes)
 
-    // Mesh blocks come out of a grow-only arena: a hipMalloc per submesh is a device-wide synchronisation of ~0.1 ms each, which adds
-    // up for the scenes the reference loads (hundreds of submeshes).  A chunk is released when the last mesh in it has been removed.
+    // Mesh blocks come out of an arena of 64 MB chunks (bump allocation inside a chunk): a hipMalloc per submesh is a device-wide
+    // synchronisation of ~0.1 ms each, which adds up for the scenes the reference loads (hundreds of submeshes).  A chunk whose last
+    // mesh has been removed is empty again: one such chunk is kept for the next add (a lone dynamic mesh that is removed and re-added
+    // every frame costs no hipFree + hipMalloc), further ones are released, and their entries in the vector are reused.
     struct MeshChunk {
         char *base = nullptr;
         size_t cap = 0, used = 0;
@@ -168,30 +169,41 @@ struct hr_ctx {
     char *meshAlloc(size_t bytes, int *chunkOut)
     {
         const size_t need = (bytes + 255) & ~(size_t)255;
-        for (int pass = 0; pass < 2; ++pass) {
-            if (!meshChunks.empty()) {
-                MeshChunk &k = meshChunks.back();
-                if (k.base && k.cap - k.used >= need) {
-                    char *p = k.base + k.used;
-                    k.used += need, k.live += 1;
-                    *chunkOut = (int)meshChunks.size() - 1;
-                    return p;
-                }
+        // the newest chunk first (it is the one being filled), then any other with room (e.g. one that ran empty)
+        for (int i = (int)meshChunks.size() - 1; i >= 0; --i) {
+            MeshChunk &k = meshChunks[i];
+            if (k.base && k.cap - k.used >= need) {
+                char *p = k.base + k.used;
+                k.used += need, k.live += 1;
+                *chunkOut = i;
+                return p;
             }
-            MeshChunk k;
-            k.cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
-            if (hipMalloc((void **)&k.base, k.cap) != hipSuccess) return nullptr;
-            meshChunks.push_back(k);
         }
-        return nullptr;
+        MeshChunk k;
+        k.cap = need > ((size_t)64 << 20) ? need : ((size_t)64 << 20);
+        if (hipMalloc((void **)&k.base, k.cap) != hipSuccess) return nullptr;
+        k.used = need, k.live = 1;
+        for (size_t i = 0; i < meshChunks.size(); ++i)
+            if (!meshChunks[i].base) { // a released chunk's entry (other meshes refer to chunks by index, so entries never move)
+                meshChunks[i] = k;
+                *chunkOut = (int)i;
+                return k.base;
+            }
+        meshChunks.push_back(k);
+        *chunkOut = (int)meshChunks.size() - 1;
+        return k.base;
     }
     void meshRelease(int chunk)
     {
         if (chunk < 0 || chunk >= (int)meshChunks.size()) return;
         MeshChunk &k = meshChunks[chunk];
-        if (--k.live <= 0 && k.base) {
+        if (!k.base || --k.live > 0) return;
+        k.live = 0, k.used = 0; // empty: its space is handed out again
+        int spare = 0;
+        for (const MeshChunk &o : meshChunks) spare += (o.base && o.live == 0) ? 1 : 0;
+        if (spare > 1 || k.cap > ((size_t)64 << 20)) { // keep ONE empty default-sized chunk
             hipFree(k.base);
-            k.base = nullptr, k.cap = k.used = 0, k.live = 0; // (the slot stays: other meshes refer to chunks by index)
+            k.base = nullptr, k.cap = 0;
         }
     }
     void meshReleaseAll()
@@ -318,8 +330,8 @@ struct hr_ctx {
 
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
-    int tuneTri = 2, tuneRefill = 16, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneSplitShade = 1, tuneSteal = 1, tuneFetchPrimary = 128, tuneFetchGate = 8, tuneHeads = 5, tuneSlowMs = 4;
-    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass, tuneSplitShade == 0}; }
+    int tuneTri = 2, tuneRefill = 16, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneFetchPrimary = 128, tuneFetchGate = 8, tuneHeads = 5, tuneSlowMs = 4;
+    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass}; }
 };
 
 #define FAIL(ctx, code, msg)  \
@@ -342,7 +354,6 @@ struct hr_ctx {
     HIP_TRY(ctx, hipSetDevice((ctx)->device))
 
 static const int kTableRing = 4;
-static const uint32_t kStealPoolCap = 1u << 20; // entries of a group's steal pool (8 MB)
 static int drainPipeline(hr_ctx *c);
 // finish every enqueued pass and wait for the device: required before anything the in-flight kernels read changes
 static int quiesce(hr_ctx *c)
@@ -369,8 +380,11 @@ static int completeForSlowCaller(hr_ctx *c)
     if (c->oldestWaitingNs == 0 || (c->pendingInject.empty() && occupiedSlots(c) == 0)) return HR_OK;
     const unsigned long long now = (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (c->tuneSlowMs <= 0 || now - c->oldestWaitingNs <= 1000000ull * (unsigned long long)c->tuneSlowMs) return HR_OK; // (HR_TUNE slow=0: never, for tests of the lag itself)
-    for (int g = 0; g < c->nGroups; ++g)
-        if (hipStreamQuery(c->groups[g].stream) != hipSuccess) return HR_OK;
+    for (int g = 0; g < c->nGroups; ++g) {
+        const hipError_t q = hipStreamQuery(c->groups[g].stream);
+        if (q == hipErrorNotReady) return HR_OK; // work in flight: the pipeline is being fed
+        HIP_TRY(c, q);                           // (anything else is a real error of an earlier launch)
+    }
     return drainPipeline(c);
 }
 static void freeLagged(hr_ctx::Lagged &L)
@@ -418,7 +432,7 @@ static void freeQueues(hr_ctx *c)
 {
     for (hr_ctx::PassSlot &ps : c->slots) {
         for (int i = 0; i < 2; ++i) hipFree(ps.q[i].A), hipFree(ps.q[i].B), hipFree(ps.q[i].C), hipFree(ps.q[i].D);
-        hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C), hipFree(ps.sq.M);
+        hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C);
         hipFree(ps.hits), hipFree(ps.hitIdx), hipFree(ps.passbuf);
         if (ps.evFinal) hipEventDestroy(ps.evFinal);
         if (ps.evResolved) hipEventDestroy(ps.evResolved);
@@ -437,7 +451,7 @@ static void slotBudget(hr_ctx *c)
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
         const size_t k = c->allLightsUsed ? 4 : 1;
-        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + (HR_STEAL ? 52 : 48) * k + hitRecordSize() + 4) + fbBytes * k + sizeof(Counters);
+        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 * k + hitRecordSize() + 4) + fbBytes * k + sizeof(Counters);
         const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
         c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
     }
@@ -506,7 +520,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("shade=", c->tuneSplitShade), get("guard=", c->tuneGuardPct), get("steal=", c->tuneSteal), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -525,10 +539,6 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             groupsOk = groupsOk && hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, c->tunePrio ? greatest : 0) == hipSuccess;
         }
         groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
-#if HR_STEAL
-        groupsOk = groupsOk && hipMalloc(&G.dPool, sizeof(unsigned long long) * kStealPoolCap) == hipSuccess &&
-                   hipMemset(G.dPool, 0, sizeof(unsigned long long) * kStealPoolCap) == hipSuccess;
-#endif
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipEventCreateWithFlags(&G.evUser, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
@@ -582,7 +592,6 @@ int hr_ctx_destroy(hr_ctx *c)
             if (e) hipEventDestroy(e);
         if (G.stream) hipStreamDestroy(G.stream);
         hipFree(G.dTables);
-        hipFree(G.dPool);
         if (G.hTables) hipHostFree(G.hTables);
         if (G.evUser) hipEventDestroy(G.evUser);
         for (hipEvent_t e : G.tableCopied)
@@ -900,8 +909,11 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
     if (!g.dBlock) FAIL(c, HR_ERR_DEVICE, "out of device memory for a mesh block");
     // (the 16-byte alignment padding behind each range is never uploaded, yet the tree cache's content hash covers the whole block:
     // recycled device memory there made the key differ from run to run)
-    HIP_TRY(c, hipMemsetAsync(g.dBlock, 0, total ? total : 16, c->stream));
     int rc = HR_OK;
+    if (hipMemsetAsync(g.dBlock, 0, total ? total : 16, c->stream) != hipSuccess) {
+        c->meshRelease(g.chunk); // (every error return behind meshAlloc gives the block back)
+        FAIL(c, HR_ERR_DEVICE, "hipMemsetAsync of a mesh block failed");
+    }
     if (interleaved) {
         rc = stagedUpload(c, g.dBlock, ilo, (size_t)(g.nVerts - 1) * (size_t)isb + (size_t)(ihi - ilo));
     } else {
@@ -981,11 +993,14 @@ unsigned long long payloadChecksum(const char *p, size_t bytes)
 }
 
 // Everything the kernels index with comes out of the file: child ranges, leaf triangle slots, the prim -> slot map, the level table.
-// A file that passes the checksum can still have been written by something else, so every index is range-checked before the arrays
-// reach the device (an out-of-range child or slot is a GPU fault or a hang in k_refit4 / k_trace, not a wrong pixel).
+// The checksum only catches accidental damage (it is not cryptographic: the cache directory is trusted like the scene files are), so
+// every index is range-checked before the arrays reach the device (an out-of-range child or slot is a GPU fault or a hang in
+// k_refit4 / k_trace, not a wrong pixel), the node count is bounded before anything is allocated, and every inner child must lie in
+// the next level's range, which proves the depth the stack check relies on.
 bool cachedTreeIsSane(const CacheHeader &h, const char *nodesBytes, const uint32_t *slotOfPrim)
 {
     if (h.triSlots < h.nTris || h.triSlots >= (1u << 28) || h.rootLeafCount > 4u || h.levels > (uint32_t)kMaxLevels) return false;
+    if (h.nNodes >= (1u << 26) || h.nNodes > h.nTris) return false; // (every 4-wide node stands for one binary inner node)
     if (h.rootLeafCount > 0 && h.rootLeafCount > h.triSlots) return false;
     if (h.levelStart[0] != 0u) return false;
     for (uint32_t l = 0; l < h.levels; ++l)
@@ -993,26 +1008,27 @@ bool cachedTreeIsSane(const CacheHeader &h, const char *nodesBytes, const uint32
     if (h.levels > 0 && h.levelStart[h.levels] != h.nNodes) return false;
     for (uint32_t i = 0; i < h.nTris; ++i)
         if (slotOfPrim[i] >= h.triSlots) return false;
-#if !HR_NODE32
+    uint32_t level = 0;
     for (uint32_t i = 0; i < h.nNodes; ++i) {
+        while (level + 1 < h.levels && i >= h.levelStart[level + 1]) ++level;
         Node4 n;
         std::memcpy(&n, nodesBytes + (size_t)i * sizeof(Node4), sizeof(Node4));
         uint32_t meta;
         std::memcpy(&meta, &n.a.w, 4);
         const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
         if (nValid > 4u || nInner > nValid) return false;
-        if (nInner > 0) { // inner children are nodes innerBase .. innerBase + nInner - 1, allocated behind their parent (breadth-first)
+        if (nInner > 0) {
+            // inner children are nodes innerBase .. innerBase + nInner - 1 and lie in the NEXT level's index range (breadth-first
+            // allocation): that proves the depth the header claims, which bounds the traversal stack (3 entries per level)
             const uint32_t base = n.c.z;
-            if (base <= i || base >= h.nNodes || nInner > h.nNodes - base) return false;
+            if (level + 1 >= h.levels) return false;
+            if (base < h.levelStart[level + 1] || base >= h.levelStart[level + 2] || nInner > h.levelStart[level + 2] - base) return false;
         }
         for (uint32_t j = nInner; j < nValid; ++j) { // leaf child j is the triangle ~(leafKey + j)
             const uint32_t slot = ~(n.c.w + j);
             if (slot >= h.triSlots) return false;
         }
     }
-#else
-    (void)nodesBytes;
-#endif
     return true;
 }
 } // namespace
@@ -1051,7 +1067,8 @@ static bool loadTree(hr_ctx *c, unsigned long long key, uint32_t nTris, BuildRes
     if (!f) return false;
     CacheHeader h;
     bool ok = fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "HRBVHTR", 8) == 0 && h.version == kCacheVersion &&
-              h.nodeBytes == sizeof(Node4) && h.key == key && h.nTris == nTris && h.nNodes > 0 && h.levels <= (uint32_t)kMaxLevels;
+              h.nodeBytes == sizeof(Node4) && h.key == key && h.nTris == nTris && h.nNodes > 0 && h.nNodes <= nTris && h.nNodes < (1u << 26) &&
+              h.levels <= (uint32_t)kMaxLevels;
     std::vector<char> buf;
     BuildResult br{};
     if (ok) {
@@ -1232,8 +1249,6 @@ int hr_scene_commit(hr_ctx *c)
         c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = ext;
         c->hScene.nTris = (int)nTris, c->hScene.nNodes = c->tree.nNodes, c->hScene.rootLeafCount = c->tree.rootLeafCount;
         c->hScene.rayEps = k.eps; // 1e-4 |diagonal|, SURVEY §8a a6
-        c->hScene.slotOfPrim = c->tree.slotOfPrim;
-        for (int q = 0; q < 3; ++q) c->hScene.gridLo[q] = k.gridLo[q], c->hScene.gridCell[q] = k.gridCell[q], c->hScene.gridExpM7[q] = k.gridExpM7[q];
         for (int q = 0; q < 3; ++q) c->info.aabb_min[q] = k.lo[q], c->info.aabb_max[q] = k.hi[q];
         c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)c->tree.nNodes, c->info.ray_epsilon = k.eps;
         c->info.bvh_levels = (uint32_t)c->tree.levels;
@@ -1659,9 +1674,6 @@ static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
     if (e == hipSuccess) e = hipMalloc(&ps.sq.A, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.sq.B, s16);
     if (e == hipSuccess) e = hipMalloc(&ps.sq.C, s16);
-#if HR_STEAL
-    if (e == hipSuccess) e = hipMalloc(&ps.sq.M, s16 / 4);
-#endif
     if (e == hipSuccess) e = hipMalloc(&ps.hits, cap * hitRecordSize());
     if (e == hipSuccess) e = hipMalloc(&ps.hitIdx, cap * sizeof(uint32_t));
     // (with HR_ESTIMATOR_ALL_LIGHTS the sample's second partial sum lies right behind the first: k_trace indexes one buffer)
@@ -1720,7 +1732,13 @@ static int resolveReady(hr_ctx *c)
             bufs.bufB[bufs.n] = next->pp.estimator == HR_ESTIMATOR_ALL_LIGHTS ? next->passbufB : nullptr;
             bufs.buf[bufs.n++] = next->passbuf;
         }
-        if (bufs.n == 0) return HR_OK;
+        if (bufs.n == 0) {
+            // nothing requested is unfinished any more: the age of "the oldest waiting request" starts afresh with the next request
+            // (stamped only in hr_render_pass, it used to survive every pass that completed the normal way, so that 4 ms after the
+            // first request EVERY progressive read-back that found the streams idle drained a partly filled batch)
+            if (c->pendingInject.empty() && occupiedSlots(c) == 0) c->oldestWaitingNs = 0;
+            return HR_OK;
+        }
         for (int k = 0; k < bufs.n; ++k) {
             bool seen = false;
             for (int j = 0; j < k; ++j) seen = seen || ready[j]->finalEv == ready[k]->finalEv;
@@ -1836,16 +1854,13 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     const int ring = (int)(G.stepCounter++ % kTableRing);
     if (G.tableUsed[ring]) HIP_TRY(c, hipEventSynchronize(G.tableCopied[ring])); // staging entry free again (4 steps old)
     StepTable &tbl = G.hTables[ring];
-    tbl.reserved0 = 0;
     std::memset(tbl.heads, 0, sizeof(tbl.heads));
     tbl.headsLog2 = (uint32_t)(c->tuneHeads < 0 ? 0 : (c->tuneHeads > 6 ? 6 : c->tuneHeads));
     tbl.nSeg = n;
     tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
     tbl.fetchMax = c->tuneFetchMax > 0 ? c->tuneFetchMax : 1, tbl.fetchMin = c->tuneFetchMin > 0 ? c->tuneFetchMin : 1;
     tbl.staticPerWave = c->tuneStaticDeal, tbl.hasGlass = c->hasGlass ? 1 : 0;
-    tbl.poolTail = tbl.poolHead = tbl.idleSeen = 0, tbl.pool = G.dPool;
     tbl.primaryFromSeg = n, tbl.fetchMaxPrimary = ((c->tuneFetchPrimary > 0 ? c->tuneFetchPrimary : 1) & 0xFFFF) | ((c->tuneFetchGate & 0xFFFF) << 16); // (primaryFromSeg is set below, once the injected passes' places in the table are known)
-    tbl.poolCap = (HR_STEAL && c->tuneSteal && c->tuneSplitShade) ? kStealPoolCap : 0u; // (the single shading kernel of shade=0 does not know the merge records)
     int injectedSegs[kMaxSegs];
     int nInjectedSegs = 0;
     for (int k = 0; k < n; ++k) {

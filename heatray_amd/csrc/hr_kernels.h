@@ -3,6 +3,8 @@
 
 #include "hr_types.h"
 
+#include <cstddef>
+
 namespace hr {
 
 struct FrameDev {
@@ -29,7 +31,6 @@ struct LaunchCfg {
     bool textureLod; // some pass has asked for HR_TEXTURE_LOD_CONE: launch the shading kernel that carries the trilinear sampler
     bool allLights;  // some pass has asked for HR_ESTIMATOR_ALL_LIGHTS: the shading kernel that can emit two occlusion rays per vertex
     bool hasGlass;   // some material of the scene is glass: the glass shading kernel is launched too
-    bool fusedShade; // HR_TUNE="shade=0": the single shading kernel of rounds 1-2 (A/B experiments)
 };
 
 // One in-flight pass as seen by the kernels of one macro step.
@@ -54,16 +55,13 @@ struct SegDev {
     int32_t pad;
 };
 
-#ifndef HR_STEAL
-#define HR_STEAL 0 // EXPERIMENT (round 3, measured a loss, hr_render.hip): cross-wave steal pool in k_trace's drain phase
-#endif
 #ifndef HR_MAX_SEGS
 #define HR_MAX_SEGS 320
 #endif
 static const int kMaxSegs = HR_MAX_SEGS;
 static const int kTraceHeadsMax = 64; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
 struct StepTable {
-    uint32_t reserved0; // (round 1-2: the single work cursor of k_trace; now `heads` below)
+    // read-mostly header: every wave of every kernel of the step reads it once
     int32_t nSeg;
     int32_t refillLanes;   // refill a wave from the work pool once this many lanes are idle
     int32_t triPhaseLanes; // run the triangle phase once this many lanes are blocked on a postponed leaf
@@ -71,24 +69,19 @@ struct StepTable {
     int32_t fetchMin;      // ... shrinking to this near the end of the pool (guided self-scheduling: short tail)
     int32_t staticPerWave; // launches of at most this many rays per resident wave are dealt out statically (k_trace)
     int32_t hasGlass;      // some material of the scene is glass (else the glass hit list is never appended to)
-    // Steal pool of the launch (k_trace, drain phase): subtrees that busy waves hand to waves that have run out of work.  Entries
-    // [poolHead, poolTail) are claimable; an entry is (work item + 1) << 32 | node reference, 0 while not yet written.
-    uint32_t poolTail, poolHead; // (one aligned 8-byte word: read together)
-    uint32_t idleSeen;     // some wave has run out of work: donations start
-    uint32_t poolCap;      // entries of `pool`; 0: no stealing in this launch
-    unsigned long long *pool;
     int32_t primaryFromSeg;  // passes [primaryFromSeg, nSeg) were injected this step: their closest-hit queues hold camera rays
-    // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
-    // kTraceHeadsMax), each with a cursor on a cache line of its own.  ONE cursor serialises at ~12 ns per atomic: a launch of 25 M camera
-    // rays in 64-ray chunks needs 390 k of them, 4.7 ms of a 10 ms launch.  A workgroup starts on range (blockIdx mod the number of ranges)
-    // — workgroups are dealt to the 8 XCDs round robin, so with 32 ranges an XCD starts on four of them — and moves on to the next range
-    // when its own is used up.  Zeroed on the host with every table upload.
-    uint32_t heads[kTraceHeadsMax * 32];
-    uint32_t headsLog2; // 2^headsLog2 ranges are in use (HR_TUNE heads=)
-    uint32_t padH[31];
     int32_t fetchMaxPrimary; // chunk size of the work fetch inside that (coherent) part of the index space: low 16 bits; high 16 bits: how many such chunks per resident wave the part must hold for it to be used
-    SegDev seg[kMaxSegs];
+    uint32_t headsLog2;      // 2^headsLog2 ranges are in use (HR_TUNE heads=)
+    // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
+    // kTraceHeadsMax), each with a cursor on a cache line of its own — none of them shares its 128-byte line with the header above
+    // or with seg[] below, which every wave reads while the cursors are hammered by atomics.  ONE cursor serialises at ~12 ns per atomic:
+    // a launch of 25 M camera rays in 64-ray chunks needs 390 k of them, 4.7 ms of a 10 ms launch.  A workgroup starts on range
+    // (blockIdx mod the number of ranges) — workgroups are dealt to the 8 XCDs round robin, so with 32 ranges an XCD starts on four of
+    // them — and moves on to the next range when its own is used up.  Zeroed on the host with every table upload.
+    alignas(128) uint32_t heads[kTraceHeadsMax * 32];
+    alignas(128) SegDev seg[kMaxSegs];
 };
+static_assert(offsetof(StepTable, heads) % 128 == 0 && offsetof(StepTable, seg) % 128 == 0, "k_trace's work cursors own their cache lines");
 
 // ---- hr_render.hip
 // Several passes per launch (a small shard injects / resolves a batch of passes per macro step: one launch instead of 8 + 8)
@@ -148,9 +141,6 @@ struct SceneConsts {
     float areaSum; // sum of the node boxes' surface areas after the last build / refit (tree-quality heuristic only)
     float triAreaSum; // sum of the triangles' areas (invariant under rigid motion, scales with the scene: what areaSum is compared with)
     uint32_t pad1;
-    float gridLo[3], gridCell[3]; // frame grid of the 32-byte nodes (hr_types.h)
-    int32_t gridExpM7[3];
-    uint32_t pad2;
 };
 
 static const int kMaxLevels = 64;

@@ -264,22 +264,10 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
 }
 
 
-#ifndef HR_TAIL_SHARE
-#define HR_TAIL_SHARE 1 // idle lanes take over subtrees of their wave's remaining rays once the work queue is empty
-#endif
 #ifndef HR_TAIL_ROUNDS
 #define HR_TAIL_ROUNDS 3
 #endif
 static const unsigned long long kNoHitKey = ~0ull;
-// HR_STEAL (hr_kernels.h): drain phase, waves that have run out of work take subtrees of other waves' rays from a global pool.
-// EXPERIMENT of round 3, parity-green on the whole GPU suite and much slower (see the comment at the pool code): off by default.
-#if HR_STEAL
-static const uint32_t kStealLow = 192;  // busy waves top the pool up while fewer than this many entries wait in it
-static const int kStealGive = 16;       // entries a wave adds per round at most
-static const int kStealTries = 6;       // polls of an empty pool (a few microseconds apart) before a wave gives up and exits
-static const uint32_t kSharedMark = 0xFFFFFFFFu; // u and v words of a hit record that is still in merge (key) format
-static const uint32_t kOccluded = 0x80000000u;   // flag bit of an occlusion ray's merge word (ShadowQueue::M)
-#endif
 
 #ifdef HR_TAILPROF
 // Experiment builds only: when does the work queue run dry, when does the launch end, how long is the longest ray?
@@ -292,27 +280,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 {
     __shared__ int stack[kTraceWaves][kStackLDS][64];
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
-#if HR_TAIL_SHARE
     // merge slots of the drain phase (below): one per ray a wave held when the work queue ran dry
     __shared__ unsigned long long mKey[kTraceWaves][64]; // min over the ray's fragments of (t bits, prim, face bit); kNoHitKey: none
     __shared__ uint32_t mCount[kTraceWaves][64];         // fragments still traversing
     __shared__ float2 mUV[kTraceWaves][64];              // barycentrics that belong to mKey
     __shared__ uint32_t mDonor[kTraceWaves][64];         // k-th donating lane of this round
-#if HR_STEAL
-    __shared__ uint32_t mGlobal[kTraceWaves][64];        // the slot's ray is also traversed by other waves (steal pool): results merge in global memory
-#endif
-#endif
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
-#if HR_LDS_NODES && !HR_NODE32
-    __shared__ uint4 topLds[HR_LDS_NODES * 3];
-    const int topCount = S.nNodes < HR_LDS_NODES ? S.nNodes : HR_LDS_NODES;
-    for (int i = (int)threadIdx.x; i < topCount * 3; i += kTraceBlock) topLds[i] = reinterpret_cast<const uint4 *>(nodes)[(i / 3) * 4 + i % 3];
-    // (buildSegStarts below ends with a workgroup barrier)
-#else
-    const uint4 *topLds = nullptr;
-    const int topCount = 0;
-#endif
     buildSegStarts(tbl, segStart, false);
     const int nSeg2 = 2 * tbl->nSeg;
     const uint32_t total = segStart[nSeg2];
@@ -348,9 +322,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     best.prim = kMissPrim, best.t = 0, best.u = 0, best.v = 0;
     int ovf[kStackOvf];
     const float tmin = S.rayEps;
-#if HR_NODE32
-    const GridK gk = gridOf(S);
-#endif
     const int rootRef = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
 
     uint32_t poolLo = 0, poolHi = 0; // wave-uniform: indices this wave has reserved and not handed out yet
@@ -375,13 +346,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     uint32_t nvC = 0, ntC = 0, nvA = 0, ntA = 0, nacc = 0;
 
     int pend = 0; // postponed leaf (a negative leaf reference) or 0: the lane keeps descending while a leaf waits
-#if HR_TAIL_SHARE
     uint32_t slot = lane;  // merge slot of the ray (fragment) this lane holds during the drain phase
     bool draining = false; // wave-uniform: the merge slots are initialised
-#if HR_STEAL
-    bool toldIdle = false; // wave-uniform: this wave has announced that it ran out of work (steal pool)
-#endif
-#endif
 #ifdef HR_TAILPROF
     const unsigned long long tStart = wall_clock64();
     const unsigned long long cStart = clock64(); // shader clock, against the 100 MHz wall clock: the frequency the kernel really ran at
@@ -466,7 +432,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     tmax = a.w, tlim = a.w;
                     idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
                     {
-                        const RayK f = rayFrame(S, o, idx, idy, idz);
+                        const RayK f = rayFrame(o, idx, idy, idz);
                         oix = f.oix, oiy = f.oiy, oiz = f.oiz;
                     }
                     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
@@ -481,7 +447,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 nIdle = __popcll(idleMask);
             }
         }
-#if HR_TAIL_SHARE
         // ---------------- drain phase: the queue is empty, so a launch now lasts as long as its longest ray (0.5 ms for a ray of
         // ~400 node steps, against ~70 on average).  Idle lanes therefore take over pending subtrees of the rays still in
         // flight in their wave: the closest hit is the lexicographic minimum of (t, prim) over ALL triangles, so it does not
@@ -492,9 +457,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 slot = lane;
                 mKey[wave][lane] = kNoHitKey;
                 mCount[wave][lane] = (item != 0xFFFFFFFFu) ? 1u : 0u;
-#if HR_STEAL
-                mGlobal[wave][lane] = 0u;
-#endif
             }
             if (item != 0xFFFFFFFFu) { // what the other fragments of this ray have found so far bounds this one too
                 const unsigned long long k = mKey[wave][slot];
@@ -540,7 +502,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     tmax = sTmax, tlim = sTlim;
                     idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
                     {
-                        const RayK f = rayFrame(S, o, idx, idy, idz);
+                        const RayK f = rayFrame(o, idx, idy, idz);
                         oix = f.oix, oiy = f.oiy, oiz = f.oiz;
                     }
                     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
@@ -555,184 +517,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 idleMask = __ballot(idle);
             }
             }
-#if HR_STEAL
-            // ---------------- steal pool.  Within a wave the idle lanes take over subtrees (above); across waves nothing did: a wave's
-            // rays still in flight when the queue runs dry are 3600 node steps of work on average and 9900 at worst, so waves finish
-            // spread over the whole drain (0.45 ms of a 1080p launch) and the chip is half empty for that long.  Therefore: once some
-            // wave has run out of work, busy waves keep a small global pool of their oldest stack entries topped up, and a wave with
-            // nothing left takes entries from it instead of exiting.  A ray traversed by several waves merges its result in global
-            // memory: closest-hit rays by an atomic minimum on the 64-bit key (t, triangle, face) kept in the ray's hit record
-            // — k_shade_sort turns it into a hit record and recomputes the barycentrics, the same arithmetic on the same triangle —
-            // occlusion rays by a counter of the groups still traversing (ShadowQueue::M), whose last one adds the light's sample.
-            // MEASURED (profiles/r3s_steal_pool_ab.txt, c3): bit-exact, and a large loss.  Compiled in but switched off it costs 7-10 %
-            // (101 instead of 94 VGPRs: four instead of five waves per SIMD, or spills when five are forced); switched on, 20 passes
-            // run at 1075 instead of 1640 Mrays/s and a 1/8 shard at 0.43 of its rate: a handed-over subtree is a few dozen node
-            // steps, less than the reload of its ray, the merge atomics and the pool traffic cost, and thousands of waves polling
-            // and topping up one pool keep each other busy.  Not built further; -DHR_STEAL=1 builds it.
-            if (tbl->poolCap != 0u) {
-                // what other waves have found for this lane's ray since
-                if (item != 0xFFFFFFFFu && mGlobal[wave][slot] != 0u) {
-                    const SegDev &sgm = tbl->seg[segIdx >> 1];
-                    if (segIdx & 1) {
-                        if (__hip_atomic_load(&sgm.sq.M[local], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kOccluded) cur = kSentinel, sp = 0, pend = 0;
-                    } else {
-                        const unsigned long long gk = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&sgm.hits[local]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (gk != kNoHitKey) {
-                            const float ts = __uint_as_float((uint32_t)(gk >> 32));
-                            tlim = ts < tlim ? ts : tlim;
-                        }
-                    }
-                }
-                const uint32_t idleSeen = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&tbl->idleSeen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                const bool canDonate = item != 0xFFFFFFFFu && sp >= 2 && sp <= kStackLDS; // (keeps an entry for itself)
-                const unsigned long long donMask = __ballot(canDonate);
-                if (idleSeen != 0u && donMask != 0ull && nIdle == 0) {
-                    const unsigned long long ht = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&tbl->poolTail), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const uint32_t tailNow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ht), headNow = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ht >> 32));
-                    const uint32_t nCan = (uint32_t)__popcll(donMask);
-                    const uint32_t nGive = nCan < (uint32_t)kStealGive ? nCan : (uint32_t)kStealGive;
-                    if (tailNow - headNow < kStealLow && tailNow + nGive <= tbl->poolCap) { // (wave-uniform)
-                        const uint32_t rank = (uint32_t)__popcll(donMask & ltMask);
-                        const bool gives = canDonate && rank < nGive;
-                        uint32_t base = 0;
-                        if (lane == (uint32_t)(__ffsll((long long)donMask) - 1)) base = atomicAdd(&tbl->poolTail, nGive);
-                        base = (uint32_t)__shfl((int)base, __ffsll((long long)donMask) - 1);
-                        const bool fits = base + nGive <= tbl->poolCap; // (entries beyond the capacity are never claimed)
-                        const SegDev &sgd = tbl->seg[segIdx >> 1];
-                        // (1) the ray's merge record exists before anybody else can see one of its subtrees
-                        bool first = false;
-                        if (gives && fits) first = atomicExch(&mGlobal[wave][slot], 1u) == 0u; // (one lane per ray of this wave)
-                        if (first) {
-                            if (segIdx & 1) {
-                                atomicExch(&sgd.sq.M[local], 1u); // this wave's group
-                            } else {
-                                atomicExch(reinterpret_cast<unsigned long long *>(&sgd.hits[local]), ((volatile unsigned long long *)mKey[wave])[slot]);
-                                reinterpret_cast<uint32_t *>(&sgd.hits[local])[2] = kSharedMark;
-                                reinterpret_cast<uint32_t *>(&sgd.hits[local])[3] = kSharedMark;
-                            }
-                        }
-                        // (everything shared between waves here is written by device-scope atomics, which execute at the memory side: what
-                        // has to be ordered is their completion, not a cache write-back)
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (gives && fits && (segIdx & 1)) atomicAdd(&sgd.sq.M[local], 1u); // the subtree handed over is one more group
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        // (2) publish: the OLDEST stack entry (the farthest, usually largest subtree), like the hand-over inside the wave
-                        if (gives && fits) {
-                            const int node = stackLane[0];
-                            __hip_atomic_store(&tbl->pool[base + rank], ((unsigned long long)(item + 1u) << 32) | (unsigned long long)(uint32_t)node, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                            sp -= 1;
-                            if (sp > 0) stackLane[0] = stackLane[sp * 64];
-                        } else if (gives && base + rank < tbl->poolCap) {
-                            // (a reservation that ran over the end of the pool is abandoned; its slots inside the pool say so)
-                            __hip_atomic_store(&tbl->pool[base + rank], ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-            }
-#endif
         }
-#endif
         if (nIdle == 64) { // nothing in flight (finished rays were retired at the end of the previous round)
             if (!exhausted) continue;
-#if HR_TAIL_SHARE && HR_STEAL
-            // ---------------- out of work: take subtrees from the steal pool, or leave
-            if (tbl->poolCap == 0u) break;
-            if (!toldIdle) {
-                toldIdle = true;
-                if (lane == 0) atomicExch(&tbl->idleSeen, 1u);
-            }
-            uint32_t got = 0, gotBase = 0;
-            for (int attempt = 0; attempt < kStealTries && got == 0u; ++attempt) {
-                if (lane == 0) {
-                    const unsigned long long ht = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&tbl->poolTail), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    uint32_t tailNow = (uint32_t)ht;
-                    const uint32_t headNow = (uint32_t)(ht >> 32);
-                    tailNow = tailNow < tbl->poolCap ? tailNow : tbl->poolCap;
-                    if (headNow < tailNow) {
-                        const uint32_t n = tailNow - headNow < 64u ? tailNow - headNow : 64u;
-                        if (atomicCAS(&tbl->poolHead, headNow, headNow + n) == headNow) got = n, gotBase = headNow;
-                    }
-                }
-                got = (uint32_t)__shfl((int)got, 0), gotBase = (uint32_t)__shfl((int)gotBase, 0);
-                if (got == 0u) __builtin_amdgcn_s_sleep(100);
-            }
-            if (got == 0u) break;
-            mCount[wave][lane] = 0u, mGlobal[wave][lane] = 0u, mKey[wave][lane] = kNoHitKey;
-            unsigned long long e = 0ull;
-            if (lane < got) {
-                do { // (the entry was reserved before it was written: its donor is a running wave, this wait is short)
-                    e = __hip_atomic_load(&tbl->pool[gotBase + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (e == 0ull) __builtin_amdgcn_s_sleep(2);
-                } while (e == 0ull);
-                __hip_atomic_store(&tbl->pool[gotBase + lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the pool is all-zero again when the launch ends
-            }
-            if (lane < got && (uint32_t)(e >> 32) != 0xFFFFFFFFu) { // (not an abandoned slot)
-                item = (uint32_t)(e >> 32) - 1u;
-                int sI = 0, sHiB = nSeg2 - 1;
-                while (sI < sHiB) {
-                    const int mid = (sI + sHiB + 1) >> 1;
-                    if (item >= segStart[mid])
-                        sI = mid;
-                    else
-                        sHiB = mid - 1;
-                }
-                segIdx = sI;
-                local = item - segStart[sI];
-                const SegDev &sg = tbl->seg[sI >> 1];
-                float4 a, b;
-                if (sI & 1) {
-                    a = G(sg.sq.A)[local], b = G(sg.sq.B)[local];
-                    skipPrim = __float_as_uint(b.w);
-                } else {
-                    a = G(sg.qin.A)[local], b = G(sg.qin.B)[local];
-                    skipPrim = (uint32_t)G(sg.qin.D)[local].z;
-                }
-                o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
-                tmax = a.w, tlim = a.w;
-                idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
-                {
-                    const RayK f = rayFrame(S, o, idx, idy, idz);
-                    oix = f.oix, oiy = f.oiy, oiz = f.oiz;
-                }
-                best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
-                sp = 0, pend = 0, cur = (int)(uint32_t)e;
-                slot = lane;
-                mCount[wave][lane] = 1u, mGlobal[wave][lane] = 1u;
-            }
-            __builtin_amdgcn_wave_barrier();
-            continue; // (the drain block above picks up what the others have found so far; then the node steps)
-#else
             break;
-#endif
         }
 #ifdef HR_TAILPROF
         if (exhausted) drainIters += 1, drainLanes += (unsigned long long)(64 - nIdle);
 #endif
 
         const bool isAny = (segIdx & 1) != 0;
-#if HR_ANY_UNORDERED
-        // A wave works through consecutive items of the launch's index space, so its rays are nearly always all of one kind; when every
-        // ray it holds is an occlusion ray, the node steps of this round are the unordered ones (hr_trace.h::nodeStep4Any)
-        const bool allAny = __ballot(item != 0xFFFFFFFFu && !isAny) == 0ull;
-        if (allAny) {
-#pragma unroll
-            for (int rep = 0; rep < HR_NODE_STEPS; ++rep) {
-                if (cur >= 0 && cur != kSentinel) {
-                    if (STATS) ++nvA;
-#ifdef HR_TAILPROF
-                    ++mySteps;
-#endif
-                    const RayK rk{idx, idy, idz, oix, oiy, oiz};
-                    nodeStep4Any(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
-                }
-                if (cur < 0 && pend == 0) {
-                    pend = cur;
-                    HR_POP();
-                }
-            }
-        } else
-#endif
         // ---------------- inner-node steps for every lane that holds an inner node
 #pragma unroll
         for (int rep = 0; rep < HR_NODE_STEPS; ++rep) {
@@ -753,11 +547,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 ++mySteps;
 #endif
                 const RayK rk{idx, idy, idz, oix, oiy, oiz};
-#if HR_NODE32
-                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, gk, tmin, tlim);
-#else
-                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim, isAny, topLds, topCount);
-#endif
+                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
             }
             // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
             // postponed it is blocked until the wave runs the triangle phase
@@ -808,9 +598,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                         best.prim = 0u; // occluded (anything but kMissPrim)
                         cur = kSentinel;
                         sp = 0;
-#if HR_TAIL_SHARE
                         if (draining) atomicMin(&mKey[wave][slot], 0ull); // the ray's other fragments stop at their next round
-#endif
                         break;
                     }
                     const uint32_t bp = best.prim & 0x7FFFFFFFu;
@@ -818,7 +606,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                         best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
                         best.t = t, best.u = u, best.v = v;
                         tlim = t;
-#if HR_TAIL_SHARE
                         if (draining) { // publish at once: subtrees handed to other lanes are speculative until a hit bounds them
                             const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)prim << 1) |
                                                           (unsigned long long)(det > 0.0f ? 1u : 0u);
@@ -826,13 +613,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                             __builtin_amdgcn_wave_barrier();
                             if (((volatile unsigned long long *)mKey[wave])[slot] == kk) mUV[wave][slot] = make_float2(u, v);
                         }
-#endif
                     }
                 }
             }
         }
         // ---------------- retire finished rays
-#if HR_TAIL_SHARE
         if (draining && cur == kSentinel && pend == 0 && item != 0xFFFFFFFFu) {
             // a fragment is done: fold its result into the ray's slot; the last fragment writes the ray's result
             const bool hit = best.prim != kMissPrim;
@@ -849,27 +634,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
             if (before == 1u) {
                 const unsigned long long k = ((volatile unsigned long long *)mKey[wave])[slot];
                 const SegDev &sg = tbl->seg[segIdx >> 1];
-#if HR_STEAL
-                const bool shared = ((volatile uint32_t *)mGlobal[wave])[slot] != 0u;
-                if (shared) {
-                    // this wave's group of the ray is done; other waves hold (or held) the rest
-                    if (isAny) {
-                        if (k != kNoHitKey) atomicOr(&sg.sq.M[local], kOccluded);
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        const uint32_t was = atomicSub(&sg.sq.M[local], 1u);
-                        if ((was & 0x3FFFFFFFu) == 1u && (was & kOccluded) == 0u && k == kNoHitKey) { // the last group, and nobody found an occluder
-                            const float4 c = G(sg.sq.C)[local];
-                            HR_GLOBAL float *px = G(sg.passbuf) + (size_t)__float_as_uint(c.w) * 4;
-                            px[0] = px[0] + c.x;
-                            px[1] = px[1] + c.y;
-                            px[2] = px[2] + c.z;
-                            ++nacc;
-                        }
-                    } else if (k != kNoHitKey) {
-                        atomicMin(reinterpret_cast<unsigned long long *>(&sg.hits[local]), k);
-                    }
-                } else
-#endif
                 if (isAny) {
                     if (k == kNoHitKey) {
                         const float4 c = G(sg.sq.C)[local];
@@ -895,7 +659,6 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #endif
             item = 0xFFFFFFFFu;
         }
-#endif
         if (cur == kSentinel && pend == 0 && item != 0xFFFFFFFFu) {
             const SegDev &sg = tbl->seg[segIdx >> 1];
             if (isAny) {
@@ -969,205 +732,9 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 #ifndef HR_SHADE_BLOCK
 #define HR_SHADE_BLOCK 256
 #endif
-#ifndef HR_SHADE_MINBLOCKS
-#define HR_SHADE_MINBLOCKS 4 // <= 128 VGPRs: four 256-thread workgroups per CU (measured best on MI355X; 5+ spills)
-#endif
 static const int kShadeBlock = HR_SHADE_BLOCK; // queue slots are reserved once per workgroup and pass (fewer same-address atomics)
-template <int MODE>
-__global__ __launch_bounds__(kShadeBlock, HR_SHADE_MINBLOCKS) void k_shade(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, Stats *stats)
-{
-    __shared__ uint32_t segStart[2 * kMaxSegs + 1];
-    __shared__ uint32_t scratch[2 + kShadeBlock / 64];
-    __shared__ int segRange[2];
-    __shared__ uint32_t waveHits[kShadeBlock / 64];
-    __shared__ uint16_t order[kShadeBlock];
-    const SceneDev &S = *Sp;
-    stats += blockIdx.x & (kStatSlots - 1);
-    buildSegStarts(tbl, segStart, true);
-    const int nSeg = tbl->nSeg;
-    const uint32_t total = segStart[2 * nSeg];
-    const uint32_t lane = laneId();
-    uint32_t nShaded = 0, nAccum = 0;
-    // Workgroups take kShadeBlock consecutive work items; a batch may straddle passes, so the compaction is done per
-    // pass present in the batch.  The trip count is uniform over the workgroup (barriers inside).
-    const uint32_t wave = threadIdx.x >> 6;
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
-    auto findSeg = [&](uint32_t item) { // last pass whose first index is <= item
-        int lo = 0, hiB = nSeg - 1;
-        while (lo < hiB) {
-            const int mid = (lo + hiB + 1) >> 1;
-            if (item >= segStart[2 * mid])
-                lo = mid;
-            else
-                hiB = mid - 1;
-        }
-        return lo;
-    };
-    for (uint32_t base = blockIdx.x * kShadeBlock; base < total; base += gridDim.x * kShadeBlock) {
-        // ---- regroup the workgroup's items by shader: PBR hits first, then glass hits, then everything else (misses), so that the
-        // long material shaders run on full, uniform waves instead of on the ~46 % of lanes that hit, split between two shaders
-        // (the results do not depend on who shades what)
-        int cls = 2;
-        {
-            const uint32_t i0 = base + threadIdx.x;
-            if (i0 < total) {
-                const int s0 = findSeg(i0);
-                const uint32_t hp = G(tbl->seg[s0].hits)[i0 - segStart[2 * s0]].prim;
-                if (hp != kMissPrim) {
-                    const uint32_t mid0 = G(S.attrs)[hp & 0x7FFFFFFFu].matflags & kMatMask;
-                    cls = (mid0 < (uint32_t)S.nMaterials && G(S.materials)[mid0].type == HR_MAT_GLASS) ? 1 : 0;
-                }
-            }
-        }
-        const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1);
-        if (lane == 0) waveHits[wave] = (uint32_t)__popcll(m0) | ((uint32_t)__popcll(m1) << 16);
-        __syncthreads();
-        uint32_t before0 = 0, before1 = 0, total0 = 0, total1 = 0;
-        for (uint32_t w = 0; w < (uint32_t)(kShadeBlock / 64); ++w) {
-            const uint32_t cnt = waveHits[w], c0 = cnt & 0xFFFFu, c1 = cnt >> 16;
-            before0 += (w < wave) ? c0 : 0u, before1 += (w < wave) ? c1 : 0u;
-            total0 += c0, total1 += c1;
-        }
-        {
-            const uint32_t r0 = (uint32_t)__popcll(m0 & ltMask), r1 = (uint32_t)__popcll(m1 & ltMask), r2 = lane - r0 - r1;
-            const uint32_t pos = cls == 0 ? before0 + r0 : (cls == 1 ? total0 + before1 + r1 : total0 + total1 + (wave * 64u - before0 - before1) + r2);
-            order[pos] = (uint16_t)threadIdx.x;
-        }
-        if (threadIdx.x == 0) {
-            const uint32_t last = (total - base < (uint32_t)kShadeBlock ? total - base : (uint32_t)kShadeBlock) - 1u;
-            segRange[0] = findSeg(base), segRange[1] = findSeg(base + last);
-        }
-        __syncthreads();
-        const uint32_t i = base + order[threadIdx.x];
-        const bool live = i < total;
-        const int sI = live ? findSeg(i) : 0;
-        constexpr bool LOD = (MODE & 1) != 0, ALL = (MODE & 2) != 0;
-        // extra[]: the additional occlusion rays of HR_ESTIMATOR_ALL_LIGHTS — [0] the analytic light, [1], [2] the second and third
-        // environment sample of a camera ray's hit (never valid in the kernels compiled without the estimator)
-        Ray nee, next;
-        ExtraRay extra[3];
-        nee.valid = next.valid = extra[0].valid = extra[1].valid = extra[2].valid = false;
-        uint32_t pixel = 0, prim = 0xFFFFFFFFu;
-        v3 neeValue(0.0f), hitP(0.0f);
-        if (live) {
-            const SegDev &sg = tbl->seg[sI];
-            const uint32_t li = i - segStart[2 * sI];
-            const float4 a = G(sg.qin.A)[li], b = G(sg.qin.B)[li], c = G(sg.qin.C)[li];
-            const int4 dm = G(sg.qin.D)[li];
-            const HitRec h = G(sg.hits)[li];
-            Ray in;
-            in.o = v3(a.x, a.y, a.z), in.d = v3(b.x, b.y, b.z), in.maxT = a.w, in.extraT = b.w;
-            in.weight = v3(c.x, c.y, c.z);
-            pixel = __float_as_uint(c.w);
-            const uint32_t meta = (uint32_t)dm.x;
-            in.sequenceID = (int)(meta & 0xFFu), in.depth = (int)((meta >> 8) & 0xFFFFu);
-            in.missKind = (int)((meta >> 24) & 7u), in.missIdx = (int)((meta >> 27) & 7u);
-            in.sequenceIndexOffset = dm.y;
-            in.occlusionTest = false, in.valid = true;
-            in.coneW = in.coneG = 0.0f; // (the variant without the mode carries no cone: nothing to keep in registers)
-            if (LOD) unpackCone((uint32_t)dm.w, in.coneW, in.coneG);
-            ShaderT<MODE> sh(S, sg.pp, G(sg.passbuf) + (size_t)pixel * 4);
-            if (h.prim == kMissPrim) {
-                // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
-                if (in.missKind == MISS_ENV) sh.performAccumulate(sh.environmentRadiance(in.d, in.weight));
-            } else {
-                prim = h.prim & 0x7FFFFFFFu;
-                uint32_t mid;
-                const typename ShaderT<MODE>::Surface sf = sh.surface(in, prim, (h.prim >> 31) != 0u, h.t, h.u, h.v, mid);
-                sh.setFootprint(in, sf.normal, h.t, prim);
-                if (mid < (uint32_t)S.nMaterials) {
-                    const HR_GLOBAL hr_material &M = G(S.materials)[mid];
-                    if (M.type == HR_MAT_GLASS) {
-                        ++nShaded;
-                        sh.glass(in, sf, h.t, M, nee, next, extra[0]);
-                    } else if (M.type == HR_MAT_PBR) {
-                        ++nShaded;
-                        sh.physicallyBased(in, sf, M, nee, next, extra[0], extra[1], extra[2]);
-                    }
-                }
-                if (nee.valid) nee.valid = sh.lightShaderValue(nee, neeValue);
-                if (ALL) hitP = sf.P; // (where the additional occlusion rays start)
-            }
-            nAccum += sh.nAccum;
-        }
-        // per-pass compaction of the emitted rays (the passes present in this batch are a contiguous range)
-        const int sLo = segRange[0], sHi = segRange[1];
-        if (sHi - sLo >= 2) {
-            // A batch that spans several passes (the late stages of a pass hold a few rays each, and a launch carries dozens of passes):
-            // one reservation per wave and pass PRESENT in the wave, instead of two or more block-wide reservations — barriers and a
-            // returning atomic each — for every pass of the range whether it emitted anything or not (that loop was the 35-45 us floor
-            // of every late-stage launch).  Slot order inside a queue never matters: every ray carries its pixel.
-            unsigned long long todo = __ballot(live && (nee.valid || next.valid || (ALL && (extra[0].valid || extra[1].valid || extra[2].valid))));
-            while (todo != 0ull) {
-                const int s = __shfl(sI, __ffsll((long long)todo) - 1);
-                const bool mine = live && sI == s;
-                todo &= ~__ballot(mine);
-                const SegDev &sg = tbl->seg[s];
-                const bool wantS = mine && nee.valid;
-                const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
-                if (wantS) {
-                    G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
-                    G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-                    G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
-                }
-                if (ALL) {
-                    const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const bool wantX = mine && extra[j].valid;
-                        const uint32_t sx = waveReserve(wantX, sg.sCountOut);
-                        if (wantX) {
-                            G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
-                            G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
-                            G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
-                        }
-                    }
-                }
-                const bool wantQ = mine && next.valid;
-                const uint32_t qSlot = waveReserve(wantQ, sg.qCountOut);
-                if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
-            }
-            continue;
-        }
-        for (int s = sLo; s <= sHi; ++s) {
-            const SegDev &sg = tbl->seg[s];
-            const bool mine = live && sI == s;
-            const bool wantS = mine && nee.valid;
-            const uint32_t sSlot = blockReserve(wantS, sg.sCountOut, scratch);
-            if (wantS) {
-                G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
-                G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-                G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
-            }
-            if (ALL) {
-                // each extra ray adds to a partial sum of its own (no two rays of a launch may write one pixel): partial sum j + 1 lies
-                // (j + 1) frames behind the first in the pass's buffer — the trace kernel just sees a pixel index beyond the frame
-                const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const bool wantX = mine && extra[j].valid;
-                    const uint32_t sx = blockReserve(wantX, sg.sCountOut, scratch);
-                    if (wantX) {
-                        G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
-                        G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
-                        G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
-                    }
-                }
-            }
-            const bool wantQ = mine && next.valid;
-            const uint32_t qSlot = blockReserve(wantQ, sg.qCountOut, scratch);
-            if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
-        }
-    }
-    nShaded = waveSum(nShaded), nAccum = waveSum(nAccum);
-    if (lane == 0) {
-        if (nShaded) atomicAdd(&stats->shadedHits, (unsigned long long)nShaded);
-        if (nAccum) atomicAdd(&stats->accumulates, (unsigned long long)nAccum);
-    }
-}
-
 // ------------------------------------------------------------------------- shade, split by shader
-// Round 3: the shading stage as three kernels instead of one (the one above stays buildable behind HR_TUNE="shade=0" for A/Bs).
+// Since round 3 the shading stage is three kernels (the fused single kernel of rounds 1-2: profiles/experiments/).
 //
 //   k_shade_sort            one lane per closest-hit ray: a ray that hit nothing runs its defaultPrimitive's shader right here (the
 //                           environment lookup; nothing at all for rl_NullPrimitive); a ray that hit something is appended to its
@@ -1242,34 +809,6 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
         if (live) {
             const SegDev &sg = tbl->seg[sI];
             uint32_t hp = G(sg.hits)[li].prim;
-#if HR_STEAL
-            if (__float_as_uint(G(sg.hits)[li].u) == kSharedMark) {
-                // The ray was traversed by several waves (k_trace's steal pool): its record still holds the merged 64-bit key
-                // (t, triangle, face).  Turn it into a hit record; the barycentrics are those of the triangle test itself — the same
-                // operations on the same operands as in the traversal, so the same bits.
-                const unsigned long long key = *reinterpret_cast<const HR_GLOBAL unsigned long long *>(G(sg.hits) + li);
-                HitRec h;
-                h.prim = kMissPrim, h.t = G(sg.qin.A)[li].w, h.u = 0.0f, h.v = 0.0f;
-                if (key != kNoHitKey) {
-                    const uint32_t lo = (uint32_t)key, prim = lo >> 1;
-                    const float4 a = G(sg.qin.A)[li], b = G(sg.qin.B)[li];
-                    const v3 o(a.x, a.y, a.z), d(b.x, b.y, b.z);
-                    const HR_GLOBAL Tri &tr = G(S.tris)[G(S.slotOfPrim)[prim]];
-                    const float4 tp = tr.p, tq = tr.q, trr = tr.r;
-                    const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
-                    const v3 pvec = cross(d, e2);
-                    const float det = dot(e1, pvec);
-                    const float inv = 1.0f / det;
-                    const v3 tvec = o - v0;
-                    const float u = dot(tvec, pvec) * inv;
-                    const v3 qvec = cross(tvec, e1);
-                    const float v = dot(d, qvec) * inv;
-                    h.prim = (lo >> 1) | (lo << 31), h.t = __uint_as_float((uint32_t)(key >> 32)), h.u = u, h.v = v;
-                }
-                G(sg.hits)[li] = h;
-                hp = h.prim;
-            }
-#endif
             if (hp == kMissPrim) {
                 // a ray that hits nothing runs its defaultPrimitive's shader (none for rl_NullPrimitive)
                 const uint32_t meta = (uint32_t)G(sg.qin.D)[li].x;
@@ -1510,15 +1049,6 @@ void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, 
     const int grid = cfg.numCUs * cfg.shadeBlocksPerCU;
     // four instantiations: bit 0 = HR_TEXTURE_LOD_CONE, bit 1 = HR_ESTIMATOR_ALL_LIGHTS compiled in; the plain one runs until a pass asks for more
     const int mode = (cfg.textureLod ? 1 : 0) | (cfg.allLights ? 2 : 0);
-    if (cfg.fusedShade) {
-        switch (mode) {
-        case 0: hipLaunchKernelGGL(k_shade<0>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
-        case 1: hipLaunchKernelGGL(k_shade<1>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
-        case 2: hipLaunchKernelGGL(k_shade<2>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
-        default: hipLaunchKernelGGL(k_shade<3>, dim3(grid), dim3(kShadeBlock), 0, cfg.stream, S, tbl, stats); break;
-        }
-        return;
-    }
     hipLaunchKernelGGL(k_shade_sort, dim3(cfg.numCUs * 8), dim3(kSortBlock), 0, cfg.stream, S, tbl, stats);
     switch (mode) {
     case 0: launchShadeHit<0>(cfg, grid, S, tbl, stats); break;

@@ -699,9 +699,8 @@ def test_full_size_config2_properties(golden):
 # ------------------------------------------------------------- the pass pipeline's scheduling never changes the result
 @pytest.mark.parametrize("tune", ["groups=1,batch=1", "groups=2", "groups=3,batch=2", "groups=2,batch=5,depth=24",
                                   "fmin=16,fmax=256,refill=16,tri=8,blocks=3", "groups=4,batch=16",
-                                  # round 3's knobs: the single shading kernel of rounds 1-2, every launch through the work cursor, every
-                                  # launch dealt out statically
-                                  "shade=0", "sdeal=0,batch=3", "sdeal=1000000,groups=1",
+                                  # round 3's knobs: every launch through the work cursor, every launch dealt out statically
+                                  "sdeal=0,batch=3", "sdeal=1000000,groups=1",
                                   # the work fetch: one cursor / 64 range cursors, camera rays in long / short chunks
                                   "sdeal=0,heads=0,fprim=256,fgate=0", "sdeal=0,heads=6,fprim=32,fgate=0,fmin=16,batch=7"])
 def test_pipeline_scheduling_is_result_invariant(golden, monkeypatch, tune):
