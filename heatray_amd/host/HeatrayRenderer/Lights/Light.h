@@ -5,6 +5,10 @@
 
 #include "ShaderLightingDefines.h"
 
+// The application's own headers rely on Utility/Log.h arriving through this file: in the reference it came in through
+// Lights/Light.h:13 -> RLWrapper/Program.h:15 (and Error.h:11), and HeatrayRenderer.h:159,177 use LOG_ERROR without including it.
+#include <Utility/Log.h>
+
 #include <memory>
 #include <string>
 #include <string_view>

@@ -13,6 +13,8 @@
 
 #include <hrcore.h>
 
+#include <Utility/Log.h>
+
 #include <assert.h>
 #include <stdio.h>
 
@@ -30,7 +32,11 @@ inline hr_ctx*& currentContext()
 inline bool checkStatus(int status, const char* call)
 {
     if (status != HR_OK) {
-        fprintf(stderr, "libhrcore error %d in %s: %s\n", status, call, hr_last_error(currentContext()));
+        // (the application's logger when one is installed — the viewer's ImGuiLog — else stderr: errors are never silent)
+        if (util::Log::instance())
+            LOG_ERROR("libhrcore error %d in %s: %s", status, call, hr_last_error(currentContext()));
+        else
+            fprintf(stderr, "libhrcore error %d in %s: %s\n", status, call, hr_last_error(currentContext()));
         assert(0 && "libhrcore call failed");
         return false;
     }
