@@ -127,6 +127,40 @@ def cpu_baseline(sc, budget_s, lut):
     }
 
 
+def parity_leg(sc, eng_frame, first_pass, n_passes, budget_s, world_label):
+    """GPU vs the CPU oracle (the PARITY build: -O2 -ffp-contract=off, the checker of tests/) on the frame the timed region itself
+    produced: the oracle renders the same passes of the same scene and the HDR buffers are compared pixel for pixel.  The whole
+    frame when that fits `budget_s` of host time (a one-pass probe decides); otherwise an interleaved 1/k shard of the frame's
+    32x32 tiles, all passes.  BASELINE.md §2: "rel-L2 of GPU HDR buffer vs oracle" per configuration."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    t0 = time.perf_counter()
+    o = oracle_lib.engine()
+    sc.apply(o)  # tables and LUT from the oracle's own generators (bit-identical to the device's: tests/test_gpu_parity.py)
+    t1 = time.perf_counter()
+    o.render_pass(sc.options.pass_params(first_pass))
+    per_pass = time.perf_counter() - t1
+    k = 1
+    if per_pass * n_passes > budget_s:
+        k = int(min(64, math.ceil(per_pass * n_passes / budget_s)))
+        o.close()
+        o = oracle_lib.engine(rank=k // 2, world=k, tile_size=32)
+        sc.apply(o)
+        o.render_pass(sc.options.pass_params(first_pass))
+    for i in range(1, n_passes):
+        o.render_pass(sc.options.pass_params(first_pass + i))
+    ref = o.readback()
+    o.close()
+    own = np.ones(ref.shape[:2], dtype=bool) if k == 1 else (tiles.owner_map(sc.width, sc.height, k) == k // 2)
+    g, r = eng_frame[own].astype(np.float64), ref[own].astype(np.float64)
+    differing = int((eng_frame[own] != ref[own]).any(axis=-1).sum())
+    return {"rel_l2": float(np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)), "bit_exact": differing == 0, "pixels": int(own.sum()),
+            "differing_pixels": differing, "passes": n_passes, "tolerance_rel_l2": 1e-4,
+            "frame": f"the timed region's own output{world_label}: passes {first_pass}..{first_pass + n_passes - 1}, "
+                     + ("every pixel of the frame" if k == 1 else f"the interleaved tile shard {k // 2} of {k} (32x32 tiles over the whole frame)"),
+            "checker": "oracle/liboracle.so (parity build), OpenMP on the host cores", "seconds": time.perf_counter() - t0}
+
+
 def _short_kernel(name):
     n = name.split("(")[0].replace("void ", "").replace("hr::", "")
     return n.split("<")[0]
@@ -153,7 +187,7 @@ def pmc_legs(args, keep_dir=None):
     # busy fractions and bytes per ray then describe a warm device at the step count the line is quoted on, not a cold process's
     # first milliseconds (on a fresh box those run up to a fifth slower).
     child = [sys.executable if os.path.basename(sys.executable).startswith("python") else "python3", os.path.join(ROOT, "bench.py"),
-             "--pmc-child", "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--no-stats-pass",
+             "--pmc-child", "--workload", args.workload, "--steps", str(args.steps), "--warmup", str(args.warmup), "--cpu-seconds", "0", "--parity-seconds", "0", "--no-stats-pass",
              "--no-pmc", "--no-converge", "--estimator", args.estimator, "--width", str(args.width), "--height", str(args.height), "--depth", str(args.depth)]
     env = dict(os.environ, TMPDIR="/tmp")
     res = {"kernels": {}, "passes": {}, "dir": out_root if keep_dir else None}
@@ -344,6 +378,8 @@ def main():
     ap.add_argument("--no-wakeup", action="store_true", help="skip the untimed device wake-up (profiling runs: every k_trace "
                     "launch rocprofv3 sees then belongs to the timed region)")
     ap.add_argument("--no-stats-pass", action="store_true", help="skip the extra counted pass that measures V and T")
+    ap.add_argument("--parity-seconds", type=float, default=None, help="host-time budget of the parity leg: the timed region's frame against the "
+                    "CPU oracle's render of the same passes (default 25; 0 = skip, which is also --quick's default: the line then carries no parity object)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (the roofline then quotes the committed per-ray "
                     "figures of profiles/traffic.json, scaled by this run's rays, and says so)")
     ap.add_argument("--quick", action="store_true", help="tuning runs: only the timed region (= --cpu-seconds 0 --no-stats-pass --no-pmc --no-converge)")
@@ -352,6 +388,8 @@ def main():
     args = ap.parse_args()
     if args.quick:
         args.cpu_seconds, args.no_stats_pass, args.no_pmc, args.no_converge = 0.0, True, True, True
+    if args.parity_seconds is None:
+        args.parity_seconds = 0.0 if args.quick else 25.0
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -444,8 +482,23 @@ def main():
     # ahead: in the timed loop the host only hands them over, as the reference's host does
     pass_blocks = [sc.options.pass_params(i) for i in range(passes_total)]
 
+    # SURVEY 8d metric 1 asks for min / median per pass beside the mean.  Passes complete a batch at a time (the pipeline keeps depth + 2
+    # stages in flight), so the unit that can be timed is the batch: whenever the library has enqueued the resolve of further passes on
+    # the ctx stream (hr_frame_passes_resolved: a host-side counter), an event is recorded behind it on that stream; consecutive events
+    # give (passes, milliseconds) per batch.
+    marks = []
+
+    def mark():
+        n = eng.passes_resolved()
+        if not marks or n > marks[-1][0]:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((n, ev))
+
     def step(i):
         eng.render_pass(pass_blocks[i])
+        if timing_marks:
+            mark()
         if exchange and (i + 1) % post_every == 0:
             # Progressive display: every step each rank packs the pixels it owns (1/world of the RGBA32F buffer) and
             # RCCL gathers them on rank 0, on a side stream so the exchange overlaps the next pass's kernels.  The
@@ -466,6 +519,7 @@ def main():
             torch.cuda.synchronize()
     wake_s = time.perf_counter() - t_wake
     eng.clear()
+    timing_marks = False
     for i in range(args.warmup):
         step(i)
     eng.clear()  # resets the accumulation buffer, the device counters and the kernel timers
@@ -473,10 +527,13 @@ def main():
     if exchange:
         dist.barrier()
     torch.cuda.synchronize()
+    timing_marks = True
     t0 = time.perf_counter()
+    mark()  # (0 passes: the start of the timed region on the stream)
     for i in range(args.steps):
         step(args.warmup + i)
     eng.flush()  # the pass pipeline keeps depth+2 passes in flight: enqueue their remaining stages
+    mark()
     full = fb
     if exchange:
         gatherer.post(fb)  # the finished image
@@ -504,6 +561,29 @@ def main():
             a = a[torch.from_numpy(tiles.owner_map(sc.width, sc.height, eng_world) == eng_rank).to(dev)]
         assert bool((a == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
         assert bool(torch.isfinite(full).all())
+        # digest of the final assembled RGBA32F frame: the same passes give the same bits for every N (SURVEY 8e acceptance:
+        # "8-GPU buffer == 1-GPU buffer bit for bit"), so the driver's SCALE lines can be compared with its BENCH line
+        import hashlib
+        frame_host = full.cpu().numpy()
+        frame_sha256 = None if emulated else hashlib.sha256(frame_host.tobytes()).hexdigest()
+        # per-batch completion times (marks above): ms per pass of every batch that completed inside the timed region
+        per_batch = []
+        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+            if n1 > n0:
+                per_batch.append(e0.elapsed_time(e1) / (n1 - n0))
+        batch_stats = None
+        if per_batch:
+            srt = sorted(per_batch)
+            batch_stats = {"min": srt[0], "median": float(np.median(srt)), "max": srt[-1], "batches": len(srt),
+                           "passes_per_batch": [int(b[0] - a[0]) for a, b in zip(marks[:-1], marks[1:]) if b[0] > a[0]],
+                           "definition": "device time between the resolves of consecutive batches of passes (events on the ctx stream) / passes in the "
+                                         "batch; the first batch includes the pipeline's fill, the last ones its drain"}
+        # ---- parity of the timed region's own output against the CPU oracle (every N; rank 0 holds the assembled frame)
+        parity = None
+        if args.parity_seconds > 0 and not emulated and not args.pmc_child:
+            parity = parity_leg(sc, frame_host, args.warmup, args.steps, args.parity_seconds,
+                                f" (assembled from {world} ranks' tiles)" if world > 1 else "")
+            assert parity["rel_l2"] <= 1e-4, f"GPU frame differs from the oracle's: {parity}"
 
         # ---- cpu_baseline leg (N = 1 only): also yields V, T of the roofline model measured by the oracle on the spec BVH
         cpu = None
@@ -690,7 +770,10 @@ def main():
             "value": mrays, "unit": "Mrays/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
             # untimed device wake-up BEFORE the W warm-up steps (clock ramp / first touch of the pass slots on a freshly started box)
             "wakeup_passes": n_wake, "wakeup_s": wake_s,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_min": batch_stats["min"] if batch_stats else None, "ms_per_step_median": batch_stats["median"] if batch_stats else None,
+            "ms_per_step_batches": batch_stats,
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "width": sc.width, "height": sc.height,
                        "max_ray_depth": sc.options.max_ray_depth, "triangles": int(info.n_triangles), "bvh_nodes": int(info.n_nodes),
@@ -700,6 +783,8 @@ def main():
             "pmc_passes": None if pmc is None else {"seconds": pmc.get("seconds"), "failed": bool(pmc.get("failed")), "passes": pmc.get("passes"),
                                                     "k_trace": pmc.get("kernels", {}).get("k_trace")},
             "cpu_baseline": cpu,
+            "parity": parity,
+            "frame_sha256": frame_sha256,
             "passes_to_converge": conv,
             "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,
                       "rays_per_path": total_rays / max(total_paths, 1.0), "bvh_build_ms": info.build_ms,

@@ -154,7 +154,7 @@ ABI_SYMBOLS = [
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
-    "display", "display_readback", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
+    "display", "display_readback", "frame_passes_resolved", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
     "frame_pass_batch", "interactive_blocks_set", "scene_cache",
 ]
 
@@ -383,16 +383,25 @@ class Engine:
         a = np.ctypeslib.as_array(p, shape=(h.value, w.value, 4))
         return a.copy() if copy else a
 
-    def display(self, params=None, fmt=HR_DISPLAY_RGBA8):
-        """Display resolve of the accumulation buffer -> numpy: uint8 [H, W, 4] (RGBA8) or float32 [H, W, 4]."""
+    def display(self, params=None, fmt=HR_DISPLAY_RGBA8, with_passes=False):
+        """Display resolve of the accumulation buffer -> numpy: uint8 [H, W, 4] (RGBA8) or float32 [H, W, 4];
+        with_passes: (image, number of complete passes it shows)."""
         params = params if params is not None else display_params()
         dt, ch = (np.uint8, 4) if (fmt & 0xFF) == HR_DISPLAY_RGBA8 else (np.float32, 4)
         p = C.c_void_p()
         w, h = C.c_int32(), C.c_int32()
-        self._call("display_readback", C.byref(params), C.c_int32(fmt), C.byref(p), C.byref(w), C.byref(h))
+        shown = C.c_uint32()
+        self._call("display_readback", C.byref(params), C.c_int32(fmt), C.byref(p), C.byref(w), C.byref(h), C.byref(shown))
         n = w.value * h.value * ch
         buf = (C.c_uint8 * n).from_address(p.value) if dt is np.uint8 else (C.c_float * n).from_address(p.value)
-        return np.frombuffer(buf, dtype=dt).reshape(h.value, w.value, ch).copy()
+        img = np.frombuffer(buf, dtype=dt).reshape(h.value, w.value, ch).copy()
+        return (img, int(shown.value)) if with_passes else img
+
+    def passes_resolved(self):
+        """Passes added to the accumulation buffer since the last clear, as enqueued so far (no synchronisation)."""
+        n = C.c_uint64()
+        self._call("frame_passes_resolved", C.byref(n))
+        return int(n.value)
 
     # -- tile-shard exchange (device pointers for the HIP core, host pointers for the oracle)
     def packed_slots(self, rank, world):
@@ -410,7 +419,7 @@ class Engine:
     def display_device(self, device_ptr, params=None, fmt=HR_DISPLAY_RGBA8):
         """Asynchronous display resolve into device memory (e.g. a torch tensor or a GL-interop buffer)."""
         params = params if params is not None else display_params()
-        self._call("display", C.byref(params), C.c_int32(fmt), C.c_void_p(int(device_ptr)))
+        self._call("display", C.byref(params), C.c_int32(fmt), C.c_void_p(int(device_ptr)), None)
 
     def readback_progressive(self, copy=True):
         """(buffer, complete passes in it) without completing the passes still in the pipeline.  copy=False returns a view

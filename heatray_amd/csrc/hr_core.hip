@@ -666,7 +666,7 @@ int hr_frame_unpack(hr_ctx *c, int32_t src_rank, int32_t world, const void *devi
 
 static size_t displayPixelBytes(int32_t format) { return format == HR_DISPLAY_RGBA8 ? 4 : 16; }
 
-int hr_display(hr_ctx *c, const hr_display_params *params, int32_t format, void *device_out)
+int hr_display(hr_ctx *c, const hr_display_params *params, int32_t format, void *device_out, uint32_t *passes_shown)
 {
     ENTER(c);
     if (!params || !device_out) FAIL(c, HR_ERR_INVALID, "null argument");
@@ -682,10 +682,19 @@ int hr_display(hr_ctx *c, const hr_display_params *params, int32_t format, void 
     fr.fb = c->fb();
     launchDisplay(c->cfg(c->stream), fr, *params, format, device_out);
     HIP_TRY(c, hipGetLastError());
+    if (passes_shown) *passes_shown = (uint32_t)(c->nextResolveOrder - c->resolvedAtClear); // (the resolves enqueued before this kernel, same stream)
     return HR_OK;
 }
 
-int hr_display_readback(hr_ctx *c, const hr_display_params *params, int32_t format, const void **pixels, int32_t *width, int32_t *height)
+int hr_frame_passes_resolved(hr_ctx *c, uint64_t *passes)
+{
+    ENTER(c);
+    if (!passes) FAIL(c, HR_ERR_INVALID, "null output");
+    *passes = c->nextResolveOrder - c->resolvedAtClear;
+    return HR_OK;
+}
+
+int hr_display_readback(hr_ctx *c, const hr_display_params *params, int32_t format, const void **pixels, int32_t *width, int32_t *height, uint32_t *passes_shown)
 {
     ENTER(c);
     if (!pixels) FAIL(c, HR_ERR_INVALID, "null output");
@@ -705,20 +714,20 @@ int hr_display_readback(hr_ctx *c, const hr_display_params *params, int32_t form
         rc = ensureLagged(c, c->progDisplay, need, true);
         if (rc) return rc;
         const int k = beginLagged(c->progDisplay);
-        rc = hr_display(c, params, format, c->progDisplay.dev[k]);
+        rc = hr_display(c, params, format, c->progDisplay.dev[k], nullptr);
         if (rc) return rc;
         const size_t nb = (size_t)c->W * c->H * displayPixelBytes(format & ~HR_DISPLAY_PROGRESSIVE);
         HIP_TRY(c, hipMemcpyAsync(c->progDisplay.pinned[k], c->progDisplay.dev[k], nb, hipMemcpyDeviceToHost, c->stream));
         // the parameters are part of the snapshot's identity: a change of settings must not hand out an old image
         int32_t key = format;
         for (size_t i = 0; i < sizeof(*params) / 4; ++i) key = key * 31 + ((const int32_t *)params)[i];
-        rc = finishLagged(c, c->progDisplay, k, key, pixels, nullptr);
+        rc = finishLagged(c, c->progDisplay, k, key, pixels, passes_shown); // (the passes of the snapshot handed out, which may be the previous call's)
         if (rc) return rc;
         if (width) *width = c->W;
         if (height) *height = c->H;
         return HR_OK;
     }
-    int rc = hr_display(c, params, format, c->dDisplay);
+    int rc = hr_display(c, params, format, c->dDisplay, passes_shown);
     if (rc) return rc;
     const size_t bytes = (size_t)c->W * c->H * displayPixelBytes(format & ~HR_DISPLAY_PROGRESSIVE);
     HIP_TRY(c, hipMemcpyAsync(c->pinnedDisplay, c->dDisplay, bytes, hipMemcpyDeviceToHost, c->stream));

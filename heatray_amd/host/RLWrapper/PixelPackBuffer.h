@@ -70,12 +70,13 @@ public:
     // format: HR_DISPLAY_RGBA8 (4 x fewer bytes over PCIe), HR_DISPLAY_RGBA32F or HR_DISPLAY_HDR_RGBA32F (saveScreenshot).
     // The pointer stays valid until the next resolveForDisplay(), resize or context destruction.
     // complete = false: progressive, like setPixelData(false) (pixels without a complete pass yet come out black).
-    inline const void* resolveForDisplay(const hr_display_params& params, int32_t format = HR_DISPLAY_RGBA8, bool complete = true)
+    // passesShown (optional): how many complete passes the returned image holds (a progressive image lags the requests).
+    inline const void* resolveForDisplay(const hr_display_params& params, int32_t format = HR_DISPLAY_RGBA8, bool complete = true, uint32_t* passesShown = nullptr)
     {
         if (!complete) format |= HR_DISPLAY_PROGRESSIVE;
         const void* pixels = nullptr;
         int32_t w = 0, h = 0;
-        if (HRFunc(hr_display_readback(currentContext(), &params, format, &pixels, &w, &h))) {
+        if (HRFunc(hr_display_readback(currentContext(), &params, format, &pixels, &w, &h, passesShown))) {
             m_width = w;
             m_height = h;
         }

@@ -458,12 +458,18 @@ typedef struct hr_display_params {            /* HeatrayRenderer.h:104-117 PostP
 
 /* Completes all enqueued passes (unless HR_DISPLAY_PROGRESSIVE), then writes width*height pixels (row 0 = bottom, like the accumulation
  * buffer) to device memory `device_out` (asynchronous on the ctx stream). Pixels without samples (a == 0) give
- * colour 0.  Pixels owned by other ranks of a tile-sharded frame are written as 0. */
-int hr_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *device_out);
+ * colour 0.  Pixels owned by other ranks of a tile-sharded frame are written as 0.
+ * `passes_shown` (may be NULL) receives the number of complete passes since the last hr_clear that the image holds — with
+ * HR_DISPLAY_PROGRESSIVE that is whatever had been resolved when the call was made, and only the call itself can say which
+ * (a later hr_readback_progressive may already see more). */
+int hr_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *device_out, uint32_t *passes_shown);
 /* Same, into a pinned host buffer owned by the ctx (synchronous); valid until the next hr_display_readback /
  * hr_frame_resize / hr_ctx_destroy.  Replaces the mapPixelData -> glBufferSubData upload of the HDR buffer. */
 int hr_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t format, const void **pixels, int32_t *width,
-                        int32_t *height);
+                        int32_t *height, uint32_t *passes_shown);
+/* Passes whose sample has been added to the accumulation buffer since the last hr_clear, as enqueued on the ctx stream so far
+ * (a host-side counter: no synchronisation).  Work enqueued on the ctx stream after this call sees exactly that many passes. */
+int hr_frame_passes_resolved(hr_ctx *ctx, uint64_t *passes);
 
 /* ------------------------------------------------------------------ tile-shard exchange
  * The "RCCL reduce of the HDR accumulation buffer" of the north-star, done as a gather of the tiles each rank

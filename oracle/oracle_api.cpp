@@ -368,25 +368,32 @@ int ora_frame_unpack(hr_ctx *ctx, int32_t rank, int32_t world, const void *packe
     return HR_OK;
 }
 
-int ora_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *out)
+int ora_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, void *out, uint32_t *passes_shown)
 {
     if (!params || !out) ORA_FAIL(ctx, HR_ERR_INVALID, "null argument");
     if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
     format &= ~HR_DISPLAY_PROGRESSIVE; // the oracle has no pipeline
     if (format < HR_DISPLAY_RGBA8 || format > HR_DISPLAY_HDR_RGBA32F) ORA_FAIL(ctx, HR_ERR_INVALID, "unknown display format");
     displayResolve(ctx->c, *params, format, out);
+    if (passes_shown) *passes_shown = ctx->passesSinceClear;
     return HR_OK;
 }
-int ora_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t format, const void **pixels, int32_t *w, int32_t *h)
+int ora_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t format, const void **pixels, int32_t *w, int32_t *h, uint32_t *passes_shown)
 {
     if (!pixels) ORA_FAIL(ctx, HR_ERR_INVALID, "null output");
     if (ctx->c.W <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "no frame");
     ctx->display.resize((size_t)ctx->c.W * ctx->c.H * 4);
-    int rc = ora_display(ctx, params, format, ctx->display.data());
+    int rc = ora_display(ctx, params, format, ctx->display.data(), passes_shown);
     if (rc) return rc;
     *pixels = ctx->display.data();
     if (w) *w = ctx->c.W;
     if (h) *h = ctx->c.H;
+    return HR_OK;
+}
+int ora_frame_passes_resolved(hr_ctx *ctx, uint64_t *passes)
+{
+    if (!passes) ORA_FAIL(ctx, HR_ERR_INVALID, "null output");
+    *passes = ctx->passesSinceClear;
     return HR_OK;
 }
 int ora_readback_progressive(hr_ctx *ctx, const float **rgba, int32_t *w, int32_t *h, uint32_t *passes)

@@ -51,8 +51,8 @@ def test_plain_start_with_two_gpus_launches_ranks_and_fails_loudly_without_devic
 
 @pytest.mark.gpu
 def test_two_rank_rehearsal_on_one_device():
-    r = _run(["--gpus", "2", "--quick", "--steps", "70", "--warmup", "1", "--workload", "c2", "--width", "512", "--height", "288"],  # (two exchanges on the way + the final one)
-             env={"HR_BENCH_ONE_DEVICE": "1"}, timeout=900)
+    args = ["--quick", "--parity-seconds", "30", "--steps", "70", "--warmup", "1", "--workload", "c2", "--width", "512", "--height", "288"]  # (two exchanges on the way + the final one)
+    r = _run(["--gpus", "2"] + args, env={"HR_BENCH_ONE_DEVICE": "1"}, timeout=900)
     assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout.decode(errors="replace")[-2000:]
@@ -60,3 +60,15 @@ def test_two_rank_rehearsal_on_one_device():
     assert d["n_gpus"] == 2 and d["rehearsal_one_device"] is True and d["steps"] == 70
     assert "REHEARSAL" in d["metric"]
     assert d["value"] > 0 and d["extra"]["rays"] > 0
+    # SURVEY 8e acceptance, checked on the line itself: the frame assembled from the two ranks' tiles equals the frame ONE rank renders
+    # (same passes => same digest), and both equal the CPU oracle's render of those passes, every pixel
+    r1 = _run(["--gpus", "1"] + args, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode(errors="replace")[-3000:]
+    d1 = json.loads(_json_lines(r1.stdout)[0])
+    assert d1["n_gpus"] == 1 and d1["steps"] == 70
+    assert isinstance(d["frame_sha256"], str) and len(d["frame_sha256"]) == 64
+    assert d["frame_sha256"] == d1["frame_sha256"]
+    for line in (d, d1):
+        p = line["parity"]
+        assert p["bit_exact"] is True and p["rel_l2"] == 0.0 and p["pixels"] == 512 * 288 and p["passes"] == 70
+    assert d1["ms_per_step_min"] <= d1["ms_per_step_median"] and d1["ms_per_step_batches"]["batches"] >= 1

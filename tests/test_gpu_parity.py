@@ -685,15 +685,17 @@ def test_full_size_config2_properties(golden):
         e.render_pass(sc.options.pass_params(s))
         parts.append(e.readback().astype(np.float64))
     assert np.allclose(parts[0] + parts[1] + parts[2], a, rtol=1e-5, atol=1e-6)
-    # one 32x32 tile of the full-size frame against the oracle (the oracle renders only the tile it owns)
-    o = oracle_lib.engine(rank=1007, world=2040, tile_size=32)
+    # the WHOLE full-size frame against the oracle, every one of the 2,073,600 pixels bit for bit (the oracle renders a 1080p pass of
+    # this scene in well under a second on the box's 16 host threads)
+    o = oracle_lib.engine()
     sc.apply(o, lut=golden["multiscatter_lut"], tables=host_tables(sc))
     for s in range(passes):
         o.render_pass(sc.options.pass_params(s))
     ob = o.readback()
-    own = ob[..., 3] > 0
-    assert own.sum() == 32 * 32
-    assert a[own].tobytes() == ob[own].tobytes()
+    assert ob.shape == a.shape == (1080, 1920, 4)
+    assert_parity(a, ob, "config 2, whole 1080p frame")
+    ost = o.stats()
+    assert (st.paths, st.rays_closest, st.rays_any, st.shaded_hits) == (ost.paths, ost.rays_closest, ost.rays_any, ost.shaded_hits)
 
 
 # ------------------------------------------------------------- the pass pipeline's scheduling never changes the result
@@ -721,36 +723,82 @@ def test_pipeline_scheduling_is_result_invariant(golden, monkeypatch, tune):
     assert ge.stats().paths == oe.stats().paths
 
 
-def test_full_size_config3_properties(golden):
-    # BASELINE config 3 size (1080p, 1M tris, HDRI + NEE, 8 bounces) — the north-star workload
-    sc = scenes.triangle_soup(1_000_000, width=1920, height=1080, bounces=8, passes=32, env=True)
-    e = core.create_engine()
-    sc.apply(e, lut=golden["multiscatter_lut"], tables=host_tables(sc))
-    info = e.scene_info()
-    assert info.n_triangles == 1_000_000
-    passes = 2
-    for s in range(passes):
-        e.render_pass(sc.options.pass_params(s))
-    a = e.readback()
-    st = e.stats()
+_C3_FULL = {}
+
+
+def _config3_full_size(golden):
+    """BASELINE config 3 at full size, once per session: the scene, the one-context GPU frame of two passes, its counters, and the
+    oracle's WHOLE frame of the same two passes (2,073,600 pixels; ~1 s per pass on 16 host threads)."""
+    if not _C3_FULL:
+        sc = scenes.triangle_soup(1_000_000, width=1920, height=1080, bounces=8, passes=32, env=True)
+        e = core.create_engine()
+        sc.apply(e, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        assert e.scene_info().n_triangles == 1_000_000
+        passes = 2
+        for s in range(passes):
+            e.render_pass(sc.options.pass_params(s))
+        a = e.readback()
+        st = e.stats()
+        e.clear()                                                  # idempotence: no atomics in the data path
+        for s in range(passes):
+            e.render_pass(sc.options.pass_params(s))
+        assert e.readback().tobytes() == a.tobytes()
+        e.close()
+        o = oracle_lib.engine()
+        sc.apply(o, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+        for s in range(passes):
+            o.render_pass(sc.options.pass_params(s))
+        _C3_FULL.update(sc=sc, passes=passes, gpu=a, gpu_stats=st, oracle=o.readback(), oracle_stats=o.stats())
+    return _C3_FULL
+
+
+def test_full_size_config3_whole_frame(golden):
+    # BASELINE config 3 (1080p, 1M tris, HDRI + NEE, 8 bounces) — the north-star workload: every pixel of the frame against the oracle
+    c3 = _config3_full_size(golden)
+    a, ob, st, ost, passes = c3["gpu"], c3["oracle"], c3["gpu_stats"], c3["oracle_stats"], c3["passes"]
+    assert a.shape == ob.shape == (1080, 1920, 4)
     assert (a[..., 3] == passes).all()
     assert np.isfinite(a).all() and (a[..., :3] >= 0).all()
     assert st.paths == 1920 * 1080 * passes
     assert st.rays_closest + st.rays_any <= 1920 * 1080 * passes * 2 * (8 + 1)
-    e.clear()                                                  # idempotence
-    for s in range(passes):
-        e.render_pass(sc.options.pass_params(s))
-    assert e.readback().tobytes() == a.tobytes()
-    # two tiles of the full-size frame (centre and a ragged top-edge tile) against the oracle, bit for bit
-    for tile_id in (1007, 2040 - 30):
-        o = oracle_lib.engine(rank=tile_id, world=2040, tile_size=32)
-        sc.apply(o, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    assert_parity(a, ob, "config 3, whole 1080p frame (2,073,600 pixels)")
+    assert (st.paths, st.rays_closest, st.rays_any, st.shaded_hits) == (ost.paths, ost.rays_closest, ost.rays_any, ost.shaded_hits)
+
+
+def test_full_size_config4_eight_shards_of_config3(golden):
+    # BASELINE config 4: config 3's frame as an 8-way tile shard at FULL size.  One device here, so the eight ranks' contexts render
+    # one after the other (each is exactly what rank r of an 8-GPU job runs: same library, same rank / world description); no
+    # collective is involved in producing the pixels (SURVEY 8e: pixels are copied, never summed).  Acceptance of 8e: the shards are
+    # disjoint, together they are the one-context frame bit for bit, and that frame is the oracle's.
+    from heatray_amd import tiles
+    c3 = _config3_full_size(golden)
+    sc, passes, one = c3["sc"], c3["passes"], c3["gpu"]
+    world = 8
+    owner = tiles.owner_map(1920, 1080, world)
+    total = np.zeros_like(one)
+    covered = np.zeros(one.shape[:2], dtype=np.int32)
+    rays = paths = 0
+    for r in range(world):
+        e = core.create_engine(rank=r, world=world, tile_size=32)
+        sc.apply(e, lut=golden["multiscatter_lut"], tables=host_tables(sc))
         for s in range(passes):
-            o.render_pass(sc.options.pass_params(s))
-        ob = o.readback()
-        own = ob[..., 3] > 0
-        assert own.sum() in (32 * 32, 32 * 24)                 # 1080 = 33 * 32 + 24: the top tile row is cropped
-        assert a[own].tobytes() == ob[own].tobytes()
+            e.render_pass(sc.options.pass_params(s))
+        f = e.readback()
+        st = e.stats()
+        e.close()
+        mine = owner == r
+        assert (f[~mine] == 0).all(), f"rank {r} wrote pixels it does not own"
+        assert (f[mine][:, 3] == passes).all()
+        assert st.paths == int(mine.sum()) * passes
+        total += f                                   # (exact: every pixel has one non-zero contributor)
+        covered += (f[..., 3] > 0).astype(np.int32)
+        rays += st.rays_closest + st.rays_any
+        paths += st.paths
+    assert (covered == 1).all()                      # disjoint and complete
+    assert total.tobytes() == one.tobytes()          # 8 shards == the one-context frame, bit for bit
+    assert_parity(total, c3["oracle"], "config 4: eight shards of config 3 vs the oracle's whole frame")
+    gst = c3["gpu_stats"]
+    assert paths == gst.paths and rays == gst.rays_closest + gst.rays_any
 
 
 def test_full_size_config5_properties(golden):
@@ -781,20 +829,22 @@ def test_full_size_config5_properties(golden):
     for s in range(passes):
         e.render_pass(sc.options.pass_params(s))
     assert e.readback().tobytes() == a.tobytes()
-    # tiles of the full-size frame against the oracle, bit for bit: the centre, and the ragged top row (2160 = 67 * 32 + 16)
-    n_tiles = 120 * 68
-    for tile_id in (34 * 120 + 60, n_tiles - 50):
-        o = oracle_lib.engine(rank=tile_id, world=n_tiles, tile_size=32)
-        sc.apply(o, lut=golden["multiscatter_lut"])
-        for s in range(passes):
-            o.render_pass(sc.options.pass_params(s))
-        ob = o.readback()
-        own = ob[..., 3] > 0
-        assert own.sum() in (32 * 32, 32 * 16)
-        assert a[own].tobytes() == ob[own].tobytes()
-        ost = o.stats()
-        if tile_id == 34 * 120 + 60:                               # the centre tile looks into the soup (the top row sees sky only)
-            assert ost.shaded_hits > 0 and ost.rays_any > 0
+    # one sixteenth of the full-size frame's tiles against the oracle, bit for bit: the interleaved shard 5 of 16 — 510 tiles spread
+    # over the whole frame, the ragged top row (2160 = 67 * 32 + 16) included; ~518,000 pixels
+    from heatray_amd import tiles
+    o = oracle_lib.engine(rank=5, world=16, tile_size=32)
+    sc.apply(o, lut=golden["multiscatter_lut"])
+    for s in range(passes):
+        o.render_pass(sc.options.pass_params(s))
+    ob = o.readback()
+    own = tiles.owner_map(W, H, 16) == 5
+    assert abs(int(own.sum()) - W * H // 16) <= 1024 and (ob[own][:, 3] == passes).all() and (ob[~own] == 0).all()
+    assert any(t // 120 == 67 for t in tiles.owned_tiles(W, H, 5, 16))            # cropped top-row tiles are part of the sample
+    r = rel_l2(a[own], ob[own])
+    assert r <= TOL
+    assert a[own].tobytes() == ob[own].tobytes(), f"config 5: {int((a[own] != ob[own]).any(axis=-1).sum())} of {int(own.sum())} pixels differ (rel-L2 {r:.3e})"
+    ost = o.stats()
+    assert ost.shaded_hits > 0 and ost.rays_any > 0
     e.close()
 
 
@@ -1169,12 +1219,14 @@ def test_strided_and_interleaved_vertex_buffers(golden):
     assert_parity(g.readback(), o.readback(), "interleaved vertex buffers")
 
 
-@pytest.mark.parametrize("tune,passes", [("batch=1,slow=0", 24), ("slow=0", 288)])
+@pytest.mark.parametrize("tune,passes", [("batch=1,slow=0", 24), ("slow=0", 288), ("", 96)])
 def test_progressive_readback_never_drains_and_holds_complete_passes(golden, monkeypatch, tune, passes):
     # hr_readback_progressive: whatever is in the buffer is a prefix of the passes, complete, bit-identical to the oracle's
     # image of that many passes; the pipeline is not completed by it
     # (a frame this small injects 16 passes at a time into two groups unless HR_TUNE says otherwise; slow=0 switches off the completion
-    # for callers slower than 4 ms per pass, which is timing-dependent and has a test of its own)
+    # for callers slower than 4 ms per pass, which is timing-dependent: with it the image must LAG (asserted below); the third case
+    # runs with the default, where a slow test host may trigger completions — every image is still a complete prefix, and the
+    # display call itself says how many passes it shows)
     monkeypatch.setenv("HR_TUNE", tune)
     sc = scenes.multi_material(64, 48, bounces=4, passes=320)
     g, o = core.create_engine(), oracle_lib.engine()
@@ -1197,16 +1249,18 @@ def test_progressive_readback_never_drains_and_holds_complete_passes(golden, mon
             assert (buf == 0).all()
         seen.append(n)
     # the progressive display snapshot shows exactly those passes
-    shown = g.display(ffi.display_params(tonemapping_enabled=True), ffi.HR_DISPLAY_RGBA32F | ffi.HR_DISPLAY_PROGRESSIVE)
-    _, n_now = g.readback_progressive()
+    shown, n_now = g.display(ffi.display_params(tonemapping_enabled=True), ffi.HR_DISPLAY_RGBA32F | ffi.HR_DISPLAY_PROGRESSIVE, with_passes=True)
+    assert 0 <= n_now <= passes
     if n_now:
         o2 = oracle_lib.engine()
         sc.apply(o2, lut=golden["multiscatter_lut"], tables=host_tables(sc))
         for s in range(n_now):
             o2.render_pass(sc.options.pass_params(s))
         assert shown.tobytes() == o2.display(ffi.display_params(tonemapping_enabled=True), ffi.HR_DISPLAY_RGBA32F).tobytes()
-    assert seen == sorted(seen) and seen[-1] < passes      # lags behind: the pipeline was never completed
-    assert max(seen) > 0
+    assert seen == sorted(seen)
+    if "slow=0" in tune:
+        assert seen[-1] < passes                           # lags behind: the pipeline was never completed
+        assert max(seen) > 0
     full = g.readback()                                        # this one completes everything
     assert full.tobytes() == oracle_frames[passes].tobytes()
     _, n = g.readback_progressive()
