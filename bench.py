@@ -51,6 +51,8 @@ WORKLOADS = {
     "c2": dict(desc="synthetic soup 50k tris, 16 PBR materials, 1 directional light, 1920x1080, 8 bounces"),
     "c2p": dict(desc="c2 with 30% single-sided / alpha-masked (pass-through) materials, as glTF assets have them"),
     "c3": dict(desc="synthetic soup 1M tris + 2048x1024 HDRI + NEE, 1920x1080, 8 bounces"),
+    # the regime the metric's name promises — paths that really bounce: the c3 soup and lights inside a closed room with a skylight
+    "c3d": dict(desc="c3's soup (1M tris) + HDRI + sun inside a closed diffuse room [-2,2]^3 with a 1.2x1.2 skylight, camera inside, 1920x1080, 8 bounces"),
     "c5": dict(desc="soup 1M tris, 25% glass, 25% clearcoat, f/2.8 pentagon-bokeh DoF, 3840x2160, 16 bounces"),
     # SURVEY 8d's coherent counterpart of the soup: an indexed, shared-vertex grid mesh
     "terrain": dict(desc="indexed terrain grid mesh 1000x500 quads (1M tris, shared vertices) + 2048x1024 HDRI + NEE, 1920x1080, 8 bounces"),
@@ -66,6 +68,8 @@ def build_scene(name, width, height, passes):
         return scenes.triangle_soup(50_000, width or 1920, height or 1080, bounces=8, passes=passes, env=False, passthrough_fraction=0.3)
     if name == "c3":
         return scenes.triangle_soup(1_000_000, width or 1920, height or 1080, bounces=8, passes=passes, env=True)
+    if name == "c3d":
+        return scenes.triangle_soup(1_000_000, width or 1920, height or 1080, bounces=8, passes=passes, env=True, room=True)
     if name == "terrain":
         return scenes.terrain(1000, 500, width or 1920, height or 1080, bounces=8, passes=passes, env=True)
     if name == "c5":
@@ -766,7 +770,7 @@ def main():
 
         mrays = total_rays / elapsed / 1e6
         out = {
-            "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3", "terrain") else f"Mrays/s ({args.workload})",
+            "metric": "Mrays/s at 1920x1080, 8 bounces" if args.workload in ("c2", "c3", "c3d", "terrain") else f"Mrays/s ({args.workload})",
             "value": mrays, "unit": "Mrays/s", "n_gpus": (dist.get_world_size() if world > 1 else 1), "steps": args.steps, "warmup": args.warmup,
             # untimed device wake-up BEFORE the W warm-up steps (clock ramp / first touch of the pass slots on a freshly started box)
             "wakeup_passes": n_wake, "wakeup_s": wake_s,

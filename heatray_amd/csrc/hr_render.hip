@@ -131,10 +131,32 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
         const size_t framePixels = (size_t)(seg.passbufB - seg.passbuf) >> 2;
         for (int j = 1; j <= 3; ++j) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel + j * framePixels] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    const uint32_t slot = blockReserve(active, seg.qCountIn, scratch);
-    if (active) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
-    const uint32_t n = waveSum(active ? 1u : 0u);
-    if (laneId() == 0 && n) atomicAdd(&stats->paths, (unsigned long long)n);
+    // A camera ray that misses the box of the whole tree is finished here: its traversal would be ONE node step at the root that
+    // pushes nothing, then a hit record, then the miss shader in k_shade_sort — a queue slot (64 B), a record and three kernels' worth
+    // of loads for a ray whose fate this kernel already knows (with the benchmark's camera — SURVEY 8d: distance 3 x the scene's
+    // radius, 50 mm lens — that is three camera rays in four).  Its defaultPrimitive's shader runs right here (the sample was just
+    // set to zero above: same single addition as later), and it still counts as a closest-hit ray: it WAS traced, by the test below.
+    // EXACTLY the traversal's own decision: rootMissed() is the slab test of nodeStep4 on the root's frame box (planes q = 0 and 255),
+    // every child plane lies inside it and fma is monotone in q, so a ray it rejects is rejected by all four children of the root.
+    bool enqueue = active;
+    uint32_t nAcc = 0;
+    if (active && S.nTris > 0 && S.rootLeafCount == 0 && rootMissed(S.nodes, r.o, r.d, S.rayEps, r.maxT)) {
+        enqueue = false;
+        if (r.missKind == MISS_ENV) {
+            ShaderT<0> sh(S, seg.pp, G(seg.passbuf) + (size_t)pixel * 4);
+            sh.performAccumulate(sh.environmentRadiance(r.d, r.weight));
+            nAcc = sh.nAccum;
+        }
+    }
+    const uint32_t slot = blockReserve(enqueue, seg.qCountIn, scratch);
+    if (enqueue) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
+    const uint32_t n = waveSum(active ? 1u : 0u), nCulled = waveSum((active && !enqueue) ? 1u : 0u);
+    nAcc = waveSum(nAcc);
+    if (laneId() == 0) {
+        if (n) atomicAdd(&stats->paths, (unsigned long long)n);
+        if (nCulled) atomicAdd(&stats->raysClosest, (unsigned long long)nCulled);
+        if (nAcc) atomicAdd(&stats->accumulates, (unsigned long long)nAcc);
+    }
 }
 
 // one workgroup per injected pass: its Counters block (a few hundred words) back to zero

@@ -140,12 +140,39 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
 // Per-ray constants of the slab test: 1 / d and the ray origin over d
 HRD RayK rayFrame(v3 o, float idx, float idy, float idz) { return RayK{idx, idy, idz, o.x * idx, o.y * idy, o.z * idz}; }
 
+// Does the ray miss the frame box of the root node — [origin, origin + 255 * scale] per axis, which contains every child's quantised box?
+// Same arithmetic as nodeStep4 with the plane bytes 0 and 255: t = q * (scale / d) + (origin / d - o / d).  For any child plane
+// 0 <= q <= 255 the entry distance is >= this box's and the exit distance <= this box's (fma is monotone in q for a fixed slope), so
+// `true` here implies that nodeStep4 at the root finds no child: the ray's closest hit is a miss.  (NaNs compare false: not culled.)
+HRD bool rootMissed(const Node4 *__restrict__ nodes, v3 o, v3 d, float tmin, float tlim);
+
 // Reciprocal for the slab test only (never for the hit): no infinities / NaNs enter the box test.
 HRD float safeInv(float d)
 {
     const float lim = 1e-20f;
     if (abs_(d) < lim) d = (d < 0.0f) ? -lim : lim;
     return 1.0f / d;
+}
+
+HRD bool rootMissed(const Node4 *__restrict__ nodes, v3 o, v3 d, float tmin, float tlim)
+{
+    const float4 a = nodes[0].a;
+    const uint32_t meta = __float_as_uint(a.w);
+    const float idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
+    const RayK rk = rayFrame(o, idx, idy, idz);
+    const float bx = __uint_as_float((meta & 0xFFu) << 23) * rk.idx;
+    const float by = __uint_as_float(((meta >> 8) & 0xFFu) << 23) * rk.idy;
+    const float bz = __uint_as_float(((meta >> 16) & 0xFFu) << 23) * rk.idz;
+    const float ax = __builtin_fmaf(a.x, rk.idx, -rk.oix), ay = __builtin_fmaf(a.y, rk.idy, -rk.oiy), az = __builtin_fmaf(a.z, rk.idz, -rk.oiz);
+    const float nX = rk.idx < 0.0f ? 255.0f : 0.0f, fX = rk.idx < 0.0f ? 0.0f : 255.0f;
+    const float nY = rk.idy < 0.0f ? 255.0f : 0.0f, fY = rk.idy < 0.0f ? 0.0f : 255.0f;
+    const float nZ = rk.idz < 0.0f ? 255.0f : 0.0f, fZ = rk.idz < 0.0f ? 0.0f : 255.0f;
+    const float tnx = __builtin_fmaf(nX, bx, ax), tfx = __builtin_fmaf(fX, bx, ax);
+    const float tny = __builtin_fmaf(nY, by, ay), tfy = __builtin_fmaf(fY, by, ay);
+    const float tnz = __builtin_fmaf(nZ, bz, az), tfz = __builtin_fmaf(fZ, bz, az);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
+    const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
+    return tn > tf;
 }
 
 // physicallyBased.rlsl:57-91 seen by an occlusion ray on a non-occluder (alpha-masked) primitive

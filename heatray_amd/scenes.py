@@ -229,10 +229,10 @@ def synthetic_hdri(width=2048, height=1024):
     return np.minimum(img, 50.0).astype(F)
 
 
-def _camera_for(sc, lo, hi, phi=0.6, theta=0.3):
+def _camera_for(sc, lo, hi, phi=0.6, theta=0.3, dist=None):
     center = (lo + hi) * 0.5
     radius = float(np.linalg.norm(hi - lo)) * 0.5
-    dist = 3.0 * radius  # OrbitCamera distance 3 x radius
+    dist = 3.0 * radius if dist is None else dist  # OrbitCamera distance 3 x radius
     o = sc.options
     o.view_matrix = host.orbit_view_matrix(dist, phi, theta, target=center)
     o.focus_distance = dist
@@ -241,10 +241,15 @@ def _camera_for(sc, lo, hi, phi=0.6, theta=0.3):
 
 
 def triangle_soup(n_tris, width=1920, height=1080, bounces=8, passes=32, env=False, seed=SEED, glass_fraction=0.0,
-                  clearcoat_fraction=0.0, n_materials=16, passthrough_fraction=0.0):
+                  clearcoat_fraction=0.0, n_materials=16, passthrough_fraction=0.0, room=False):
     """S-50k / S-1M: N random triangles, centroid ~U([-1,1]^3), two edge vectors ~U([-l,l]^3) with
     l = 0.5 N^(-1/3), de-indexed with flat normals, 16 materials, one directional light
-    (theta 60 deg, phi 30 deg, illuminance 683 pi) and optionally the synthetic HDRI."""
+    (theta 60 deg, phi 30 deg, illuminance 683 pi) and optionally the synthetic HDRI.
+
+    room=True (workload c3d): the same soup and lights inside a closed, emissive-free room [-2,2]^3 of one more diffuse material,
+    with the camera inside it and a 1.2 x 1.2 skylight in the ceiling as the only way in for the sun and the sky: every camera ray
+    hits something and nearly every bounce does too, so paths run until Russian roulette ends them — the regime of
+    physicallyBased.rlsl:277-330 the open soup (77 % of the rays leave the scene) hardly exercises."""
     rng = SplitMix64(seed)
     sc = Scene(f"soup{n_tris}", width=width, height=height)
     l = 0.5 * n_tris ** (-1.0 / 3.0)
@@ -271,13 +276,27 @@ def triangle_soup(n_tris, width=1920, height=1080, bounces=8, passes=32, env=Fal
         uv = np.tile(np.array([[0, 0], [1, 0], [0, 1]], dtype=F), (sel.size, 1)) if masked else None
         # alpha-masked primitives are not occluders: shadow rays run their shader (Mesh.cpp:95-100)
         sc.meshes.append(MeshData(p, n, np.arange(p.shape[0], dtype=np.uint32), uvs=uv, material_id=m, is_occluder=not masked))
+    if room:
+        h, k = 2.0, 0.6  # half size of the room, half size of the skylight
+        walls = [_quad((-h, -h, h), (h, -h, h), (h, -h, -h), (-h, -h, -h)),       # floor (normal +y)
+                 _quad((-h, -h, -h), (h, -h, -h), (h, h, -h), (-h, h, -h)),       # back (+z)
+                 _quad((h, -h, h), (-h, -h, h), (-h, h, h), (h, h, h)),           # front (-z)
+                 _quad((-h, -h, h), (-h, -h, -h), (-h, h, -h), (-h, h, h)),       # left (+x)
+                 _quad((h, -h, -h), (h, -h, h), (h, h, h), (h, h, -h)),           # right (-x)
+                 # ceiling (normal -y): four strips around the skylight
+                 _quad((-h, h, -h), (h, h, -h), (h, h, -k), (-h, h, -k)), _quad((-h, h, k), (h, h, k), (h, h, h), (-h, h, h)),
+                 _quad((-h, h, -k), (-k, h, -k), (-k, h, k), (-h, h, k)), _quad((k, h, -k), (h, h, -k), (h, h, k), (k, h, k))]
+        p, n, i = _merge(walls)
+        sc.materials[n_materials] = host.bake_pbr(base_color=(0.7, 0.7, 0.7), roughness=1.0, metallic=0.0)
+        sc.meshes.append(MeshData(p, n, i, material_id=n_materials))
     sc.lights.add_directional(color=(1, 1, 1), illuminance=683.0 * math.pi, phi=math.radians(30.0), theta=math.radians(60.0))
     if env:
         sc.env_pixels = synthetic_hdri()
     o = sc.options
     o.max_ray_depth, o.max_render_passes = bounces, passes
     o.fstop = host.FSTOP_DISABLED
-    _camera_for(sc, pos.reshape(-1, 3).min(0), pos.reshape(-1, 3).max(0))
+    # (room: the camera stands inside, 2.2 from the centre on the usual orbit: at (1.19, 0.65, 1.73), looking slightly down)
+    _camera_for(sc, pos.reshape(-1, 3).min(0), pos.reshape(-1, 3).max(0), dist=2.2 if room else None)
     return sc
 
 

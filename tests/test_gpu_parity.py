@@ -308,6 +308,18 @@ def test_soup_with_environment(golden):
     assert ge.stats().rays_any == oe.stats().rays_any
 
 
+def test_closed_room_paths_bounce(golden):
+    # workload c3d at a small size: the soup inside a closed room with a skylight, camera inside — nearly every ray hits, paths are
+    # five closest-hit segments long on average (the open soup: 1.4), Russian roulette (physicallyBased.rlsl:279-288) ends them
+    sc = scenes.triangle_soup(20000, width=160, height=96, bounces=8, passes=32, env=True, room=True)
+    g, o, ge, oe = render_both(sc, 6, lut=golden["multiscatter_lut"])
+    assert_parity(g, o, "closed room")
+    st, ost = ge.stats(), oe.stats()
+    assert (st.paths, st.rays_closest, st.rays_any, st.shaded_hits) == (ost.paths, ost.rays_closest, ost.rays_any, ost.shaded_hits)
+    assert st.rays_closest >= 4 * st.paths and st.shaded_hits >= 0.8 * st.rays_closest
+    assert g[..., :3].max() > 0
+
+
 def test_glass_clearcoat_dof_config5_small(golden):
     # BASELINE config 5 at test size: 25 % glass, 25 % clearcoat, f/2.8 depth of field, 16 bounces
     sc = scenes.triangle_soup(4000, width=96, height=54, bounces=16, passes=8, env=True, glass_fraction=0.25,
