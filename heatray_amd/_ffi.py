@@ -118,7 +118,7 @@ class PassStats(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4)]
+    _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4), ("trace_clock_ms", C.c_float), ("trace_clock_launches", C.c_uint32)]
 
 
 class DisplayParams(C.Structure):
@@ -368,10 +368,13 @@ class Engine:
         return s
 
     def kernel_times(self):
-        """{kernel: (total_ms, launches)} since the last clear (HR_CTX_TIME_KERNELS contexts only)."""
+        """{kernel: (total_ms, launches)} since the last clear: HIP-event times (zero unless the context was created with
+        HR_CTX_TIME_KERNELS) and, under "trace_clock", k_trace's time by the device clock (always)."""
         t = KernelTimes()
         self._call("get_kernel_times", C.byref(t))
-        return {n: (t.ms[i], t.launches[i]) for i, n in enumerate(HR_KERNEL_NAMES)}
+        d = {n: (t.ms[i], t.launches[i]) for i, n in enumerate(HR_KERNEL_NAMES)}
+        d["trace_clock"] = (t.trace_clock_ms, t.trace_clock_launches)
+        return d
 
     def synchronize(self):
         self._call("synchronize")

@@ -1864,6 +1864,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     if (G.tableUsed[ring]) HIP_TRY(c, hipEventSynchronize(G.tableCopied[ring])); // staging entry free again (4 steps old)
     StepTable &tbl = G.hTables[ring];
     std::memset(tbl.heads, 0, sizeof(tbl.heads));
+    std::memset(tbl.clkStart, 0xFF, sizeof(tbl.clkStart)), std::memset(tbl.clkEnd, 0, sizeof(tbl.clkEnd));
     tbl.headsLog2 = (uint32_t)(c->tuneHeads < 0 ? 0 : (c->tuneHeads > 6 ? 6 : c->tuneHeads));
     tbl.nSeg = n;
     tbl.refillLanes = c->tuneRefill, tbl.triPhaseLanes = c->tuneTri;
@@ -2002,7 +2003,14 @@ static int drainPipeline(hr_ctx *c)
     while (!c->pendingInject.empty()) {
         const int stages = stagesOf(c, c->pendingInject.front());
         const int batch = batchFor(c, stages);
-        const int n = (int)c->pendingInject.size() < batch ? (int)c->pendingInject.size() : batch;
+        int n = (int)c->pendingInject.size() < batch ? (int)c->pendingInject.size() : batch;
+        // the last, partly filled batch of a run on several pipeline groups is dealt out over the groups (each group's dependent
+        // chain of stages then carries a share of it, and the chains overlap on the device) instead of going to one of them whole
+        if (c->nGroups > 1 && (int)c->pendingInject.size() <= batch) {
+            const int idleGroups = c->nGroups - (c->nextGroup % c->nGroups);
+            const int share = ((int)c->pendingInject.size() + idleGroups - 1) / (idleGroups > 0 ? idleGroups : 1);
+            n = share < 1 ? 1 : share;
+        }
         int perGroup = batch * stages;
         int rc = injectBatch(c, n, perGroup);
         if (rc) return rc;
@@ -2134,13 +2142,19 @@ int hr_get_kernel_times(hr_ctx *c, hr_kernel_times *out)
 {
     ENTER(c);
     if (!out) FAIL(c, HR_ERR_INVALID, "null output");
-    if (!c->timeKernels) FAIL(c, HR_ERR_INVALID, "context was not created with HR_CTX_TIME_KERNELS");
     {
         int rc = drainPipeline(c);
         if (rc) return rc;
     }
     c->drainTimes();
     for (int k = 0; k < HR_KERNEL_COUNT; ++k) out->ms[k] = c->kernelMs[k], out->launches[k] = c->kernelLaunches[k];
+    std::vector<Stats> parts(kStatSlots);
+    HIP_TRY(c, hipMemcpyAsync(parts.data(), c->dStats, sizeof(Stats) * kStatSlots, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long ticks = 0, launches = 0;
+    for (const Stats &p : parts) ticks += p.traceTicks, launches += p.traceLaunches;
+    out->trace_clock_ms = (float)((double)ticks * 1e-5); // 100 MHz: 10 ns per tick
+    out->trace_clock_launches = (uint32_t)launches;
     return HR_OK;
 }
 

@@ -20,6 +20,7 @@ struct HitRec; // hr_trace.h
 static const int kStatSlots = 4096;
 struct Stats {
     unsigned long long paths, raysClosest, raysAny, shadedHits, accumulates, nodeVisits, triTests, nodeVisitsAny, triTestsAny;
+    unsigned long long traceTicks, traceLaunches; // k_trace by the 100 MHz device clock: first workgroup's start to last workgroup's end, summed over launches
 };
 
 struct LaunchCfg {
@@ -59,6 +60,7 @@ struct SegDev {
 #define HR_MAX_SEGS 320
 #endif
 static const int kMaxSegs = HR_MAX_SEGS;
+static const int kClkSlots = 16;
 static const int kTraceHeadsMax = 64; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
 struct StepTable {
     // read-mostly header: every wave of every kernel of the step reads it once
@@ -79,6 +81,11 @@ struct StepTable {
     // (blockIdx mod the number of ranges) — workgroups are dealt to the 8 XCDs round robin, so with 32 ranges an XCD starts on four of
     // them — and moves on to the next range when its own is used up.  Zeroed on the host with every table upload.
     alignas(128) uint32_t heads[kTraceHeadsMax * 32];
+    // k_trace times itself with the device's constant 100 MHz clock: every workgroup folds its start and end into one of kClkSlots
+    // (min, max) pairs, and the step's next kernel (k_shade_sort) adds (max end - min start) to the Stats counters.  No event packets
+    // on the stream (a record costs a dependent chain of small launches 4-8 us each).  Initialised with every table upload.
+    alignas(128) unsigned long long clkStart[kClkSlots];
+    unsigned long long clkEnd[kClkSlots];
     alignas(128) SegDev seg[kMaxSegs];
 };
 static_assert(offsetof(StepTable, heads) % 128 == 0 && offsetof(StepTable, seg) % 128 == 0, "k_trace's work cursors own their cache lines");

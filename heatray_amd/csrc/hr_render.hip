@@ -309,6 +309,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     __shared__ uint32_t mDonor[kTraceWaves][64];         // k-th donating lane of this round
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
+    const unsigned long long clk0 = wall_clock64();
     buildSegStarts(tbl, segStart, false);
     const int nSeg2 = 2 * tbl->nSeg;
     const uint32_t total = segStart[nSeg2];
@@ -739,6 +740,14 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
             atomicAdd(&stats->triTestsAny, (unsigned long long)ntA);
         }
     }
+    // ---- the launch times itself (StepTable::clkStart): every workgroup folds its start and end into one of kClkSlots (min, max)
+    // pairs — 80 atomics per address, spread over the launch; ONE counter of finished workgroups would put 1280 same-address
+    // atomics (~12 ns each) into the tail of every launch.  The kernel behind this one (k_shade_sort) adds max - min to the counters.
+    if (threadIdx.x == 0) {
+        const uint32_t cs = blockIdx.x & (kClkSlots - 1);
+        __hip_atomic_fetch_min(&tbl->clkStart[cs], clk0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(&tbl->clkEnd[cs], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         unsigned long long nc = 0, na = 0;
         for (int k = 0; k < tbl->nSeg; ++k) {
@@ -818,6 +827,15 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
     const int nSeg = tbl->nSeg;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { // duration of the k_trace launch of this step, by its own clock readings (hr_kernels.h: clkStart)
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (int k = 0; k < kClkSlots; ++k) {
+            const unsigned long long a = tbl->clkStart[k], b = tbl->clkEnd[k];
+            lo = a < lo ? a : lo, hi = b > hi ? b : hi;
+        }
+        if (hi > lo) atomicAdd(&stats->traceTicks, hi - lo);
+        atomicAdd(&stats->traceLaunches, 1ull);
+    }
     buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? *tbl->seg[k].qCountIn : 0u; });
     const uint32_t total = start[nSeg];
     const bool glassToo = tbl->hasGlass != 0;

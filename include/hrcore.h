@@ -378,9 +378,11 @@ typedef struct hr_pass_stats {
     uint64_t tri_tests_any;
 } hr_pass_stats;
 
-/* Per-kernel device time, summed over every launch since the last hr_clear
- * (HR_CTX_TIME_KERNELS only).  OpenRL's counterpart: RL_RENDER_FRAME_TIME /
- * RL_PROFILE (rl.h:346-355), which Heatray never queries. */
+/* Per-kernel device time, summed over every launch since the last hr_clear: ms[] / launches[] from HIP event pairs
+ * around the kernels (HR_CTX_TIME_KERNELS contexts only, else zero: every record is a packet of a few microseconds on
+ * the stream, which a small tile shard's dependent launches feel), trace_clock_* from the constant 100 MHz device clock
+ * read inside k_trace itself (first workgroup's start to last workgroup's end; always on, nothing on the stream).
+ * OpenRL's counterpart: RL_RENDER_FRAME_TIME / RL_PROFILE (rl.h:346-355), which Heatray never queries. */
 #define HR_KERNEL_RAYGEN 0
 #define HR_KERNEL_TRACE 1   /* closest-hit + occlusion traversal (one kernel) */
 #define HR_KERNEL_SHADE 2
@@ -389,6 +391,8 @@ typedef struct hr_pass_stats {
 typedef struct hr_kernel_times {
     float ms[HR_KERNEL_COUNT];
     uint32_t launches[HR_KERNEL_COUNT];
+    float trace_clock_ms;          /* k_trace, device clock */
+    uint32_t trace_clock_launches;
 } hr_kernel_times;
 
 /* Interactive 3x3 mode (perspective.rlsl:42-57): which pixel of a block is sampled in a sub-pass is looked up in a small table,
@@ -419,7 +423,7 @@ int hr_frame_pass_batch(hr_ctx *ctx, int32_t max_ray_depth, int32_t *batch);
 int hr_flush(hr_ctx *ctx);
 /* synchronises the stream, then copies the counters */
 int hr_get_stats(hr_ctx *ctx, hr_pass_stats *out);
-/* synchronises the stream, then sums the recorded event pairs */
+/* completes the enqueued passes, synchronises, then sums the recorded event pairs and the device-clock totals */
 int hr_get_kernel_times(hr_ctx *ctx, hr_kernel_times *out);
 /* replaces PixelPackBuffer::setPixelData + mapPixelData (PixelPackBuffer.h:39-60):
  * synchronous copy to a pinned host buffer owned by the ctx; the pointer stays
