@@ -67,7 +67,7 @@ class SceneInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint64), ("n_nodes", C.c_uint64), ("aabb_min", C.c_float * 3),
                 ("aabb_max", C.c_float * 3), ("ray_epsilon", C.c_float), ("build_ms", C.c_float),
                 ("bvh_levels", C.c_uint32), ("refitted", C.c_uint32),
-                ("box_area_ratio", C.c_float), ("reserved", C.c_uint32)]
+                ("box_area_ratio", C.c_float), ("builder", C.c_uint32), ("cost_radix", C.c_float), ("cost_ploc", C.c_float)]
 
 
 class TextureDesc(C.Structure):

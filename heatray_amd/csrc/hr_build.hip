@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ key
 // One bottom-up round: a node whose children were finished in an EARLIER launch gets its box.
 // stamp[i] = round in which node i was finished (0 = not yet); visibility comes from the kernel boundary.
 HRD float boxArea(const Box6 &b);
+HRD float4 collapseCost(int left, int right, float area, const float4 *__restrict__ cost);
 // ... and the costs of the collapse to a 4-wide tree (k_collapse4): cost[i] = (C1, C2, C3, C4), Ck = the least sum of the surface areas of
 // the 4-wide nodes that can represent the subtree of binary node i when it may occupy up to k child slots of its 4-wide parent
 // (k = 1: it is a child itself, a node of its own; k >= 2: it may be opened and its two children share the slots).  A triangle costs
@@ -382,16 +383,7 @@ __global__ __launch_bounds__(256) void k_refit_round(const KNode *__restrict__ n
         u.hi[c] = fmax_(a.hi[c], b.hi[c]);
     }
     nodeBox[i] = u;
-    if (cost) {
-        const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const float4 cl = k.left < 0 ? z : cost[k.left], cr = k.right < 0 ? z : cost[k.right];
-        const float h2 = cl.x + cr.x;
-        const float h3 = fmin_(cl.x + cr.y, cl.y + cr.x);
-        const float h4 = fmin_(cl.x + cr.z, fmin_(cl.y + cr.y, cl.z + cr.x));
-        const float c1 = boxArea(u) + h4;
-        const float c2 = fmin_(c1, h2), c3 = fmin_(c2, h3), c4 = fmin_(c3, h4);
-        cost[i] = make_float4(c1, c2, c3, c4);
-    }
+    if (cost) cost[i] = collapseCost(k.left, k.right, boxArea(u), cost);
     stamp[i] = round;
 }
 
@@ -457,6 +449,19 @@ HRD float boxArea(const Box6 &b)
 {
     const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
     return dx * dy + dy * dz + dz * dx;
+}
+
+// (C1, C2, C3, C4) of a binary node from its children's (see k_refit_round); a triangle child (ref < 0) costs nothing
+HRD float4 collapseCost(int left, int right, float area, const float4 *__restrict__ cost)
+{
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 cl = left < 0 ? z : cost[left], cr = right < 0 ? z : cost[right];
+    const float h2 = cl.x + cr.x;
+    const float h3 = fmin_(cl.x + cr.y, cl.y + cr.x);
+    const float h4 = fmin_(cl.x + cr.z, fmin_(cl.y + cr.y, cl.z + cr.x));
+    const float c1 = area + h4;
+    const float c2 = fmin_(c1, h2), c3 = fmin_(c2, h3), c4 = fmin_(c3, h4);
+    return make_float4(c1, c2, c3, c4);
 }
 
 // biased exponent e (1..254) of the smallest power of two s = 2^(e-127) with ext / s <= 255
@@ -693,11 +698,217 @@ void launchTriAreaSum(hipStream_t st, const Tri *leafTris, uint32_t nSlots, Scen
     if (nSlots) hipLaunchKernelGGL(k_tri_area_sum, dim3((nSlots + 255) / 256), dim3(256), 0, st, leafTris, nSlots, consts);
 }
 
+// ------------------------------------------------------------------------------------------- PLOC
+// Parallel locally-ordered clustering (Meister & Bittner 2018) over the Morton-ordered triangle boxes: in every iteration each cluster
+// looks for its nearest neighbour (smallest surface area of the merged box) among the r clusters before and behind it in the array,
+// mutual nearest neighbours merge, the array is compacted.  The binary tree that results is what the radix tree of k_karras is for the
+// LBVH: input of the same DP collapse to 4-wide nodes.  On meshes it is the better tree (terrain: -17 % summed node area, i.e. node
+// visits per ray; tools/tree_proto.py, profiles/r4_tree_proto.txt); on the benchmark's uniform triangle fog spatial-median splits are
+// within 7 % of a full-sweep SAH build and PLOC is 2-6 % WORSE than the LBVH — so buildLBVH builds both and keeps the cheaper one.
+#ifndef HR_PLOC_RADIUS_MAX
+#define HR_PLOC_RADIUS_MAX 32
+#endif
+HRD float unionArea(const Box6 &a, const Box6 &b)
+{
+    const float dx = fmax_(a.hi[0], b.hi[0]) - fmin_(a.lo[0], b.lo[0]), dy = fmax_(a.hi[1], b.hi[1]) - fmin_(a.lo[1], b.lo[1]),
+                dz = fmax_(a.hi[2], b.hi[2]) - fmin_(a.lo[2], b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// state of the clustering on the device: [0] clusters in the array, [1] binary nodes made so far
+__global__ __launch_bounds__(256) void k_ploc_nn(const Box6 *__restrict__ box, const uint32_t *__restrict__ state, int r, uint32_t *__restrict__ nn)
+{
+    __shared__ Box6 tile[256 + 2 * HR_PLOC_RADIUS_MAX];
+    const int m = (int)state[0];
+    const int base = (int)blockIdx.x * 256;
+    if (base >= m) return;
+    for (int t = threadIdx.x; t < 256 + 2 * r; t += 256) {
+        const int g = base - r + t;
+        if (g >= 0 && g < m) tile[t] = box[g];
+    }
+    __syncthreads();
+    const int i = base + (int)threadIdx.x;
+    if (i >= m) return;
+    const Box6 me = tile[threadIdx.x + r];
+    // the candidate with the smallest key (area, |i - j|, parity of min(i, j), min(i, j)) — a key that is the same seen from both ends
+    // of a pair, so the pair with the globally smallest key is always mutual and every iteration merges at least one pair; among equal
+    // areas (coincident or regularly spaced triangles) the nearest index wins and then the pair (2k, 2k + 1), so that a run of equal
+    // boxes pairs up completely in one iteration instead of one pair at a time
+    float best = __builtin_inff();
+    int bestJ = -1;
+    for (int off = -r; off <= r; ++off) {
+        const int j = i + off;
+        if (off == 0 || j < 0 || j >= m) continue;
+        const float a = unionArea(me, tile[(int)threadIdx.x + r + off]);
+        bool better = bestJ < 0 || a < best;
+        if (!better && a == best) {
+            const int d1 = off < 0 ? -off : off, d0 = bestJ > i ? bestJ - i : i - bestJ;
+            const int lo1 = i < j ? i : j, lo0 = i < bestJ ? i : bestJ;
+            better = d1 < d0 || (d1 == d0 && ((lo1 & 1) < (lo0 & 1) || ((lo1 & 1) == (lo0 & 1) && lo1 < lo0)));
+        }
+        if (better) best = a, bestJ = j;
+    }
+    nn[i] = (uint32_t)bestJ;
+}
+
+// PHASE 0: per workgroup, how many clusters stay in the array and how many pairs merge (packed: stay | merge << 32).
+// PHASE 1: with those counts turned into exclusive prefixes, write the next array: a merging pair becomes a new binary node (its box,
+// its collapse costs: both children exist since an earlier launch) at the place of its lower member; the higher member disappears.
+template <int PHASE>
+__global__ __launch_bounds__(256) void k_ploc_merge(const uint32_t *__restrict__ state, const uint32_t *__restrict__ nn, const int *__restrict__ refIn,
+                                                    const Box6 *__restrict__ boxIn, unsigned long long *__restrict__ blockSums, int *__restrict__ refOut,
+                                                    Box6 *__restrict__ boxOut, KNode *__restrict__ knodes, Box6 *__restrict__ nodeBox, float4 *__restrict__ cost)
+{
+    __shared__ uint32_t wk[4], wm[4];
+    const uint32_t m = state[0];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= m) return; // (uniform)
+    bool keep = false, makes = false;
+    uint32_t j = 0;
+    if (i < m) {
+        j = nn[i];
+        const bool mutual = j < m && nn[j] == i;
+        keep = !(mutual && j < i);
+        makes = mutual && i < j;
+    }
+    const unsigned long long kb = __ballot(keep), mb = __ballot(makes);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (lane == 0) wk[wave] = (uint32_t)__popcll(kb), wm[wave] = (uint32_t)__popcll(mb);
+    __syncthreads();
+    if (PHASE == 0) {
+        if (threadIdx.x == 0) blockSums[blockIdx.x] = (unsigned long long)(wk[0] + wk[1] + wk[2] + wk[3]) | ((unsigned long long)(wm[0] + wm[1] + wm[2] + wm[3]) << 32);
+        return;
+    }
+    uint32_t kBefore = 0, mBefore = 0;
+    for (uint32_t w = 0; w < wave; ++w) kBefore += wk[w], mBefore += wm[w];
+    const unsigned long long pre = blockSums[blockIdx.x], lt = (1ull << lane) - 1ull;
+    const uint32_t pos = (uint32_t)pre + kBefore + (uint32_t)__popcll(kb & lt);
+    if (makes) {
+        const uint32_t id = state[1] + (uint32_t)(pre >> 32) + mBefore + (uint32_t)__popcll(mb & lt);
+        const Box6 a = boxIn[i], b = boxIn[j];
+        Box6 u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) u.lo[c] = fmin_(a.lo[c], b.lo[c]), u.hi[c] = fmax_(a.hi[c], b.hi[c]);
+        KNode k;
+        k.left = refIn[i], k.right = refIn[j], k.first = 0, k.last = 0;
+        knodes[id] = k;
+        nodeBox[id] = u;
+        cost[id] = collapseCost(k.left, k.right, boxArea(u), cost);
+        refOut[pos] = (int)id;
+        boxOut[pos] = u;
+    } else if (keep) {
+        refOut[pos] = refIn[i];
+        boxOut[pos] = boxIn[i];
+    }
+}
+
+// exclusive scan of n packed (low | high << 32) counters by ONE workgroup; then the iteration's totals update the state
+__global__ __launch_bounds__(1024) void k_ploc_scan(unsigned long long *__restrict__ data, uint32_t *__restrict__ state)
+{
+    __shared__ unsigned long long waveSums[16];
+    __shared__ unsigned long long carry;
+    const uint32_t n = (state[0] + 255u) / 256u;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const unsigned long long v = (i < n) ? data[i] : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(inc, o);
+            if ((int)lane >= o) inc += t;
+        }
+        if (lane == 63) waveSums[wave] = inc;
+        __syncthreads();
+        unsigned long long wavePrefix = 0;
+        for (uint32_t w = 0; w < wave; ++w) wavePrefix += waveSums[w];
+        const unsigned long long c = carry;
+        if (i < n) data[i] = c + wavePrefix + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + wavePrefix + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        state[2] = (uint32_t)carry;         // clusters of the next array
+        state[3] = (uint32_t)(carry >> 32); // nodes made by this iteration
+    }
+}
+__global__ void k_ploc_advance(uint32_t *state)
+{
+    state[0] = state[2];
+    state[1] += state[3];
+}
+__global__ __launch_bounds__(256) void k_ploc_init(const Box6 *__restrict__ leafBox, uint32_t n, int *__restrict__ ref, Box6 *__restrict__ box)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ref[i] = ~(int)i;
+    box[i] = leafBox[i];
+}
+
+// Binary tree over the sorted triangles by PLOC: knodes / nodeBox / cost have n - 1 entries; *rootOut is the root's index (n - 2).
+// Returns 0, or non-zero when it did not finish (the caller then keeps the radix tree).
+static int buildPLOC(hipStream_t st, const Box6 *leafBox, uint32_t n, int radius, KNode *knodes, Box6 *nodeBox, float4 *cost, int *rootOut)
+{
+    int *ref[2] = {nullptr, nullptr};
+    Box6 *box[2] = {nullptr, nullptr};
+    uint32_t *nn = nullptr, *state = nullptr;
+    unsigned long long *sums = nullptr;
+    const uint32_t nb0 = (n + 255) / 256;
+    bool ok = hipMalloc(&ref[0], 4ull * n) == hipSuccess && hipMalloc(&ref[1], 4ull * n) == hipSuccess && hipMalloc(&box[0], sizeof(Box6) * (size_t)n) == hipSuccess &&
+              hipMalloc(&box[1], sizeof(Box6) * (size_t)n) == hipSuccess && hipMalloc(&nn, 4ull * n) == hipSuccess && hipMalloc(&state, 16) == hipSuccess &&
+              hipMalloc(&sums, 8ull * nb0) == hipSuccess;
+    const uint32_t init[4] = {n, 0u, 0u, 0u};
+    ok = ok && hipMemcpyAsync(state, init, 16, hipMemcpyHostToDevice, st) == hipSuccess;
+    int rc = ok ? 0 : 1;
+    if (ok) {
+        hipLaunchKernelGGL(k_ploc_init, dim3(nb0), dim3(256), 0, st, leafBox, n, ref[0], box[0]);
+        const int r = radius < 1 ? 1 : (radius > HR_PLOC_RADIUS_MAX ? HR_PLOC_RADIUS_MAX : radius);
+        uint32_t m = n;
+        int cur = 0;
+        // every iteration merges at least one pair (k_ploc_nn), typically a third of the clusters: ~45 iterations for a million
+        // triangles.  The host reads the cluster count back after each (a 4-byte copy: the launches are sized by it).
+        for (uint32_t it = 0; m > 1; ++it) {
+            if (it >= 4096u) { // (a pathological input that merges a pair at a time: not worth it, the radix tree is kept)
+                rc = 7;
+                break;
+            }
+            const uint32_t nb = (m + 255) / 256;
+            hipLaunchKernelGGL(k_ploc_nn, dim3(nb), dim3(256), 0, st, box[cur], state, r, nn);
+            hipLaunchKernelGGL((k_ploc_merge<0>), dim3(nb), dim3(256), 0, st, state, nn, ref[cur], box[cur], sums, ref[cur ^ 1], box[cur ^ 1], knodes, nodeBox, cost);
+            hipLaunchKernelGGL(k_ploc_scan, dim3(1), dim3(1024), 0, st, sums, state);
+            hipLaunchKernelGGL((k_ploc_merge<1>), dim3(nb), dim3(256), 0, st, state, nn, ref[cur], box[cur], sums, ref[cur ^ 1], box[cur ^ 1], knodes, nodeBox, cost);
+            hipLaunchKernelGGL(k_ploc_advance, dim3(1), dim3(1), 0, st, state);
+            uint32_t mNew = 0;
+            if (hipMemcpyAsync(&mNew, state, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                rc = 1;
+                break;
+            }
+            if (mNew >= m || mNew == 0) { // (cannot happen: see k_ploc_nn)
+                rc = 7;
+                break;
+            }
+            m = mNew;
+            cur ^= 1;
+        }
+        if (rc == 0 && m != 1) rc = 7;
+        uint32_t made = 0;
+        if (rc == 0 && (hipMemcpyAsync(&made, state + 1, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = 1;
+        if (rc == 0 && made != n - 1) rc = 7;
+        *rootOut = (int)n - 2;
+    }
+    hipFree(ref[0]), hipFree(ref[1]), hipFree(box[0]), hipFree(box[1]), hipFree(nn), hipFree(state), hipFree(sums);
+    return rc;
+}
+
 int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, const SceneConsts *dConsts,
-              BuildResult *out)
+              BuildResult *out, const BuildOptions &opt)
 {
     out->nodes = nullptr, out->tris = nullptr, out->nodeBox = nullptr, out->slotOfPrim = nullptr;
     out->nNodes = 0, out->rootLeafCount = 0, out->levels = 0, out->triSlots = 0;
+    out->builder = 0, out->costRadix = out->costPloc = 0.0f;
     for (uint32_t &v : out->levelStart) v = 0;
     if (n == 0) return 0;
     if (n >= (1u << 28)) return 2;
@@ -779,34 +990,81 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
             if (rootStamp == 0) rc = 3;
         }
 #endif
+        // ---- the second candidate: the PLOC tree over the same sorted triangles; the one whose collapse costs less (summed surface area
+        // of the 4-wide nodes = expected node visits of a random ray) is kept
+        KNode *pKnodes = nullptr;
+        Box6 *pBox = nullptr;
+        float4 *pCost = nullptr;
+        int pRoot = 0;
+        bool usePloc = false;
+        out->costRadix = out->costPloc = 0.0f;
+        if (rc == 0 && dpCost && opt.ploc != 0 && n >= 4u) {
+            bool ok = hipMalloc(&pKnodes, sizeof(KNode) * (size_t)nInternal) == hipSuccess && hipMalloc(&pBox, sizeof(Box6) * (size_t)nInternal) == hipSuccess &&
+                      hipMalloc(&pCost, sizeof(float4) * (size_t)nInternal) == hipSuccess;
+            ok = ok && buildPLOC(st, leafBox, n, opt.plocRadius, pKnodes, pBox, pCost, &pRoot) == 0;
+            float4 cR{}, cP{};
+            Box6 rootBox{};
+            ok = ok && hipMemcpyAsync(&cR, dpCost, sizeof(float4), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(&cP, pCost + pRoot, sizeof(float4), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(&rootBox, nodeBox, sizeof(Box6), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+            if (ok) {
+                const float dx = rootBox.hi[0] - rootBox.lo[0], dy = rootBox.hi[1] - rootBox.lo[1], dz = rootBox.hi[2] - rootBox.lo[2];
+                const float ra = dx * dy + dy * dz + dz * dx;
+                out->costRadix = ra > 0.0f ? cR.x / ra : 0.0f, out->costPloc = ra > 0.0f ? cP.x / ra : 0.0f;
+                // PLOC has to win clearly (5 %): the surface-area measure assumes rays distributed like random lines through the root box,
+                // while real rays concentrate where the geometry is — the benchmark soup inside a room (c3d) rates PLOC 2.3 % cheaper
+                // because of the room's 18 large triangles and traces 4.3 % SLOWER with it (the soup itself suits the radix tree's regular
+                // cells: PLOC 4.9 % dearer, 3 % slower); a mesh gains far more than the margin (terrain: 26.5 % cheaper, 18 % fewer node
+                // visits per ray, +5.5 % Mrays/s) — profiles/r4j_ploc_ab.txt, r4k_tree_costs.txt
+                usePloc = opt.ploc >= 2 || cP.x < 0.95f * cR.x;
+            }
+            (void)hipGetLastError();
+        }
         const uint32_t nMax = (uint32_t)nInternal; // every 4-wide node stands for one binary inner node
         HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)n));
         int *binOf = nullptr;
         HR_CHECK(hipMalloc(&out->nodes, sizeof(Node4) * (size_t)nMax));
         HR_CHECK(hipMalloc(&out->nodeBox, sizeof(Box6) * (size_t)nMax));
         HR_CHECK(hipMalloc(&binOf, 4ull * nMax));
-        const int rootBin = 0;
-        const uint32_t init[2] = {1u, 0u};
-        HR_CHECK(hipMemcpyAsync(binOf, &rootBin, 4, hipMemcpyHostToDevice, st));
-        HR_CHECK(hipMemcpyAsync(total, init, 8, hipMemcpyHostToDevice, st));
         uint32_t levelStart = 0, levelEnd = 1;
-        for (int level = 0; level < 64 && levelEnd > levelStart; ++level) {
-            const uint32_t cnt = levelEnd - levelStart;
-            hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, knodes, leafBox, nodeBox, binOf, levelStart, levelEnd, total,
-                               total + 1, sorted, finalTris, out->nodes, out->nodeBox, dConsts, dpCost);
-            uint32_t newEnd = 0;
-            HR_CHECK(hipMemcpyAsync(&newEnd, total, 4, hipMemcpyDeviceToHost, st));
-            HR_CHECK(hipStreamSynchronize(st));
-            if (newEnd > nMax) {
-                rc = 4;
-                break;
+        for (int attempt = 0; attempt < 2 && rc == 0; ++attempt) {
+            const KNode *bk = usePloc ? pKnodes : knodes;
+            const Box6 *bb = usePloc ? pBox : nodeBox;
+            const float4 *bc = usePloc ? pCost : dpCost;
+            const int rootBin = usePloc ? pRoot : 0;
+            const uint32_t init[2] = {1u, 0u};
+            HR_CHECK(hipMemcpyAsync(binOf, &rootBin, 4, hipMemcpyHostToDevice, st));
+            HR_CHECK(hipMemcpyAsync(total, init, 8, hipMemcpyHostToDevice, st));
+            levelStart = 0, levelEnd = 1;
+            out->levels = 0;
+            // (the radix tree is at most 58 levels deep — its key length; a PLOC tree has no such bound, so it is only kept when its collapse
+            // fits the traversal stack; otherwise the second attempt collapses the radix tree)
+            const int levelCap = usePloc ? (opt.maxLevels < 64 ? opt.maxLevels : 64) : 64;
+            for (int level = 0; level < levelCap && levelEnd > levelStart; ++level) {
+                const uint32_t cnt = levelEnd - levelStart;
+                hipLaunchKernelGGL(k_collapse4, dim3((cnt + 255) / 256), dim3(256), 0, st, bk, leafBox, bb, binOf, levelStart, levelEnd, total,
+                                   total + 1, sorted, finalTris, out->nodes, out->nodeBox, dConsts, bc);
+                uint32_t newEnd = 0;
+                HR_CHECK(hipMemcpyAsync(&newEnd, total, 4, hipMemcpyDeviceToHost, st));
+                HR_CHECK(hipStreamSynchronize(st));
+                if (newEnd > nMax) {
+                    rc = 4;
+                    break;
+                }
+                out->levelStart[level] = levelStart, out->levelStart[level + 1] = levelEnd;
+                levelStart = levelEnd;
+                levelEnd = newEnd;
+                out->levels = level + 1;
             }
-            out->levelStart[level] = levelStart, out->levelStart[level + 1] = levelEnd;
-            levelStart = levelEnd;
-            levelEnd = newEnd;
-            out->levels = level + 1;
+            if (rc == 0 && levelEnd > levelStart && usePloc) { // too deep for the stack: fall back to the radix tree
+                usePloc = false;
+                continue;
+            }
+            break;
         }
+        out->builder = usePloc ? 1 : 0;
         hipFree(binOf);
+        hipFree(pKnodes), hipFree(pBox), hipFree(pCost);
         if (levelEnd > levelStart && rc == 0) rc = 6; // deeper than the key length allows: cannot happen with n < 2^28
         out->nNodes = (int)levelEnd;
         uint32_t placed = 0;

@@ -229,6 +229,7 @@ struct hr_ctx {
     // recomputed bottom-up on the device, no allocation, one synchronisation at the end.
     bool topologyDirty = true, transformDirty = false;
     int tuneRefit = 1;        // HR_TUNE="refit=0": always rebuild
+    int tunePloc = 1, tunePlocRadius = 16; // HR_TUNE="ploc=0|1|2,plocr=N": tree builder (hr_build.hip: buildLBVH keeps the cheaper of the radix tree and PLOC)
     int tuneGuardPct = 125;   // HR_TUNE="guard=N": a refit whose boxes' area exceeds N % of the built tree's rebuilds instead (profiles/r3j_instanced_refit.txt)
     // persistent device arrays of the committed scene (grow-only capacities, reused across commits)
     GeomDev *dG = nullptr;
@@ -520,7 +521,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -1236,7 +1237,8 @@ int hr_scene_commit(hr_ctx *c)
                 launchSceneConsts(c->stream, c->dScratch, c->dConsts, nullptr);
                 cacheHit = true;
             } else {
-                const int brc = buildLBVH(c->stream, c->trisPrim, nTris, k.lo, k.hi, k.pad, c->dConsts, &cs.br);
+                const BuildOptions bo{c->tunePloc, c->tunePlocRadius, (kStackLDS + kStackOvf) / 3};
+                const int brc = buildLBVH(c->stream, c->trisPrim, nTris, k.lo, k.hi, k.pad, c->dConsts, &cs.br, bo);
                 if (brc != 0) FAIL(c, HR_ERR_DEVICE, brc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
                 if (!c->cachePath.empty()) saveTree(c, key, nTris, cs.br);
             }
@@ -1262,7 +1264,8 @@ int hr_scene_commit(hr_ctx *c)
         c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)c->tree.nNodes, c->info.ray_epsilon = k.eps;
         c->info.bvh_levels = (uint32_t)c->tree.levels;
         c->info.refitted = refit ? 1u : (cacheHit ? 2u : 0u);
-        c->info.box_area_ratio = (c->builtAreaSum > 0.0f && k.triAreaSum > 0.0f) ? (k.areaSum / k.triAreaSum) / c->builtAreaSum : 0.0f, c->info.reserved = 0;
+        c->info.box_area_ratio = (c->builtAreaSum > 0.0f && k.triAreaSum > 0.0f) ? (k.areaSum / k.triAreaSum) / c->builtAreaSum : 0.0f;
+        c->info.builder = (uint32_t)c->tree.builder, c->info.cost_radix = c->tree.costRadix, c->info.cost_ploc = c->tree.costPloc;
     }
     HIP_TRY(c, hipEventRecord(cs.e1, c->stream));
     HIP_TRY(c, hipEventSynchronize(cs.e1));

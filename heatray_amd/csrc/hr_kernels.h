@@ -160,6 +160,13 @@ struct BuildResult {
     int32_t levels; // levels of 4-wide inner nodes (the traversal stack holds at most 3 entries per level)
     uint32_t triSlots;    // entries of `tris` (32-byte nodes: 4 per node, some unused)
     uint32_t levelStart[kMaxLevels + 1]; // nodes of level L are [levelStart[L], levelStart[L + 1]) (breadth-first allocation)
+    int32_t builder;            // which binary tree was collapsed: 0 the radix tree over Morton codes (LBVH), 1 PLOC
+    float costRadix, costPloc;  // summed surface area of the 4-wide nodes over the root's, per candidate (0: not built)
+};
+struct BuildOptions {
+    int ploc;       // 0: radix tree only; 1: build both, keep the cheaper collapse; 2: PLOC whenever it fits the traversal stack
+    int plocRadius; // search radius of the nearest-neighbour step
+    int maxLevels;  // levels of 4-wide nodes the traversal stack can hold (a PLOC tree deeper than that is not used)
 };
 
 // scene bounds as float-ordered uints: lo.xyz, hi.xyz.  slotOfPrim != null: triangles go to their leaf slot (refit), else prim order.
@@ -169,7 +176,7 @@ void launchAssemble(hipStream_t st, const GeomDev *geoms, int nGeoms, uint32_t n
 void launchSceneConsts(hipStream_t st, const uint32_t *boundsOrdered, SceneConsts *out, SceneDev *scene);
 // Full LBVH build from assembled triangles (prim order); allocates scratch internally; returns device arrays (hipMalloc).
 int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const float lo[3], const float hi[3], float pad,
-              const SceneConsts *deviceConsts, BuildResult *out);
+              const SceneConsts *deviceConsts, BuildResult *out, const BuildOptions &opt);
 // Refit: the tree keeps its topology; every node's child boxes are recomputed bottom-up from the triangles in `tree.tris`
 // (already moved by launchAssemble) and re-quantised.  Level by level, no host synchronisation.
 void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts);

@@ -144,7 +144,9 @@ typedef struct hr_scene_info {
     float box_area_ratio; /* quality of a refitted tree: (sum of its node boxes' areas / sum of its triangles' areas) relative to the
                            * value right after the last full build (1 after a build; a refit whose ratio would exceed 1.25 rebuilds
                            * instead); 0: unknown */
-    uint32_t reserved;
+    uint32_t builder;     /* which binary tree the 4-wide tree was collapsed from: 0 the radix tree over Morton codes (LBVH), 1 PLOC */
+    float cost_radix;     /* summed surface area of the 4-wide nodes / the root's, for the radix tree ...                              */
+    float cost_ploc;      /* ... and for the PLOC tree (expected node visits of a random ray; the cheaper one is kept; 0: not built)    */
 } hr_scene_info;
 int hr_scene_get_info(hr_ctx *ctx, hr_scene_info *out);
 

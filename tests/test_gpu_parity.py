@@ -129,6 +129,52 @@ def test_traversal_hits_bit_exact(n_tris):
     assert ag.tobytes() == ao.tobytes()
 
 
+@pytest.mark.parametrize("tune,builder", [("ploc=0", 0), ("ploc=2", 1), ("ploc=2,plocr=3", 1), ("ploc=1", None)])
+def test_both_tree_builders_give_the_oracles_hits(monkeypatch, tune, builder):
+    # hr_build.hip builds two binary trees over the Morton-ordered triangles — the radix tree (LBVH) and PLOC — and collapses the one
+    # with the cheaper 4-wide tree (HR_TUNE ploc=1, the default; 0 / 2 force one).  Hits never depend on the tree: a mesh (where PLOC
+    # wins), the uniform soup (where the radix tree wins) and the hostile scene give the oracle's hits bit for bit either way.
+    monkeypatch.setenv("HR_TUNE", tune)
+    for sc in (scenes.terrain(120, 60, width=32, height=32), scenes.triangle_soup(30000, width=32, height=32), _hostile_scene()[0]):
+        g, o = core.create_engine(), oracle_lib.engine()
+        sc.apply(g), sc.apply(o)
+        gi = g.scene_info()
+        if builder is not None and gi.n_triangles >= 4:
+            assert gi.builder == builder, (sc.name, gi.builder)
+        if tune != "ploc=0":
+            assert gi.cost_radix > 0 and gi.cost_ploc > 0
+            if tune == "ploc=1":
+                assert gi.builder == (1 if gi.cost_ploc < 0.95 * gi.cost_radix else 0)
+        rng = np.random.default_rng(5)
+        n = 20000
+        # (the hostile scene keeps the ray distribution of its own test above — origins within a few units, every ray aimed at a
+        # triangle: its 8000-unit triangle puts the bounds thousands of units from half-unit triangles, and at such distances float32
+        # Moeller-Trumbore itself reports phantom hits metres off a triangle, which no box test around the real triangle can — or
+        # should — reproduce)
+        hostile = sc.name == "hostile"
+        lo, hi = (np.full(3, -1.25), np.full(3, 1.25)) if hostile else (np.array(gi.aabb_min), np.array(gi.aabb_max))
+        org = rng.uniform(lo - 0.2 * (hi - lo), hi + 0.2 * (hi - lo), (n, 3)).astype(np.float32)
+        d = rng.normal(size=(n, 3))
+        tgt = np.concatenate([m.positions[m.indices.astype(np.int64)].reshape(-1, 3, 3).mean(axis=1) for m in sc.meshes])
+        k = n if hostile else n // 2
+        aim = tgt[rng.integers(0, tgt.shape[0], k)] + rng.normal(scale=1e-3, size=(k, 3)) - org[:k]
+        d[:k] = aim
+        d = (d / np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-30)).astype(np.float32)
+        hg, ho = g.debug_trace(org, d), o.debug_trace(org, d)
+        assert (ho["prim"] >= 0).sum() > 100
+        assert hg.tobytes() == ho.tobytes(), f"{sc.name}: {(hg != ho).sum()} of {n} closest hits differ"
+        tm = rng.uniform(0.05, 2.5, n).astype(np.float32) * float(np.linalg.norm(hi - lo)) * 0.3
+        ag = g.debug_trace(org, d, tmax=tm, skip_prim=ho["prim"], any_hit=True)
+        ao = o.debug_trace(org, d, tmax=tm, skip_prim=ho["prim"], any_hit=True)
+        assert ag.tobytes() == ao.tobytes()
+        # a transform edit refits whichever tree was built
+        g.set_transform(0, scenes._translate(0.01, 0.02, -0.01)), o.set_transform(0, scenes._translate(0.01, 0.02, -0.01))
+        g.commit(), o.commit()
+        assert g.scene_info().refitted == 1
+        assert g.debug_trace(org, d).tobytes() == o.debug_trace(org, d).tobytes()
+        g.close(), o.close()
+
+
 def test_traversal_vs_brute_force_oracle():
     sc = scenes.triangle_soup(5000, width=32, height=32)
     g, o = core.create_engine(), oracle_lib.engine()
@@ -209,7 +255,8 @@ def test_hostile_geometry_hits_bit_exact(golden):
     assert_parity(g.readback(), o.readback(), "hostile geometry render")
 
 
-def test_deep_tree_stresses_the_traversal_stack():
+@pytest.mark.parametrize("tune", ["", "ploc=2"])
+def test_deep_tree_stresses_the_traversal_stack(monkeypatch, tune):
     # A deliberately deep tree: 8192 coincident triangles inside one Morton cell of a scene 2000 units wide (the radix tree splits
     # them on index bits, and every ray through them hits all four children at every level), a chain of 28 nested, mutually
     # overlapping sheets whose centroids sit in ever smaller Morton cells, and some filler.  The traversal stack (16 LDS entries
@@ -229,11 +276,12 @@ def test_deep_tree_stresses_the_traversal_stack():
     nrm = np.tile(np.array([0, 0, 1], np.float32), (pos.shape[0] * 3, 1))
     sc.materials = scenes._material_palette(scenes.SplitMix64(2), 1)
     sc.meshes.append(scenes.MeshData(pos.reshape(-1, 3), nrm, np.arange(pos.shape[0] * 3, dtype=np.uint32), material_id=0))
+    monkeypatch.setenv("HR_TUNE", tune)
     g, ob = core.create_engine(), oracle_lib.engine()
     sc.apply(g), sc.apply(ob)
     oracle_lib.load().ora_set_brute_force(ob._ctx, 1)
     info = g.scene_info()
-    assert info.bvh_levels >= 8, info.bvh_levels                    # a shallow tree would not test anything
+    assert info.bvh_levels >= (8 if not tune else 5), info.bvh_levels   # a shallow tree would not test anything
     assert 3 * info.bvh_levels <= 16 + 160                          # kStackLDS + kStackOvf (hr_trace.h)
     n = 4000
     org = np.zeros((n, 3), np.float32)
