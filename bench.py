@@ -520,7 +520,10 @@ def main():
     # first touch of ~10 GB of pass slots), which the 2-step warm-up of the contract does not absorb.
     t_wake = time.perf_counter()
     n_wake = 0
-    while not args.no_wakeup and (n_wake < 64 or (time.perf_counter() - t_wake < 1.0 and n_wake < 1024)):
+    # (round 4: 64 passes — 0.17 s — measure the same as the 512 of rounds 2-3, also as the first GPU process of a fresh box:
+    # profiles/r4l_wakeup.txt; HR_BENCH_WAKE_MAX overrides)
+    wake_cap = int(os.environ.get("HR_BENCH_WAKE_MAX", "64"))
+    while not args.no_wakeup and n_wake < wake_cap:
         eng.render_pass(sc.options.pass_params(n_wake % passes_total))
         n_wake += 1
         if n_wake % 32 == 0:
