@@ -6,6 +6,7 @@
 #include "hr_kernels.h"
 #include "hr_trace.h"
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -13,6 +14,7 @@
 #include <cstring>
 #include <deque>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace hr;
@@ -106,10 +108,11 @@ struct hr_ctx {
         int step = 0, nIter = 0;
         unsigned long long order = 0; // injection order (passes resolve in this order)
         hr_pass_params pp{};
-        RayQueue q[2]{};
-        ShadowQueue sq{};
-        void *hits = nullptr;
-        uint32_t *hitIdx = nullptr; // hit list: PBR hits from the front, glass hits from the back (k_shade_sort -> k_shade_hit)
+        // The pass's rays live in its group's step arenas (Group::arena): what its last step's shading emitted, i.e. what its next
+        // step traces.  Only the pass buffer belongs to the slot.
+        RayQueue qcur{};       // closest-hit rays of the pass's next stage
+        ShadowQueue scur{};    // occlusion rays of the pass's next stage
+        uint32_t capCur = 0;   // rays qcur can hold (= upper bound of what it holds)
         float *passbuf = nullptr;
         float *passbufB = nullptr; // second partial sum (allLightsUsed): passbuf + W * H * 4, same allocation
         Counters *ctr = nullptr;
@@ -134,6 +137,30 @@ struct hr_ctx {
         // steps ago (a step that has long finished while newer ones are still queued: it never waits for work it has just
         // enqueued) and retires the passes whose queue ran empty.
         uint32_t *hQCount = nullptr;    // [kStatusRing][kMaxSlots][kMaxBounceSlots], pinned
+        // Ray memory of the group (round 4).  A pass used to own two ray queues, an occlusion queue, hit records and a hit list, all
+        // sized for EVERY owned pixel, for its whole life: 196 B x pixels x 120 slots = 53 GB for a 1080p render, while a pass past
+        // its first bounce holds a few percent of the pixels.  Now every macro step carves what it needs out of three regions:
+        //   arena[t & 1]  what step t's shading emits (closest-hit and occlusion rays of every in-flight pass), read by step t + 1;
+        //   scratch       what lives inside one step: the injected passes' camera rays, hit records, hit lists.
+        // A queue is sized by an upper bound of what can arrive in it: a ray emits at most one continuation ray and kS occlusion rays,
+        // so the bound is the length of the pass's closest-hit queue ONE stage earlier — which k_trace itself reports: its first
+        // workgroup writes, when it starts, the queue lengths of its step table to pinned host memory and then the step's number
+        // (hCounts / hSeq; no packet on the stream).  Preparing step t the host waits for step t - 1's report (by then step t - 2 has
+        // finished and all of step t - 1 is still queued: the device never runs dry); only a pass's FIRST stage is sized by pixels.
+        // Regions grow on demand (a synchronisation of the group's stream, during the first passes of a render).
+        struct Region {
+            char *base = nullptr;
+            size_t cap = 0;
+        };
+        Region arena[2], scratch;
+        size_t arenaHighWater = 0; // most either half ever needed: both halves are kept that large (consecutive steps see the same load)
+        uint32_t *hCounts = nullptr;                   // [kTableRing][kMaxSegs], pinned: closest-hit queue length per table entry
+        volatile unsigned long long *hSeq = nullptr;   // [kTableRing], pinned: step number + 1 whose lengths the entry holds
+        uint32_t *dCounts = nullptr;                   // the same two arrays as the device addresses them
+        unsigned long long *dSeq = nullptr;
+        int countN[4] = {0, 0, 0, 0};                  // entries of the step table that went with ring entry r
+        int countSlot[4][HR_MAX_SEGS];                 // ... their pass slots
+        unsigned long long countOrder[4][HR_MAX_SEGS]; // ... and passes (order + 1)
         hipEvent_t statusEv[4] = {nullptr, nullptr, nullptr, nullptr};
         bool statusUsed[4] = {false, false, false, false};
         unsigned long long statusOrder[4][2 * HR_MAX_SEGS]; // pass (order + 1) a slot held when the snapshot was taken, 0 = none
@@ -229,6 +256,8 @@ struct hr_ctx {
     // recomputed bottom-up on the device, no allocation, one synchronisation at the end.
     bool topologyDirty = true, transformDirty = false;
     int tuneRefit = 1;        // HR_TUNE="refit=0": always rebuild
+    // pipeline diagnostics (HR_DEBUG_PIPE=1 prints them when the context is destroyed)
+    unsigned long long dbgGrowths = 0, dbgGrowBytes = 0, dbgWaits = 0, dbgWaitNs = 0, dbgWaitSpun = 0;
     int tunePloc = 1, tunePlocRadius = 16; // HR_TUNE="ploc=0|1|2,plocr=N": tree builder (hr_build.hip: buildLBVH keeps the cheaper of the radix tree and PLOC)
     int tuneGuardPct = 125;   // HR_TUNE="guard=N": a refit whose boxes' area exceeds N % of the built tree's rebuilds instead (profiles/r3j_instanced_refit.txt)
     // persistent device arrays of the committed scene (grow-only capacities, reused across commits)
@@ -432,19 +461,22 @@ static int finishLagged(hr_ctx *c, hr_ctx::Lagged &L, int k, int32_t format, con
 static void freeQueues(hr_ctx *c)
 {
     for (hr_ctx::PassSlot &ps : c->slots) {
-        for (int i = 0; i < 2; ++i) hipFree(ps.q[i].A), hipFree(ps.q[i].B), hipFree(ps.q[i].C), hipFree(ps.q[i].D);
-        hipFree(ps.sq.A), hipFree(ps.sq.B), hipFree(ps.sq.C);
-        hipFree(ps.hits), hipFree(ps.hitIdx), hipFree(ps.passbuf);
+        hipFree(ps.passbuf);
         if (ps.evFinal) hipEventDestroy(ps.evFinal);
         if (ps.evResolved) hipEventDestroy(ps.evResolved);
         ps = hr_ctx::PassSlot();
+    }
+    for (hr_ctx::Group &G : c->groups) {
+        hipFree(G.arena[0].base), hipFree(G.arena[1].base), hipFree(G.scratch.base);
+        G.arena[0] = G.arena[1] = G.scratch = hr_ctx::Group::Region();
+        G.arenaHighWater = 0;
     }
     c->nSlotsAllocated = 0;
     c->queueCapacity = 0;
 }
 
-// how many passes may be in flight: each slot holds two ray queues, an occlusion queue, hit records and a pass buffer
-// (twice the occlusion queue and a second pass buffer once HR_ESTIMATOR_ALL_LIGHTS has been used)
+// how many passes may be in flight: a slot holds a pass buffer (four partial sums once HR_ESTIMATOR_ALL_LIGHTS has been used); the rays
+// live in the groups' step arenas, about 7 KB per owned pixel of the frame for both generations of a step's young passes (below)
 static void slotBudget(hr_ctx *c)
 {
     size_t freeB = 0, totalB = 0;
@@ -452,7 +484,7 @@ static void slotBudget(hr_ctx *c)
     if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
         const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
         const size_t k = c->allLightsUsed ? 4 : 1;
-        const size_t perSlot = (size_t)(c->queueCapacity ? c->queueCapacity : 1) * (2 * 64 + 48 * k + hitRecordSize() + 4) + fbBytes * k + sizeof(Counters);
+        const size_t perSlot = fbBytes * k + sizeof(Counters);
         const size_t fit = (freeB / 2) / perSlot; // at most half of the free device memory for pass slots
         c->maxSlots = fit < 1 ? 1 : (fit > (size_t)kMaxSlots ? kMaxSlots : (int)fit);
     }
@@ -545,6 +577,12 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.statusEv[k], hipEventDisableTiming) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hQCount, sizeof(uint32_t) * kTableRing * kMaxSlots * kMaxBounceSlots, hipHostMallocDefault) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hCounts, sizeof(uint32_t) * kTableRing * kMaxSegs, hipHostMallocDefault) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hSeq, sizeof(unsigned long long) * kTableRing, hipHostMallocDefault) == hipSuccess;
+        groupsOk = groupsOk && hipHostGetDevicePointer((void **)&G.dCounts, G.hCounts, 0) == hipSuccess &&
+                   hipHostGetDevicePointer((void **)&G.dSeq, (void *)G.hSeq, 0) == hipSuccess;
+        if (groupsOk)
+            for (int k = 0; k < kTableRing; ++k) G.hSeq[k] = 0ull;
         std::memset(G.statusOrder, 0, sizeof(G.statusOrder));
     }
     if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
@@ -563,6 +601,9 @@ int hr_ctx_destroy(hr_ctx *c)
 {
     if (!c) return HR_OK;
     hipSetDevice(c->device);
+    if (getenv("HR_DEBUG_PIPE"))
+        fprintf(stderr, "hr_ctx %p: ray-memory growths %llu (last sizes summed %.1f MiB); queue-length waits %llu, of which %llu had to spin, %.2f ms in total\n", (void *)c,
+                c->dbgGrowths, (double)c->dbgGrowBytes / 1048576.0, c->dbgWaits, c->dbgWaitSpun, (double)c->dbgWaitNs * 1e-6);
     drainPipeline(c);
     hipStreamSynchronize(c->stream);
     c->drainTimes();
@@ -589,6 +630,8 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dCounters);
     for (hr_ctx::Group &G : c->groups) {
         if (G.hQCount) hipHostFree(G.hQCount);
+        if (G.hCounts) hipHostFree(G.hCounts);
+        if (G.hSeq) hipHostFree((void *)G.hSeq);
         for (hipEvent_t e : G.statusEv)
             if (e) hipEventDestroy(e);
         if (G.stream) hipStreamDestroy(G.stream);
@@ -783,7 +826,7 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
         // together: 9 passes of a 1080p frame per step measured 1715 against 1607 Mrays/s (128 passes) and 1488 against 1400
         // (20 passes) for one at a time on two pipeline groups (profiles/r2b_batch_sweep*.txt).  Round 3, with the small launches
         // dealt out statically and the shading stage split: 11-14 passes per step are another 3-4 % over 9 at 20 passes and 2 % at
-        // 128 (profiles/r3n_batch_sweep.txt); 12 it is (120 pass slots of a 1080p frame: 53 GB of the 288).  A caller that asks for
+        // 128 (profiles/r3n_batch_sweep.txt); 12 it is (120 pass buffers of a 1080p frame and the step arenas: ~21 GB of the 288; 53 GB before round 4 sized the queues by stage).  A caller that asks for
         // pixels after every pass (hr_readback) completes what is pending, so batching never delays a displayed frame.
         const long long target = 12ll * 1920ll * 1080ll;
         const long long own = c->queueCapacity ? c->queueCapacity : 1;
@@ -1665,6 +1708,7 @@ int hr_clear(hr_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats) * kStatSlots, c->stream));
     c->resolvedAtClear = c->nextResolveOrder;
     c->snapshotEpoch++;
+    if (getenv("HR_DEBUG_PIPE")) fprintf(stderr, "hr_clear %p: ray-memory growths so far %llu, waits %llu (%.2f ms)\n", (void *)c, c->dbgGrowths, c->dbgWaits, (double)c->dbgWaitNs * 1e-6);
     c->drainTimes();
     for (int k = 0; k < HR_KERNEL_COUNT; ++k) c->kernelMs[k] = 0.0f, c->kernelLaunches[k] = 0;
     return HR_OK;
@@ -1672,38 +1716,74 @@ int hr_clear(hr_ctx *c)
 
 static int allocSlot(hr_ctx *c, hr_ctx::PassSlot &ps)
 {
-    const size_t cap = c->queueCapacity ? c->queueCapacity : 1;
-    const size_t n16 = cap * 16;
     const size_t fbBytes = (size_t)c->W * c->H * 4 * sizeof(float);
-    hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipMalloc(&ps.q[i].A, n16);
-        if (e == hipSuccess) e = hipMalloc(&ps.q[i].B, n16);
-        if (e == hipSuccess) e = hipMalloc(&ps.q[i].C, n16);
-        if (e == hipSuccess) e = hipMalloc(&ps.q[i].D, n16);
-    }
-    const size_t s16 = n16 * (c->allLightsUsed ? 4 : 1); // up to four occlusion rays per path with HR_ESTIMATOR_ALL_LIGHTS
-    if (e == hipSuccess) e = hipMalloc(&ps.sq.A, s16);
-    if (e == hipSuccess) e = hipMalloc(&ps.sq.B, s16);
-    if (e == hipSuccess) e = hipMalloc(&ps.sq.C, s16);
-    if (e == hipSuccess) e = hipMalloc(&ps.hits, cap * hitRecordSize());
-    if (e == hipSuccess) e = hipMalloc(&ps.hitIdx, cap * sizeof(uint32_t));
-    // (with HR_ESTIMATOR_ALL_LIGHTS the sample's second partial sum lies right behind the first: k_trace indexes one buffer)
-    if (e == hipSuccess) e = hipMalloc(&ps.passbuf, fbBytes * (c->allLightsUsed ? 4 : 1));
-    if (e == hipSuccess && c->allLightsUsed) ps.passbufB = ps.passbuf + (size_t)c->W * c->H * 4;
+    // (with HR_ESTIMATOR_ALL_LIGHTS the sample's further partial sums lie right behind the first: k_trace indexes one buffer)
+    const hipError_t e = hipMalloc(&ps.passbuf, fbBytes * (c->allLightsUsed ? 4 : 1));
     if (e != hipSuccess) { // say what ran out: a pass slot is the unit the pipeline's memory grows in
         size_t freeB = 0, totalB = 0;
         hipMemGetInfo(&freeB, &totalB);
-        c->err = "pass slot " + std::to_string(c->nSlotsAllocated + 1) + " (" + std::to_string((11 * n16 + cap * hitRecordSize() + fbBytes) >> 20) +
-                 " MiB of ray queues and pass buffer at " + std::to_string(c->W) + "x" + std::to_string(c->H) + "): " + hipGetErrorString(e) + "; " +
-                 std::to_string(freeB >> 20) + " MiB of device memory free";
+        c->err = "pass slot " + std::to_string(c->nSlotsAllocated + 1) + " (" + std::to_string(fbBytes >> 20) + " MiB pass buffer at " + std::to_string(c->W) + "x" +
+                 std::to_string(c->H) + "): " + hipGetErrorString(e) + "; " + std::to_string(freeB >> 20) + " MiB of device memory free";
         return HR_ERR_DEVICE;
     }
+    if (c->allLightsUsed) ps.passbufB = ps.passbuf + (size_t)c->W * c->H * 4;
     ps.ctr = c->dCounters + (&ps - c->slots);
     HIP_TRY(c, hipEventCreateWithFlags(&ps.evFinal, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&ps.evResolved, hipEventDisableTiming));
     ps.allocated = true;
     c->nSlotsAllocated++;
+    return HR_OK;
+}
+
+// ---- the groups' ray memory (hr_ctx::Group::arena / scratch)
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+static size_t rayQueueBytes(size_t cap) { return 4 * align256(cap * 16); }
+static size_t shadowQueueBytes(size_t cap) { return 3 * align256(cap * 16); }
+static RayQueue carveRayQueue(char *&p, size_t cap)
+{
+    RayQueue q;
+    const size_t n = align256(cap * 16);
+    q.A = (float4 *)p, q.B = (float4 *)(p + n), q.C = (float4 *)(p + 2 * n), q.D = (int4 *)(p + 3 * n);
+    p += 4 * n;
+    return q;
+}
+static ShadowQueue carveShadowQueue(char *&p, size_t cap)
+{
+    ShadowQueue q;
+    const size_t n = align256(cap * 16);
+    q.A = (float4 *)p, q.B = (float4 *)(p + n), q.C = (float4 *)(p + 2 * n);
+    p += 3 * n;
+    return q;
+}
+// a region that is too small is replaced once everything the group has enqueued is done (what it held is dead by then: a step's
+// scratch dies with the step, and arena[t & 1] holds the rays step t - 2 emitted, which step t - 1 consumed)
+static int ensureRegion(hr_ctx *c, hr_ctx::Group &G, hr_ctx::Group::Region &r, size_t need, const char *what)
+{
+    if (need <= r.cap) return HR_OK;
+    c->dbgGrowths++, c->dbgGrowBytes += need;
+    if (getenv("HR_DEBUG_PIPE")) fprintf(stderr, "  grow %s: need %.1f MiB, had %.1f MiB (step %llu)\n", what, (double)need / 1048576.0, (double)r.cap / 1048576.0, G.stepCounter);
+    HIP_TRY(c, hipStreamSynchronize(G.stream));
+    hipFree(r.base);
+    r.base = nullptr, r.cap = 0;
+    // a third of headroom: counts vary from pass to pass, and while the pipeline fills (the first depth + 2 steps of a render) every
+    // step carries one more generation of passes — for the benchmark soup the steady state needs 27 % more than the step that
+    // triggered the last growth (profiles/r4m_mem.txt); a step that needs more regrows once more
+    const size_t want = (need + need / 3 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+    hipError_t e = hipMalloc((void **)&r.base, want);
+    size_t got = want;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        got = align256(need);
+        e = hipMalloc((void **)&r.base, got);
+    }
+    if (e != hipSuccess) {
+        size_t freeB = 0, totalB = 0;
+        hipMemGetInfo(&freeB, &totalB);
+        c->err = std::string("ray memory (") + what + ", " + std::to_string(need >> 20) + " MiB for one macro step at " + std::to_string(c->W) + "x" + std::to_string(c->H) +
+                 "): " + hipGetErrorString(e) + "; " + std::to_string(freeB >> 20) + " MiB of device memory free";
+        return HR_ERR_DEVICE;
+    }
+    r.cap = got;
     return HR_OK;
 }
 
@@ -1769,6 +1849,30 @@ static int resolveReady(hr_ctx *c)
     }
 }
 
+// wait for the queue lengths step (want - 1) of this group reports when its k_trace starts (Group::hCounts)
+static int waitCounts(hr_ctx *c, hr_ctx::Group &G, int ring, unsigned long long want)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    c->dbgWaits++;
+    for (unsigned spins = 0;; ++spins) {
+        if (G.hSeq[ring] == want) {
+            if (spins) c->dbgWaitSpun++, c->dbgWaitNs += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            break;
+        }
+        if ((spins & 255u) == 255u) {
+            const hipError_t q = hipStreamQuery(G.stream);
+            if (q == hipSuccess) { // everything enqueued has run: the report must have arrived
+                if (G.hSeq[ring] == want) break;
+                FAIL(c, HR_ERR_DEVICE, "internal: a step's queue lengths never arrived");
+            }
+            if (q != hipErrorNotReady) HIP_TRY(c, q);
+            std::this_thread::yield();
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return HR_OK;
+}
+
 // One macro step of pipeline group g: (raygen of the injected passes) -> trace of every in-flight pass of the group ->
 // shade; passes whose last stage this was become `finished`.
 static int macroStep(hr_ctx *c, int g, int nInject)
@@ -1818,6 +1922,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         }
         waited[nInjected] = ps.everResolved ? ps.resolvedEv : nullptr;
         ps.active = true, ps.finished = false, ps.group = g, ps.step = 0, ps.nIter = pp.max_ray_depth + 1, ps.pp = pp;
+        ps.qcur = RayQueue{}, ps.scur = ShadowQueue{}, ps.capCur = 0;
         ps.order = c->injected++;
         injectedSlots[nInjected++] = slot;
     }
@@ -1863,8 +1968,56 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         for (int b = a; b > 0 && c->slots[order[b]].order < c->slots[order[b - 1]].order; --b) std::swap(order[b], order[b - 1]);
     if (n == 0) return resolveReady(c);
     if (n > kMaxSegs) FAIL(c, HR_ERR_INVALID, "internal: too many passes in one group");
-    const int ring = (int)(G.stepCounter++ % kTableRing);
+    const unsigned long long stepIdx = G.stepCounter++;
+    const int ring = (int)(stepIdx % kTableRing);
     if (G.tableUsed[ring]) HIP_TRY(c, hipEventSynchronize(G.tableCopied[ring])); // staging entry free again (4 steps old)
+    // ---- ray memory of this step (Group::arena): every queue sized by an upper bound of what can arrive in it
+    const uint32_t P = c->queueCapacity ? c->queueCapacity : 1u;
+    const size_t kS = c->allLightsUsed ? 4 : 1;
+    uint32_t boundIn[kMaxSegs];
+    {
+        bool wanted = false;
+        for (int k = 0; k < n; ++k) wanted = wanted || c->slots[order[k]].step > 0;
+        int idxOfSlot[kMaxSlots];
+        const int prev = (int)((stepIdx + kTableRing - 1) % kTableRing);
+        if (wanted && stepIdx > 0) {
+            int rc = waitCounts(c, G, prev, stepIdx); // (step stepIdx - 1 wrote stepIdx: its number + 1)
+            if (rc) return rc;
+            for (int i = 0; i < kMaxSlots; ++i) idxOfSlot[i] = -1;
+            for (int j = 0; j < G.countN[prev]; ++j) idxOfSlot[G.countSlot[prev][j]] = j;
+        }
+        for (int k = 0; k < n; ++k) {
+            const hr_ctx::PassSlot &ps = c->slots[order[k]];
+            uint32_t b = P;
+            if (ps.step > 0) {
+                b = ps.capCur; // (what its queue can hold is a bound too: used when the pass was not in the previous step's table)
+                const int j = (wanted && stepIdx > 0) ? idxOfSlot[order[k]] : -1;
+                if (j >= 0 && G.countOrder[prev][j] == ps.order + 1ull) {
+                    const uint32_t seen = G.hCounts[(size_t)prev * kMaxSegs + j]; // length of its closest-hit queue one stage ago
+                    b = seen < b ? seen : b;
+                }
+            }
+            boundIn[k] = b;
+        }
+    }
+    size_t needArena = 0, needScratch = 0;
+    for (int k = 0; k < n; ++k) {
+        const hr_ctx::PassSlot &ps = c->slots[order[k]];
+        const bool closest = c->hasPassthrough || ps.step < ps.nIter;
+        if (ps.step == 0) needScratch += rayQueueBytes(P);
+        if (closest) {
+            needScratch += align256((size_t)boundIn[k] * hitRecordSize()) + align256((size_t)boundIn[k] * 4);
+            needArena += rayQueueBytes(boundIn[k]) + shadowQueueBytes((size_t)boundIn[k] * kS);
+        }
+    }
+    hr_ctx::Group::Region &arena = G.arena[stepIdx & 1ull];
+    {
+        G.arenaHighWater = needArena > G.arenaHighWater ? needArena : G.arenaHighWater;
+        int rc = ensureRegion(c, G, arena, G.arenaHighWater, "rays emitted by a step");
+        if (rc == HR_OK) rc = ensureRegion(c, G, G.scratch, needScratch, "camera rays and hit records of a step");
+        if (rc) return rc;
+    }
+    char *pArena = arena.base, *pScratch = G.scratch.base;
     StepTable &tbl = G.hTables[ring];
     std::memset(tbl.heads, 0, sizeof(tbl.heads));
     std::memset(tbl.clkStart, 0xFF, sizeof(tbl.clkStart)), std::memset(tbl.clkEnd, 0, sizeof(tbl.clkEnd));
@@ -1880,8 +2033,18 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         hr_ctx::PassSlot &ps = c->slots[order[k]];
         SegDev &sg = tbl.seg[k];
         const int st = ps.step;
-        sg.qin = ps.q[st & 1], sg.qout = ps.q[(st + 1) & 1], sg.sq = ps.sq;
-        sg.hits = (HitRec *)ps.hits, sg.passbuf = ps.passbuf;
+        const bool closest = c->hasPassthrough || st < ps.nIter;
+        sg.qin = st == 0 ? carveRayQueue(pScratch, P) : ps.qcur; // (a new pass's camera rays live for this step only)
+        sg.sqIn = ps.scur;                                        // (nothing to trace there in a pass's first step: sCountIn is the zero word)
+        sg.qout = RayQueue{}, sg.sqOut = ShadowQueue{}, sg.hits = nullptr, sg.hitIdx = nullptr;
+        if (closest) {
+            sg.hits = (HitRec *)pScratch, pScratch += align256((size_t)boundIn[k] * hitRecordSize());
+            sg.hitIdx = (uint32_t *)pScratch, pScratch += align256((size_t)boundIn[k] * 4);
+            sg.qout = carveRayQueue(pArena, boundIn[k]);
+            sg.sqOut = carveShadowQueue(pArena, (size_t)boundIn[k] * kS);
+            ps.qcur = sg.qout, ps.scur = sg.sqOut, ps.capCur = boundIn[k];
+        }
+        sg.passbuf = ps.passbuf;
         sg.passbufB = ps.pp.estimator == HR_ESTIMATOR_ALL_LIGHTS ? ps.passbufB : nullptr;
         // The per-stage counters are a ring: a chain of pass-through rays (stacked single-sided sheets seen from behind, alpha holes:
         // physicallyBased.rlsl:70-108 re-emits without a depth bound) can outlive any fixed number of stages, so from stage
@@ -1899,14 +2062,17 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         sg.sCountIn = st > 0 ? &ps.ctr->sCount[(st - 1) % R] : c->dZero;
         sg.qCountOut = &ps.ctr->qCount[(st + 1) % R];
         sg.sCountOut = &ps.ctr->sCount[st % R];
-        sg.hitIdx = ps.hitIdx, sg.pCount = &ps.ctr->pCount[st % R], sg.gCount = &ps.ctr->gCount[st % R];
-        sg.hitCap = (uint32_t)(c->queueCapacity ? c->queueCapacity : 1), sg.pad2 = 0;
+        sg.pCount = &ps.ctr->pCount[st % R], sg.gCount = &ps.ctr->gCount[st % R];
+        sg.hitCap = boundIn[k] ? boundIn[k] : 1u, sg.pad2 = 0;
         sg.pp = ps.pp;
-        sg.closestEnabled = (c->hasPassthrough || st < ps.nIter) ? 1 : 0;
+        sg.closestEnabled = closest ? 1 : 0;
+        G.countSlot[ring][k] = order[k], G.countOrder[ring][k] = ps.order + 1ull;
         for (int j = 0; j < nInjected; ++j)
             if (order[k] == injectedSlots[j]) injectedSegs[nInjectedSegs++] = k;
     }
     if (nInjectedSegs > 0) tbl.primaryFromSeg = injectedSegs[0]; // (the table is in pass order: the passes injected now are its last entries)
+    G.countN[ring] = n;
+    tbl.hostCounts = G.dCounts + (size_t)ring * kMaxSegs, tbl.hostSeq = G.dSeq + ring, tbl.seqValue = stepIdx + 1ull;
     StepTable *dTbl = G.dTables + ring;
     const size_t tblBytes = offsetof(StepTable, seg) + (size_t)n * sizeof(SegDev);
     HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, tblBytes, hipMemcpyHostToDevice, G.stream));

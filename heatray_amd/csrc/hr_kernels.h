@@ -38,7 +38,8 @@ struct LaunchCfg {
 struct SegDev {
     RayQueue qin;        // closest-hit rays traced and shaded this step
     RayQueue qout;       // closest-hit rays emitted for the next step
-    ShadowQueue sq;      // occlusion rays: traced this step (emitted by the previous step's shade), then refilled by this step's shade
+    ShadowQueue sqIn;    // occlusion rays traced this step (emitted by the previous step's shade)
+    ShadowQueue sqOut;   // occlusion rays this step's shade emits (traced by the next step)
     HitRec *hits;        // closest-hit records of qin
     float *passbuf;      // RGBA32F sample of this pass (full-frame indexing)
     float *passbufB;     // HR_ESTIMATOR_ALL_LIGHTS: the sample's second partial sum (analytic-light contributions), or null
@@ -74,6 +75,11 @@ struct StepTable {
     int32_t primaryFromSeg;  // passes [primaryFromSeg, nSeg) were injected this step: their closest-hit queues hold camera rays
     int32_t fetchMaxPrimary; // chunk size of the work fetch inside that (coherent) part of the index space: low 16 bits; high 16 bits: how many such chunks per resident wave the part must hold for it to be used
     uint32_t headsLog2;      // 2^headsLog2 ranges are in use (HR_TUNE heads=)
+    // k_trace's first workgroup reports the closest-hit queue length of every entry to pinned HOST memory when it starts, then the
+    // step's number (hr_core.hip, Group::hCounts): how the host sizes the next steps' queues without a packet on the stream
+    uint32_t *hostCounts;
+    unsigned long long *hostSeq;
+    unsigned long long seqValue;
     // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
     // kTraceHeadsMax), each with a cursor on a cache line of its own — none of them shares its 128-byte line with the header above
     // or with seg[] below, which every wave reads while the cursors are hammered by atomics.  ONE cursor serialises at ~12 ns per atomic:

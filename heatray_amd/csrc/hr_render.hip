@@ -296,6 +296,19 @@ static const unsigned long long kNoHitKey = ~0ull;
 __device__ unsigned long long g_tailprof[24]; // [0] min start clock, [1] min exhaustion clock, [2] max end clock, [3] max steps of a ray, [4] sum steps, [5] rays
 #endif
 
+// The host's view of the queue lengths (StepTable::hostCounts): the launch's first workgroup stores the closest-hit queue length of every
+// table entry to pinned host memory (system scope), then the step's number.  Not inlined: k_trace sits exactly at the register count that
+// gives five waves per SIMD, and this prologue must not move it (inlined it cost 4 VGPRs: four waves, -4.5 %).
+__device__ __attribute__((noinline)) void reportQueueLengths(const StepTable *tbl, const uint32_t *segStart)
+{
+    if (!tbl->hostCounts) return;
+    for (int k = (int)threadIdx.x; k < tbl->nSeg; k += kTraceBlock)
+        __hip_atomic_store(&tbl->hostCounts[k], segStart[2 * k + 1] - segStart[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(tbl->hostSeq, tbl->seqValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <bool STATS>
 __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
                                                   StepTable *__restrict__ tbl, Stats *stats)
@@ -312,6 +325,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     const unsigned long long clk0 = wall_clock64();
     buildSegStarts(tbl, segStart, false);
     const int nSeg2 = 2 * tbl->nSeg;
+    if (blockIdx.x == 0) reportQueueLengths(tbl, segStart);
     const uint32_t total = segStart[nSeg2];
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
     int *stackLane = &stack[wave][0][lane];
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     const SegDev &sg = tbl->seg[sI >> 1];
                     float4 a, b;
                     if (sI & 1) { // occlusion ray
-                        a = G(sg.sq.A)[local], b = G(sg.sq.B)[local];
+                        a = G(sg.sqIn.A)[local], b = G(sg.sqIn.B)[local];
                         skipPrim = __float_as_uint(b.w);
                     } else {
                         a = G(sg.qin.A)[local], b = G(sg.qin.B)[local];
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                 const SegDev &sg = tbl->seg[segIdx >> 1];
                 if (isAny) {
                     if (k == kNoHitKey) {
-                        const float4 c = G(sg.sq.C)[local];
+                        const float4 c = G(sg.sqIn.C)[local];
                         HR_GLOBAL float *px = G(sg.passbuf) + (size_t)__float_as_uint(c.w) * 4;
                         px[0] = px[0] + c.x;
                         px[1] = px[1] + c.y;
@@ -686,7 +700,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
             const SegDev &sg = tbl->seg[segIdx >> 1];
             if (isAny) {
                 if (best.prim == kMissPrim) { // unoccluded: the light's shader accumulates into the pass's sample
-                    const float4 c = G(sg.sq.C)[local];
+                    const float4 c = G(sg.sqIn.C)[local];
                     HR_GLOBAL float *px = G(sg.passbuf) + (size_t)__float_as_uint(c.w) * 4;
                     px[0] = px[0] + c.x;
                     px[1] = px[1] + c.y;
@@ -960,9 +974,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
             const bool wantS = live && nee.valid;
             const uint32_t sSlot = blockReserve(wantS, sg.sCountOut, scratch);
             if (wantS) {
-                G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
-                G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-                G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+                G(sg.sqOut.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                G(sg.sqOut.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
+                G(sg.sqOut.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
             }
             if (ALL) {
                 // each extra ray adds to a partial sum of its own (no two rays of a launch may write one pixel): partial sum j + 1 lies
@@ -973,9 +987,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                     const bool wantX = live && extra[j].valid;
                     const uint32_t sx = blockReserve(wantX, sg.sCountOut, scratch);
                     if (wantX) {
-                        G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
-                        G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
-                        G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
+                        G(sg.sqOut.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
+                        G(sg.sqOut.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
+                        G(sg.sqOut.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
                     }
                 }
             }
@@ -992,9 +1006,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                 const bool wantS = mine && nee.valid;
                 const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
                 if (wantS) {
-                    G(sg.sq.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
-                    G(sg.sq.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-                    G(sg.sq.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+                    G(sg.sqOut.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                    G(sg.sqOut.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
+                    G(sg.sqOut.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
                 }
                 if (ALL) {
                     const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);
@@ -1003,9 +1017,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                         const bool wantX = mine && extra[j].valid;
                         const uint32_t sx = waveReserve(wantX, sg.sCountOut);
                         if (wantX) {
-                            G(sg.sq.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
-                            G(sg.sq.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
-                            G(sg.sq.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
+                            G(sg.sqOut.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
+                            G(sg.sqOut.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
+                            G(sg.sqOut.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
                         }
                     }
                 }
