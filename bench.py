@@ -491,23 +491,8 @@ def main():
     # ahead: in the timed loop the host only hands them over, as the reference's host does
     pass_blocks = [sc.options.pass_params(i) for i in range(passes_total)]
 
-    # SURVEY 8d metric 1 asks for min / median per pass beside the mean.  Passes complete a batch at a time (the pipeline keeps depth + 2
-    # stages in flight), so the unit that can be timed is the batch: whenever the library has enqueued the resolve of further passes on
-    # the ctx stream (hr_frame_passes_resolved: a host-side counter), an event is recorded behind it on that stream; consecutive events
-    # give (passes, milliseconds) per batch.
-    marks = []
-
-    def mark():
-        n = eng.passes_resolved()
-        if not marks or n > marks[-1][0]:
-            ev = torch.cuda.Event(enable_timing=True)
-            ev.record()
-            marks.append((n, ev))
-
     def step(i):
         eng.render_pass(pass_blocks[i])
-        if timing_marks:
-            mark()
         if exchange and (i + 1) % post_every == 0:
             # Progressive display: every step each rank packs the pixels it owns (1/world of the RGBA32F buffer) and
             # RCCL gathers them on rank 0, on a side stream so the exchange overlaps the next pass's kernels.  The
@@ -531,7 +516,6 @@ def main():
             torch.cuda.synchronize()
     wake_s = time.perf_counter() - t_wake
     eng.clear()
-    timing_marks = False
     for i in range(args.warmup):
         step(i)
     eng.clear()  # resets the accumulation buffer, the device counters and the kernel timers
@@ -539,13 +523,10 @@ def main():
     if exchange:
         dist.barrier()
     torch.cuda.synchronize()
-    timing_marks = True
     t0 = time.perf_counter()
-    mark()  # (0 passes: the start of the timed region on the stream)
     for i in range(args.steps):
         step(args.warmup + i)
     eng.flush()  # the pass pipeline keeps depth+2 passes in flight: enqueue their remaining stages
-    mark()
     full = fb
     if exchange:
         gatherer.post(fb)  # the finished image
@@ -581,18 +562,23 @@ def main():
         import hashlib
         frame_host = full.cpu().numpy()
         frame_sha256 = None if emulated else hashlib.sha256(frame_host.tobytes()).hexdigest()
-        # per-batch completion times (marks above): ms per pass of every batch that completed inside the timed region
-        per_batch = []
-        for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
-            if n1 > n0:
-                per_batch.append(e0.elapsed_time(e1) / (n1 - n0))
+        # SURVEY 8d metric 1 asks for min / median per pass beside the mean.  The renderer is a pipeline: a macro step advances every
+        # in-flight pass by one stage, and a step in which the pipeline is FULL (stages x batch passes in flight) does one pass's worth
+        # of work per pass it injects.  libhrcore logs every step's k_trace launch by the device clock (hr_get_step_log): the period
+        # between consecutive full steps / passes injected = time per pass in steady state; a run shorter than two pipeline depths
+        # has no such steps (the driver's 20 passes: fill and drain only) and reports null with the step log's summary.
+        log = eng.step_log()
         batch_stats = None
-        if per_batch:
-            srt = sorted(per_batch)
-            batch_stats = {"min": srt[0], "median": float(np.median(srt)), "max": srt[-1], "batches": len(srt),
-                           "passes_per_batch": [int(b[0] - a[0]) for a, b in zip(marks[:-1], marks[1:]) if b[0] > a[0]],
-                           "definition": "device time between the resolves of consecutive batches of passes (events on the ctx stream) / passes in the "
-                                         "batch; the first batch includes the pipeline's fill, the last ones its drain"}
+        if log:
+            full = max(r[2] for r in log)
+            per_pass = [(log[i + 1][0] - log[i][0]) / log[i][3] for i in range(len(log) - 1) if log[i][2] == full and log[i][3] > 0 and log[i + 1][2] == full]
+            tr = sorted(r[1] for r in log)
+            batch_stats = {"macro_steps": len(log), "passes_in_flight_max": full, "steady_state_steps": len(per_pass),
+                           "k_trace_launch_ms": {"min": tr[0], "median": float(np.median(tr)), "max": tr[-1]},
+                           "min": min(per_pass) if len(per_pass) >= 2 else None, "median": float(np.median(per_pass)) if len(per_pass) >= 2 else None,
+                           "max": max(per_pass) if len(per_pass) >= 2 else None,
+                           "definition": "period between consecutive macro steps with a full pipeline / passes injected per step (device clock, hr_get_step_log); "
+                                         "null when the timed region holds fewer than two such steps (it is then fill and drain only)"}
         # ---- parity of the timed region's own output against the CPU oracle (every N; rank 0 holds the assembled frame)
         parity = None
         if args.parity_seconds > 0 and not emulated and not args.pmc_child:
@@ -789,7 +775,7 @@ def main():
             "wakeup_passes": n_wake, "wakeup_s": wake_s,
             "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_min": batch_stats["min"] if batch_stats else None, "ms_per_step_median": batch_stats["median"] if batch_stats else None,
-            "ms_per_step_batches": batch_stats,
+            "ms_per_step_steady_state": batch_stats,
             "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {WORKLOADS[args.workload]['desc']}", "width": sc.width, "height": sc.height,

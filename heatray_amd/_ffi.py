@@ -117,6 +117,10 @@ class PassStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class StepRecord(C.Structure):
+    _fields_ = [("start_ms", C.c_double), ("trace_ms", C.c_float), ("passes_in_flight", C.c_int32), ("passes_injected", C.c_int32), ("reserved", C.c_int32)]
+
+
 class KernelTimes(C.Structure):
     _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4), ("trace_clock_ms", C.c_float), ("trace_clock_launches", C.c_uint32)]
 
@@ -154,7 +158,7 @@ ABI_SYMBOLS = [
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
-    "display", "display_readback", "frame_passes_resolved", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
+    "display", "display_readback", "frame_passes_resolved", "get_step_log", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
     "frame_pass_batch", "interactive_blocks_set", "scene_cache",
 ]
 
@@ -375,6 +379,13 @@ class Engine:
         d = {n: (t.ms[i], t.launches[i]) for i, n in enumerate(HR_KERNEL_NAMES)}
         d["trace_clock"] = (t.trace_clock_ms, t.trace_clock_launches)
         return d
+
+    def step_log(self, capacity=4096):
+        """[(start_ms, trace_ms, passes_in_flight, passes_injected)] of the macro steps since the last clear (newest 4096)."""
+        recs = (StepRecord * capacity)()
+        n = C.c_int32()
+        self._call("get_step_log", recs, C.c_int32(capacity), C.byref(n))
+        return [(r.start_ms, r.trace_ms, r.passes_in_flight, r.passes_injected) for r in recs[: n.value]]
 
     def synchronize(self):
         self._call("synchronize")

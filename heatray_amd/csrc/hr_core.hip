@@ -182,6 +182,7 @@ struct hr_ctx {
     unsigned long long injected = 0;
     uint32_t *dZero = nullptr;    // a zero word (occlusion count of a pass's first step)
     Counters *dCounters = nullptr; // one per pass slot, contiguous (copied to the host in one piece in pass-through scenes)
+    unsigned long long *dStepLog = nullptr; // kStepLogCap records of three words (StepTable::stepLog)
 
     // Mesh blocks come out of an arena of 64 MB chunks (bump allocation inside a chunk): a hipMalloc per submesh is a device-wide
     // synchronisation of ~0.1 ms each, which adds up for the scenes the reference loads (hundreds of submeshes).  A chunk whose last
@@ -587,7 +588,8 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
     }
     if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
         hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, sizeof(uint32_t) * 6 * kBoundSlots) != hipSuccess ||
-        hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters) * kMaxSlots) != hipSuccess) {
+        hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters) * kMaxSlots) != hipSuccess ||
+        hipMalloc(&c->dStepLog, sizeof(unsigned long long) * 3 * kStepLogCap) != hipSuccess) {
         delete c;
         return HR_ERR_DEVICE;
     }
@@ -627,7 +629,7 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
     hipFree(c->dTexDensity);
     for (Texture &t : c->textures) hipFree(t.dmips);
-    hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dCounters);
+    hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dCounters), hipFree(c->dStepLog);
     for (hr_ctx::Group &G : c->groups) {
         if (G.hQCount) hipHostFree(G.hQCount);
         if (G.hCounts) hipHostFree(G.hCounts);
@@ -2073,6 +2075,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     if (nInjectedSegs > 0) tbl.primaryFromSeg = injectedSegs[0]; // (the table is in pass order: the passes injected now are its last entries)
     G.countN[ring] = n;
     tbl.hostCounts = G.dCounts + (size_t)ring * kMaxSegs, tbl.hostSeq = G.dSeq + ring, tbl.seqValue = stepIdx + 1ull;
+    tbl.stepLog = c->dStepLog, tbl.nInjectedNow = (uint32_t)nInjected, tbl.padL = 0;
     StepTable *dTbl = G.dTables + ring;
     const size_t tblBytes = offsetof(StepTable, seg) + (size_t)n * sizeof(SegDev);
     HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, tblBytes, hipMemcpyHostToDevice, G.stream));
@@ -2324,6 +2327,35 @@ int hr_get_kernel_times(hr_ctx *c, hr_kernel_times *out)
     for (const Stats &p : parts) ticks += p.traceTicks, launches += p.traceLaunches;
     out->trace_clock_ms = (float)((double)ticks * 1e-5); // 100 MHz: 10 ns per tick
     out->trace_clock_launches = (uint32_t)launches;
+    return HR_OK;
+}
+
+int hr_get_step_log(hr_ctx *c, hr_step_record *out, int32_t capacity, int32_t *n_records)
+{
+    ENTER(c);
+    if (!out || !n_records || capacity <= 0) FAIL(c, HR_ERR_INVALID, "bad arguments");
+    {
+        int rc = drainPipeline(c);
+        if (rc) return rc;
+    }
+    std::vector<Stats> parts(1);
+    std::vector<unsigned long long> log(3 * (size_t)kStepLogCap);
+    HIP_TRY(c, hipMemcpyAsync(parts.data(), c->dStats, sizeof(Stats), hipMemcpyDeviceToHost, c->stream)); // (k_shade_sort's first thread counts in the first copy)
+    HIP_TRY(c, hipMemcpyAsync(log.data(), c->dStepLog, log.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const unsigned long long total = parts[0].traceLaunches;
+    const unsigned long long first = total > (unsigned long long)kStepLogCap ? total - (unsigned long long)kStepLogCap : 0ull;
+    int32_t n = 0;
+    unsigned long long t0 = 0;
+    for (unsigned long long i = first; i < total && n < capacity; ++i) {
+        const unsigned long long *rec = &log[3 * (size_t)(i % (unsigned long long)kStepLogCap)];
+        if (n == 0) t0 = rec[0];
+        out[n].start_ms = (double)(rec[0] - t0) * 1e-5; // 100 MHz device clock
+        out[n].trace_ms = (float)((double)(rec[1] - rec[0]) * 1e-5);
+        out[n].passes_in_flight = (int32_t)(uint32_t)rec[2], out[n].passes_injected = (int32_t)(rec[2] >> 32), out[n].reserved = 0;
+        ++n;
+    }
+    *n_records = n;
     return HR_OK;
 }
 

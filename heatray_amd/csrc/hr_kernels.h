@@ -62,6 +62,7 @@ struct SegDev {
 #endif
 static const int kMaxSegs = HR_MAX_SEGS;
 static const int kClkSlots = 16;
+static const int kStepLogCap = 4096; // macro steps the step log keeps (a ring)
 static const int kTraceHeadsMax = 64; // in-flight passes of one group: (passes injected per macro step) x (stages per pass)
 struct StepTable {
     // read-mostly header: every wave of every kernel of the step reads it once
@@ -80,6 +81,9 @@ struct StepTable {
     uint32_t *hostCounts;
     unsigned long long *hostSeq;
     unsigned long long seqValue;
+    // log of the k_trace launches since the last hr_clear (hr_get_step_log): k_shade_sort appends (first start, last end) by the device clock
+    unsigned long long *stepLog; // kStepLogCap x {start tick, end tick, passes in the table | passes injected << 32}
+    uint32_t nInjectedNow, padL;
     // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
     // kTraceHeadsMax), each with a cursor on a cache line of its own — none of them shares its 128-byte line with the header above
     // or with seg[] below, which every wave reads while the cursors are hammered by atomics.  ONE cursor serialises at ~12 ns per atomic:

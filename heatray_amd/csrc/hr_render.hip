@@ -848,7 +848,11 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
             lo = a < lo ? a : lo, hi = b > hi ? b : hi;
         }
         if (hi > lo) atomicAdd(&stats->traceTicks, hi - lo);
-        atomicAdd(&stats->traceLaunches, 1ull);
+        const unsigned long long idx = atomicAdd(&stats->traceLaunches, 1ull); // (this thread always adds to the first copy of the counters)
+        if (tbl->stepLog) {
+            unsigned long long *rec = tbl->stepLog + 3ull * (idx % (unsigned long long)kStepLogCap);
+            rec[0] = lo, rec[1] = hi, rec[2] = (unsigned long long)(uint32_t)nSeg | ((unsigned long long)tbl->nInjectedNow << 32);
+        }
     }
     buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? *tbl->seg[k].qCountIn : 0u; });
     const uint32_t total = start[nSeg];

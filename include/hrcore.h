@@ -397,6 +397,19 @@ typedef struct hr_kernel_times {
     uint32_t trace_clock_launches;
 } hr_kernel_times;
 
+/* One record per macro step of the pass pipeline since the last hr_clear (the newest 4096): when its k_trace launch started and how
+ * long it ran, by the device clock, how many passes were in flight in it and how many of them it injected.  A step in which the
+ * pipeline is full (passes_in_flight = stages x batch) does one pass's worth of work per injected pass: the period between such
+ * steps / passes_injected is the steady-state time per pass; the steps before and behind are the pipeline's fill and drain. */
+typedef struct hr_step_record {
+    double start_ms;   /* relative to the first record */
+    float trace_ms;
+    int32_t passes_in_flight;
+    int32_t passes_injected;
+    int32_t reserved;
+} hr_step_record;
+int hr_get_step_log(hr_ctx *ctx, hr_step_record *out, int32_t capacity, int32_t *n_records);
+
 /* Interactive 3x3 mode (perspective.rlsl:42-57): which pixel of a block is sampled in a sub-pass is looked up in a small table,
  * the reference's interactiveBlockSamplesTexture (PassGenerator.cpp:267-294: the nx x ny list of (row, col) pairs, shuffled
  * with std::random_device, uploaded as an RL_NEAREST / RL_REPEAT RGB texture).  coords_xy holds nx*ny integer pairs in the

@@ -390,6 +390,12 @@ int ora_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t f
     if (h) *h = ctx->c.H;
     return HR_OK;
 }
+int ora_get_step_log(hr_ctx *ctx, hr_step_record *, int32_t, int32_t *n)
+{
+    if (!n) ORA_FAIL(ctx, HR_ERR_INVALID, "null output");
+    *n = 0; // the oracle has no pipeline
+    return HR_OK;
+}
 int ora_frame_passes_resolved(hr_ctx *ctx, uint64_t *passes)
 {
     if (!passes) ORA_FAIL(ctx, HR_ERR_INVALID, "null output");

@@ -52,6 +52,7 @@ int hr_readback_progressive(hr_ctx *c, const float **rgba, int32_t *w, int32_t *
 int hr_synchronize(hr_ctx *) { return HR_OK; }
 int hr_display(hr_ctx *, const hr_display_params *, int32_t, void *, uint32_t *) { return HR_OK; }
 int hr_frame_passes_resolved(hr_ctx *, uint64_t *n) { if (n) *n = 0; return HR_OK; }
+int hr_get_step_log(hr_ctx *, hr_step_record *, int32_t, int32_t *n) { if (n) *n = 0; return HR_OK; }
 int hr_display_readback(hr_ctx *c, const hr_display_params *, int32_t, const void **px, int32_t *w, int32_t *h, uint32_t *) { *px = c->frame.data(); if (w) *w = c->w; if (h) *h = c->h; return HR_OK; }
 int hr_frame_packed_slots(hr_ctx *, int32_t, int32_t, uint64_t *n) { *n = 0; return HR_OK; }
 int hr_frame_pack_owned(hr_ctx *, void *, void *) { return HR_OK; }
