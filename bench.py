@@ -475,16 +475,17 @@ def main():
     # 20-pass run, profiles/r4e_shard_ab.txt), so with N > 1 k_trace is timed by the device clock it reads itself (always on;
     # the N = 1 line carries both, they agree).  HR_BENCH_TIME_KERNELS=0/1 forces either.
     time_kernels = os.environ.get("HR_BENCH_TIME_KERNELS", "1" if (world == 1 and not emulated) else "0") != "0"
-    eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, time_kernels=time_kernels)
+    TILE = int(os.environ.get("HR_BENCH_TILE", "32"))  # (tile size experiments; SURVEY 8e: 32)
+    eng = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=TILE, stream=stream, time_kernels=time_kernels)
     sc.apply(eng)  # tables and LUT are generated on the device
     info = eng.scene_info()
     fb = torch.zeros((sc.height, sc.width, 4), dtype=torch.float32, device=dev)
     eng.bind_external_frame(fb.data_ptr())
-    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=32, dst=0, n_buffers=3, engine=eng, host_staged=one_device) if exchange else None
+    gatherer = tiles.FrameGatherer(sc.width, sc.height, rank, world, dev, tile=TILE, dst=0, n_buffers=3, engine=eng, host_staged=one_device) if exchange else None
 
     # libhrcore injects (and therefore resolves) passes in batches (hr_frame_pass_batch): the accumulation buffer changes once per
     # batch, so that is the exchange cadence as well.
-    owned_px = len(tiles.owned_tiles(sc.width, sc.height, eng_rank, eng_world)) * 32 * 32
+    owned_px = len(tiles.owned_tiles(sc.width, sc.height, eng_rank, eng_world, TILE)) * TILE * TILE
     post_every = max(1, eng.pass_batch(sc.options.max_ray_depth))
 
     # the per-pass uniform blocks (what PassGenerator::runRenderFrameJob fills in C++, PassGenerator.cpp:349-369) are prepared
@@ -554,7 +555,7 @@ def main():
         # sanity of the timed result itself: every owned pixel got exactly `steps` samples
         a = full[..., 3]
         if emulated:
-            a = a[torch.from_numpy(tiles.owner_map(sc.width, sc.height, eng_world) == eng_rank).to(dev)]
+            a = a[torch.from_numpy(tiles.owner_map(sc.width, sc.height, eng_world, TILE) == eng_rank).to(dev)]
         assert bool((a == float(args.steps)).all()), "sample count mismatch in the accumulation buffer"
         assert bool(torch.isfinite(full).all())
         # digest of the final assembled RGBA32F frame: the same passes give the same bits for every N (SURVEY 8e acceptance:
@@ -595,7 +596,7 @@ def main():
         # ---- the product's own traversal counters (4-wide quantised BVH), one extra counted pass outside the timed region
         gpu_counts = None
         if not args.no_stats_pass:
-            se = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=32, stream=stream, collect_stats=True)
+            se = core.create_engine(device_id=local_rank, rank=eng_rank, world=eng_world, tile_size=TILE, stream=stream, collect_stats=True)
             sc.apply(se)
             se.render_pass(sc.options.pass_params(args.warmup))
             ss = se.stats()

@@ -1,0 +1,42 @@
+#!/bin/bash
+# tools/r4_final.sh {a|b|c} — ON THE GPU BOX: the measurement set of round 4's final state -> gpurun_out/r4z_*
+ROOT="$PWD"; cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
+part="$1"
+if [ "$part" = a ]; then
+  python3 -m pytest tests -m gpu -q > gpurun_out/r4z_gpu_tests.log 2>&1; tail -2 gpurun_out/r4z_gpu_tests.log
+  (time python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4z_bench_driver_style.json 2> gpurun_out/r4z_bench_driver_style.err) 2> gpurun_out/r4z_driver_time.txt
+  echo "driver-style done"; tail -c 400 gpurun_out/r4z_bench_driver_style.json
+  python3 bench.py > gpurun_out/r4z_bench_default.json 2> gpurun_out/r4z_bench_default.err
+  echo "default done"
+fi
+if [ "$part" = b ]; then
+  python3 bench.py --quick --steps 16 > /dev/null 2>&1
+  for cfg in "r4z:--steps 20 --warmup 5" "r4z128:--steps 128" "r4_c3d:--workload c3d --steps 20 --warmup 5" "r4_terrain:--workload terrain --steps 20 --warmup 5"; do
+    tag="${cfg%%:*}"; args="${cfg#*:}"
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "gpurun_out/prof_$tag" -o t --output-format csv -- python3 bench.py --quick --no-wakeup $args > "gpurun_out/${tag}_bench_under_rocprof.json" 2> "gpurun_out/${tag}_rocprof.err" || { echo "rocprof $tag failed"; tail -3 "gpurun_out/${tag}_rocprof.err"; }
+    s=$(find "gpurun_out/prof_$tag" -name '*kernel_stats.csv' | head -1); [ -n "$s" ] && cp "$s" "gpurun_out/${tag}_kernel_stats.csv"
+    rm -rf "gpurun_out/prof_$tag"
+    HR_BENCH_TIME_KERNELS=1 python3 bench.py --quick $args > "gpurun_out/${tag}_bench_plain.json" 2>/dev/null
+    echo "profile $tag done"
+  done
+  python3 bench.py --workload c3d --steps 20 --warmup 5 --no-converge > gpurun_out/r4_c3d_bench.json 2> gpurun_out/r4_c3d_bench.err; echo "c3d line done"
+  python3 bench.py --workload terrain --steps 20 --warmup 5 --no-converge > gpurun_out/r4_terrain_bench.json 2> gpurun_out/r4_terrain_bench.err; echo "terrain line done"
+fi
+if [ "$part" = c ]; then
+  for wl in c1 c2 c2p c3 c3d c5 terrain; do
+    for st in 20 128; do
+      HR_BENCH_TIME_KERNELS=1 python3 bench.py --quick --workload $wl --steps $st $( [ $st = 20 ] && echo "--warmup 5" ) > gpurun_out/wl.json 2>/dev/null && python3 - $wl $st <<'PY'
+import json, sys
+d = json.load(open("gpurun_out/wl.json")); k = d["extra"]["kernel_ms_rank0"]; n = d["extra"]["kernel_launches_rank0"]
+print(f"{sys.argv[1]:8s} {sys.argv[2]:>4s} steps: {d['value']:8.1f} Mrays/s  {d['ms_per_step']:.3f} ms/step  {d['extra']['paths_per_s']/1e6:8.1f} Mpaths/s  rays/path {d['extra']['rays_per_path']:.2f}  trace {k['trace']/max(n['trace'],1):.3f} ms x{n['trace']}  shade {k['shade']/max(n['shade'],1):.3f}")
+PY
+    done
+  done > gpurun_out/r4z_workloads.txt 2>&1
+  cat gpurun_out/r4z_workloads.txt
+  { bash tools/r4_shard_ratio.sh 20; bash tools/r4_shard_ratio.sh 128; } > gpurun_out/r4_shards.txt 2>&1; grep "ratio\|N=1" gpurun_out/r4_shards.txt
+  for w in 2 4; do for st in 20 128; do echo "== W=$w steps=$st"; tools/shards.sh $w $st "" | tail -1; done; done >> gpurun_out/r4_shards.txt 2>&1
+  python3 tools/commit_time.py 2>&1 | tail -1 > gpurun_out/r4z_commit_time.json
+  python3 tools/tree_costs.py 2>&1 | grep -v amdgpu > gpurun_out/r4z_tree_costs.txt
+  { HR_FUZZ_SEEDS=600 timeout -k 10 500 python3 -m pytest tests/test_gpu_fuzz.py -m gpu -q 2>&1 | tail -2; echo "HR_FUZZ_SEEDS=600 python -m pytest tests/test_gpu_fuzz.py -m gpu"; timeout -k 10 200 python3 tools/leak_check.py 2>&1 | tail -2; } > gpurun_out/r4z_fuzz_leak.txt 2>&1
+  cat gpurun_out/r4z_fuzz_leak.txt
+fi
