@@ -501,20 +501,18 @@ def main():
             # buffers), so any point of the stream gives a consistent progressive image.
             gatherer.post(fb)
 
-    # Untimed device wake-up before the W warm-up steps: the first GPU process on a freshly started box runs 1.4-2.5 x slower
-    # for its first few hundred milliseconds (measured: 1131 vs 1560 Mrays/s on the first run after boot; clocks ramping and the
-    # first touch of ~10 GB of pass slots), which the 2-step warm-up of the contract does not absorb.
+    # Untimed wake-up before the W warm-up steps: ONE FILL OF THE PASS PIPELINE — (depth + 2) stages x `post_every` passes per macro step,
+    # plus one batch — so that the library's ray arenas have reached their steady-state size (they grow on demand while the pipeline
+    # fills: each step carries one more generation of passes; hr_core.hip, Group::arena) and the clocks are up.  132 passes (0.26 s)
+    # for c3; rounds 2-3 ran 512 passes / 1 s here to touch 53 GB of per-slot queues.  HR_BENCH_WAKE_MAX overrides.
     t_wake = time.perf_counter()
     n_wake = 0
-    # (round 4: 64 passes — 0.17 s — measure the same as the 512 of rounds 2-3, also as the first GPU process of a fresh box:
-    # profiles/r4l_wakeup.txt; HR_BENCH_WAKE_MAX overrides)
-    wake_cap = int(os.environ.get("HR_BENCH_WAKE_MAX", "64"))
+    wake_cap = int(os.environ.get("HR_BENCH_WAKE_MAX", str(max(64, (sc.options.max_ray_depth + 3) * post_every))))
     while not args.no_wakeup and n_wake < wake_cap:
         eng.render_pass(sc.options.pass_params(n_wake % passes_total))
         n_wake += 1
-        if n_wake % 32 == 0:
-            eng.flush()
-            torch.cuda.synchronize()
+    eng.flush()
+    torch.cuda.synchronize()
     wake_s = time.perf_counter() - t_wake
     eng.clear()
     for i in range(args.warmup):

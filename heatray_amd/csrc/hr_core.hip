@@ -1765,12 +1765,15 @@ static int ensureRegion(hr_ctx *c, hr_ctx::Group &G, hr_ctx::Group::Region &r, s
     c->dbgGrowths++, c->dbgGrowBytes += need;
     if (getenv("HR_DEBUG_PIPE")) fprintf(stderr, "  grow %s: need %.1f MiB, had %.1f MiB (step %llu)\n", what, (double)need / 1048576.0, (double)r.cap / 1048576.0, G.stepCounter);
     HIP_TRY(c, hipStreamSynchronize(G.stream));
+    const size_t hadCap = r.cap;
     hipFree(r.base);
     r.base = nullptr, r.cap = 0;
     // a third of headroom: counts vary from pass to pass, and while the pipeline fills (the first depth + 2 steps of a render) every
     // step carries one more generation of passes — for the benchmark soup the steady state needs 27 % more than the step that
     // triggered the last growth (profiles/r4m_mem.txt); a step that needs more regrows once more
-    const size_t want = (need + need / 3 + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
+    size_t want = need + need / 3;
+    if (hadCap && want < hadCap + hadCap / 2) want = hadCap + hadCap / 2; // (a region that has to grow again grows by half at least: few events)
+    want = (want + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
     hipError_t e = hipMalloc((void **)&r.base, want);
     size_t got = want;
     if (e != hipSuccess) {
