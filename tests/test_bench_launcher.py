@@ -75,3 +75,20 @@ def test_two_rank_rehearsal_on_one_device():
     assert ss["macro_steps"] >= 3 and ss["k_trace_launch_ms"]["min"] > 0
     if ss["steady_state_steps"] >= 2:
         assert d1["ms_per_step_min"] <= d1["ms_per_step_median"] <= ss["max"]
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_path_with_one_rank():
+    # The real collective library on the real device, as far as one GPU allows: HR_BENCH_FORCE_EXCHANGE=1 runs the N > 1 code path — an
+    # "nccl" (= RCCL) process group, hr_frame_pack_owned -> dist.gather on a side stream after every resolved batch, hr_frame_unpack,
+    # the final assembly — in a single rank.  Same passes => the same digest as the plain run, and the oracle's frame.
+    args = ["--quick", "--parity-seconds", "30", "--steps", "70", "--warmup", "1", "--workload", "c2", "--width", "512", "--height", "288"]
+    r = _run(["--gpus", "1"] + args, env={"HR_BENCH_FORCE_EXCHANGE": "1"}, timeout=900)
+    assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+    d = json.loads(_json_lines(r.stdout)[0])
+    assert "RCCL gather" in d["config"]["sharding"]
+    r1 = _run(["--gpus", "1"] + args, timeout=900)
+    assert r1.returncode == 0, r1.stderr.decode(errors="replace")[-3000:]
+    d1 = json.loads(_json_lines(r1.stdout)[0])
+    assert d["frame_sha256"] == d1["frame_sha256"]
+    assert d["parity"]["bit_exact"] is True and d["parity"]["pixels"] == 512 * 288
