@@ -848,6 +848,88 @@ __global__ __launch_bounds__(256) void k_ploc_init(const Box6 *__restrict__ leaf
     box[i] = leafBox[i];
 }
 
+// The last iterations in ONE workgroup: once at most kPlocTail clusters are left they live in LDS and the remaining ~20 iterations (each
+// of which was five launches and a 4-byte read-back) run without leaving the kernel.  Same nearest-neighbour rule, same pair rule, same
+// order of the new nodes (array order) as the iterations above, so the tree does not depend on where the hand-over happens.
+static const int kPlocTail = 1024;
+__global__ __launch_bounds__(kPlocTail) void k_ploc_tail(uint32_t *__restrict__ state, const int *__restrict__ refIn, const Box6 *__restrict__ boxIn, int r,
+                                                        KNode *__restrict__ knodes, Box6 *__restrict__ nodeBox, float4 *cost /* read back inside the launch: no restrict */)
+{
+    __shared__ Box6 sbox[2][kPlocTail];
+    __shared__ int sref[2][kPlocTail];
+    __shared__ int snn[kPlocTail];
+    __shared__ uint32_t wk[kPlocTail / 64], wm[kPlocTail / 64];
+    const int t = (int)threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    int m = (int)state[0];
+    uint32_t base = state[1];
+    if (t < m) sbox[0][t] = boxIn[t], sref[0][t] = refIn[t];
+    __syncthreads();
+    int cur = 0;
+    while (m > 1) {
+        // nearest neighbour (k_ploc_nn's rule)
+        int bestJ = -1;
+        if (t < m) {
+            const Box6 me = sbox[cur][t];
+            float best = __builtin_inff();
+            for (int off = -r; off <= r; ++off) {
+                const int j = t + off;
+                if (off == 0 || j < 0 || j >= m) continue;
+                const float a = unionArea(me, sbox[cur][j]);
+                bool better = bestJ < 0 || a < best;
+                if (!better && a == best) {
+                    const int d1 = off < 0 ? -off : off, d0 = bestJ > t ? bestJ - t : t - bestJ;
+                    const int lo1 = t < j ? t : j, lo0 = t < bestJ ? t : bestJ;
+                    better = d1 < d0 || (d1 == d0 && ((lo1 & 1) < (lo0 & 1) || ((lo1 & 1) == (lo0 & 1) && lo1 < lo0)));
+                }
+                if (better) best = a, bestJ = j;
+            }
+            snn[t] = bestJ;
+        }
+        __syncthreads();
+        bool keep = false, makes = false;
+        int j = 0;
+        if (t < m) {
+            j = snn[t];
+            const bool mutual = j >= 0 && j < m && snn[j] == t;
+            keep = !(mutual && j < t);
+            makes = mutual && t < j;
+        }
+        const unsigned long long kb = __ballot(keep), mb = __ballot(makes);
+        if (lane == 0) wk[wave] = (uint32_t)__popcll(kb), wm[wave] = (uint32_t)__popcll(mb);
+        __syncthreads();
+        uint32_t kBefore = 0, mBefore = 0, kTotal = 0, mTotal = 0;
+        for (uint32_t w = 0; w < (uint32_t)(kPlocTail / 64); ++w) {
+            kBefore += w < wave ? wk[w] : 0u, mBefore += w < wave ? wm[w] : 0u;
+            kTotal += wk[w], mTotal += wm[w];
+        }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const uint32_t pos = kBefore + (uint32_t)__popcll(kb & lt);
+        if (makes) {
+            const uint32_t id = base + mBefore + (uint32_t)__popcll(mb & lt);
+            const Box6 a = sbox[cur][t], b = sbox[cur][j];
+            Box6 u;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) u.lo[c] = fmin_(a.lo[c], b.lo[c]), u.hi[c] = fmax_(a.hi[c], b.hi[c]);
+            KNode k;
+            k.left = sref[cur][t], k.right = sref[cur][j], k.first = 0, k.last = 0;
+            knodes[id] = k;
+            nodeBox[id] = u;
+            // (a child made earlier in THIS launch was written by another thread: visible after the barrier below and the fence)
+            cost[id] = collapseCost(k.left, k.right, boxArea(u), cost);
+            sref[cur ^ 1][pos] = (int)id;
+            sbox[cur ^ 1][pos] = u;
+        } else if (keep) {
+            sref[cur ^ 1][pos] = sref[cur][t];
+            sbox[cur ^ 1][pos] = sbox[cur][t];
+        }
+        __threadfence();
+        __syncthreads();
+        m = (int)kTotal, base += mTotal, cur ^= 1;
+    }
+    if (t == 0) state[0] = (uint32_t)m, state[1] = base;
+}
+
 // Binary tree over the sorted triangles by PLOC: knodes / nodeBox / cost have n - 1 entries; *rootOut is the root's index (n - 2).
 // Returns 0, or non-zero when it did not finish (the caller then keeps the radix tree).
 static int buildPLOC(hipStream_t st, const Box6 *leafBox, uint32_t n, int radius, KNode *knodes, Box6 *nodeBox, float4 *cost, int *rootOut)
@@ -870,7 +952,7 @@ static int buildPLOC(hipStream_t st, const Box6 *leafBox, uint32_t n, int radius
         int cur = 0;
         // every iteration merges at least one pair (k_ploc_nn), typically a third of the clusters: ~45 iterations for a million
         // triangles.  The host reads the cluster count back after each (a 4-byte copy: the launches are sized by it).
-        for (uint32_t it = 0; m > 1; ++it) {
+        for (uint32_t it = 0; m > (uint32_t)kPlocTail; ++it) {
             if (it >= 4096u) { // (a pathological input that merges a pair at a time: not worth it, the radix tree is kept)
                 rc = 7;
                 break;
@@ -893,7 +975,7 @@ static int buildPLOC(hipStream_t st, const Box6 *leafBox, uint32_t n, int radius
             m = mNew;
             cur ^= 1;
         }
-        if (rc == 0 && m != 1) rc = 7;
+        if (rc == 0 && m > 1) hipLaunchKernelGGL(k_ploc_tail, dim3(1), dim3(kPlocTail), 0, st, state, ref[cur], box[cur], r, knodes, nodeBox, cost);
         uint32_t made = 0;
         if (rc == 0 && (hipMemcpyAsync(&made, state + 1, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = 1;
         if (rc == 0 && made != n - 1) rc = 7;

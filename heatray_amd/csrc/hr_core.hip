@@ -2020,7 +2020,19 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         G.arenaHighWater = needArena > G.arenaHighWater ? needArena : G.arenaHighWater;
         int rc = ensureRegion(c, G, arena, G.arenaHighWater, "rays emitted by a step");
         if (rc == HR_OK) rc = ensureRegion(c, G, G.scratch, needScratch, "camera rays and hit records of a step");
-        if (rc) return rc;
+        if (rc) {
+            // out of device memory: nothing of this step has been enqueued except the counters' reset.  The passes it was to inject go
+            // back to the head of the request queue (their slots are free again), so that a later call — after the caller has released
+            // memory — injects them properly instead of tracing queues no k_raygen ever filled.
+            for (int j = nInjected - 1; j >= 0; --j) {
+                hr_ctx::PassSlot &ps = c->slots[injectedSlots[j]];
+                c->pendingInject.push_front(ps.pp);
+                ps.active = false;
+                c->injected--;
+            }
+            G.stepCounter--;
+            return rc;
+        }
     }
     char *pArena = arena.base, *pScratch = G.scratch.base;
     StepTable &tbl = G.hTables[ring];
