@@ -397,7 +397,9 @@ typedef struct hr_kernel_times {
     uint32_t trace_clock_launches;
 } hr_kernel_times;
 
-/* One record per macro step of the pass pipeline since the last hr_clear (the newest 4096): when its k_trace launch started and how
+/* The pipeline's own timeline — what the reference shows as "pass time" in its UI (HeatrayRenderer.cpp:960, the passTime argument of
+ * PassCompleteCallback, PassGenerator.h:161) and OpenRL would report through RL_RENDER_FRAME_TIME (rl.h:346-355), per step instead of
+ * per pass because passes overlap here.  One record per macro step of the pass pipeline since the last hr_clear (the newest 4096): when its k_trace launch started and how
  * long it ran, by the device clock, how many passes were in flight in it and how many of them it injected.  A step in which the
  * pipeline is full (passes_in_flight = stages x batch) does one pass's worth of work per injected pass: the period between such
  * steps / passes_injected is the steady-state time per pass; the steps before and behind are the pipeline's fill and drain. */
@@ -487,7 +489,9 @@ int hr_display(hr_ctx *ctx, const hr_display_params *params, int32_t format, voi
 int hr_display_readback(hr_ctx *ctx, const hr_display_params *params, int32_t format, const void **pixels, int32_t *width,
                         int32_t *height, uint32_t *passes_shown);
 /* Passes whose sample has been added to the accumulation buffer since the last hr_clear, as enqueued on the ctx stream so far
- * (a host-side counter: no synchronisation).  Work enqueued on the ctx stream after this call sees exactly that many passes. */
+ * (a host-side counter: no synchronisation).  Work enqueued on the ctx stream after this call sees exactly that many passes.
+ * The reference's counterpart is the passIndex its PassCompleteCallback hands the viewer (PassGenerator.h:161,
+ * PassGenerator.cpp:390-400: one callback per pass, because rlRenderFrame is synchronous there). */
 int hr_frame_passes_resolved(hr_ctx *ctx, uint64_t *passes);
 
 /* ------------------------------------------------------------------ tile-shard exchange
