@@ -215,3 +215,27 @@ def test_thin_lens_depth_of_field_blur_disc():
         assert np.abs(v[inside] - np.interp(-x0[inside] / rho, us, esf)).max() < 0.06, z_obj
     x0, v = profile(F_dist)                                  # in focus: the edge is as sharp as the pixel grid allows
     assert width_10_90(x0, v) < 1.5 * (x0[1] - x0[0])
+
+
+def test_emissive_texture_replaces_the_emissive_colour():
+    # :156-159 emissive = texture2D(Material.emissiveTexture, texCoord).rgb (replaces, does not multiply)
+    sc = _scene(lit=False)
+    tex = np.array([[[0.2, 0.4, 0.6], [0.9, 0.1, 0.3]]], dtype=F)
+    sc.textures.append((tex, ffi.HR_WRAP_CLAMP_TO_EDGE, ffi.HR_FILTER_NEAREST))
+    sc.materials[0] = host.bake_pbr(base_color=(0, 0, 0), emissive_color=(1.0, 1.0, 1.0), roughness=1.0, specular_f0=0.0, emissive_texture=0)
+    sc.meshes.append(_quad_mesh(material_id=0))
+    rgb = _render(sc)
+    h, w = rgb.shape[:2]
+    assert np.array_equal(rgb[h // 2, w // 4], tex[0, 0]) and np.array_equal(rgb[h // 2, 3 * w // 4], tex[0, 1])
+
+
+def test_material_baking_clamps():
+    # PhysicallyBasedMaterial.cpp:133-145: roughness >= 0.01, specularF0 * 0.08, clearCoat * 0.2, alphas = roughness^2;
+    # GlassMaterial.cpp:88-126 keeps the same roughness floor
+    m = host.bake_pbr(roughness=0.0, specular_f0=1.0, clear_coat=1.0, clear_coat_roughness=0.0, metallic=2.0, base_color=(2, -1, 0.5))
+    assert m.roughness == F(0.01) and m.roughness_alpha == F(0.01) * F(0.01)
+    assert m.specular_f0 == F(0.08) and m.clear_coat == F(0.2)
+    assert m.clear_coat_roughness == F(0.01) and m.clear_coat_roughness_alpha == F(0.01) * F(0.01)
+    assert m.metallic == 1.0 and list(m.base_color) == [1.0, 0.0, 0.5]
+    g = host.bake_glass(base_color=(0.5, 0.5, 0.5), roughness=0.0, ior=1.5, density=0.5)
+    assert g.roughness == F(0.01)
