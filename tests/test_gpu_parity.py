@@ -368,6 +368,18 @@ def test_closed_room_paths_bounce(golden):
     assert g[..., :3].max() > 0
 
 
+def test_known_answer_scenes_of_the_surface_inputs(golden):
+    # the scenes whose oracle images tests/test_oracle_kat_surface.py checks against closed forms (textures in every slot, vertex colours,
+    # a tangent-space normal map, the clamp, an alpha-masked non-occluder crossed by camera and shadow rays, a single-sided back face):
+    # the HIP path gives the same bits
+    import test_oracle_kat_surface as kat
+    for what, sc in kat.gpu_parity_scenes():
+        g, o, ge, oe = render_both(sc, 3, lut=golden["multiscatter_lut"])
+        assert_parity(g, o, what)
+        assert ge.stats().rays_closest == oe.stats().rays_closest and ge.stats().rays_any == oe.stats().rays_any
+        ge.close(), oe.close()
+
+
 def test_glass_clearcoat_dof_config5_small(golden):
     # BASELINE config 5 at test size: 25 % glass, 25 % clearcoat, f/2.8 depth of field, 16 bounces
     sc = scenes.triangle_soup(4000, width=96, height=54, bounces=16, passes=8, env=True, glass_fraction=0.25,

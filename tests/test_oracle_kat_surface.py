@@ -239,3 +239,38 @@ def test_material_baking_clamps():
     assert m.metallic == 1.0 and list(m.base_color) == [1.0, 0.0, 0.5]
     g = host.bake_glass(base_color=(0.5, 0.5, 0.5), roughness=0.0, ior=1.5, density=0.5)
     assert g.roughness == F(0.01)
+
+
+# ---- the scenes above, for the GPU suite: the HIP path must give the oracle's image of each, bit for bit
+def gpu_parity_scenes():
+    out = []
+    sc = _scene(lit=False)
+    sc.materials[0] = host.bake_pbr(base_color=(0, 0, 0), emissive_color=(0.3, 0.7, 1.0), roughness=1.0, specular_f0=0.0)
+    sc.meshes.append(_quad_mesh(material_id=0))
+    sc.options.max_channel_value = 0.5
+    out.append(("emission and clamp", sc))
+    sc = _scene(depth=3)
+    sc.textures.append((np.array([[[0.5, 0.25, 1.0, 1.0], [1.0, 0.5, 0.25, 1.0]]], dtype=F), ffi.HR_WRAP_CLAMP_TO_EDGE, ffi.HR_FILTER_NEAREST))
+    sc.textures.append((np.array([[(0.123, 0.8, 0.3)]], dtype=F), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_NEAREST))
+    sc.textures.append((np.array([[((math.sin(0.3) + 1) / 2, 0.5, (math.cos(0.3) + 1) / 2)]], dtype=F), ffi.HR_WRAP_REPEAT, ffi.HR_FILTER_NEAREST))
+    sc.textures.append((np.array([[[0.2, 0.4, 0.6], [0.9, 0.1, 0.3]]], dtype=F), ffi.HR_WRAP_CLAMP_TO_EDGE, ffi.HR_FILTER_NEAREST))
+    sc.materials[0] = host.bake_pbr(base_color=(0.8, 0.6, 0.9), roughness=0.7, metallic=0.9, specular_f0=0.5, vertex_colors=True, base_color_texture=0,
+                                    metallic_roughness_texture=1, normalmap=2, emissive_texture=3)
+    m = _quad_mesh(material_id=0)
+    m.colors = np.tile(np.array([0.5, 1.0, 0.25], dtype=F), (4, 1))
+    m.tangents = np.tile(np.array([1, 0, 0], dtype=F), (4, 1))
+    m.bitangents = np.tile(np.array([0, 0, -1], dtype=F), (4, 1))
+    sc.meshes.append(m)
+    out.append(("base colour, metallic-roughness, normal and emissive textures with vertex colours", sc))
+    sc = _scene(w=96, h=48, depth=2)
+    sc.textures.append((np.array([[[1, 1, 1, 0.0], [1, 1, 1, 1.0]]], dtype=F), ffi.HR_WRAP_CLAMP_TO_EDGE, ffi.HR_FILTER_NEAREST))
+    sc.materials[0] = host.bake_pbr(base_color=(0.5, 0.6, 0.7), roughness=1.0, specular_f0=0.0)
+    sc.materials[1] = host.bake_pbr(base_color=(0.9, 0.2, 0.2), roughness=1.0, specular_f0=0.0, alpha_mask=True, base_color_texture=0)
+    sc.materials[2] = host.bake_pbr(base_color=(0.9, 0.1, 0.1), roughness=1.0, specular_f0=0.0, double_sided=False)
+    sc.meshes.append(_quad_mesh(y=0.0, material_id=0))
+    sc.meshes.append(_quad_mesh(y=1.5, s=1.0, material_id=1, is_occluder=False))
+    mesh = _quad_mesh(y=0.8, s=0.7, up=False, material_id=2)
+    mesh.positions = (mesh.positions + np.array([2.5, 0, 0.5], dtype=F)).astype(F)
+    sc.meshes.append(mesh)
+    out.append(("alpha-masked sheet and a single-sided sheet seen from behind, over a floor", sc))
+    return out
