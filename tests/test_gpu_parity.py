@@ -1363,6 +1363,35 @@ def test_a_slow_caller_does_not_wait_for_a_batch_to_fill(golden):
         assert buf.tobytes() == o.readback().tobytes()
 
 
+def test_step_log_resolved_counter_and_the_kernels_own_clock(golden):
+    # hr_get_step_log / hr_frame_passes_resolved / hr_kernel_times.trace_clock_*: the pipeline's own account of itself
+    sc = scenes.triangle_soup(20000, width=320, height=192, bounces=4, passes=64, env=True)
+    g = core.create_engine(time_kernels=True)
+    sc.apply(g, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    batch = g.pass_batch(sc.options.max_ray_depth)
+    assert g.passes_resolved() == 0
+    seen = []
+    for s in range(3 * batch + 1):
+        g.render_pass(sc.options.pass_params(s))
+        seen.append(g.passes_resolved())
+    assert seen == sorted(seen) and seen[-1] <= 3 * batch + 1          # a host-side counter of enqueued resolves: never ahead of the requests
+    g.flush()
+    assert g.passes_resolved() == 3 * batch + 1
+    log = g.step_log()
+    kt = g.kernel_times()
+    assert len(log) == kt["trace"][1] == kt["trace_clock"][1] >= sc.options.max_ray_depth + 2
+    starts = [r[0] for r in log]
+    assert starts == sorted(starts) and starts[0] == 0.0
+    assert sum(r[3] for r in log) == 3 * batch + 1                         # every pass was injected by exactly one step
+    assert max(r[2] for r in log) <= 3 * batch + 1 and all(r[1] > 0 for r in log)
+    # the launch durations by the device clock agree with the HIP events around the same launches (events include the launch's edges)
+    assert abs(sum(r[1] for r in log) - kt["trace_clock"][0]) < 1e-3 * max(kt["trace_clock"][0], 1e-3) + 1e-3
+    assert 0.5 * kt["trace"][0] < kt["trace_clock"][0] <= 1.05 * kt["trace"][0] + 0.05
+    g.clear()
+    assert g.passes_resolved() == 0 and g.step_log() == []
+    g.close()
+
+
 def test_large_scene_3m_triangles(golden):
     # maximum-size end of the range (tools/big_scene_check.py goes to 30 M): device LBVH + collapse of 3 M triangles, hits against
     # the oracle's own tree and a render, bit for bit
