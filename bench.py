@@ -539,6 +539,7 @@ def main():
     st = eng.stats()
     kt = eng.kernel_times()
     trace_clock = kt.pop("trace_clock")
+    camera_packets = kt.pop("camera_packets")  # (the packet selector's state: camera rays as 64-ray packets or one per lane; its probe's union factor)
     if not time_kernels:  # (no events recorded: the device clock's figure stands in for k_trace's)
         kt["trace"] = trace_clock
     rays = torch.tensor([float(st.rays_closest + st.rays_any), float(st.paths), float(st.rays_closest)], dtype=torch.float64, device=red_dev)
@@ -790,6 +791,7 @@ def main():
             "passes_to_converge": conv,
             "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,
                       "rays_per_path": total_rays / max(total_paths, 1.0), "bvh_build_ms": info.build_ms,
+                      "camera_rays": {"traced_as": "packets" if camera_packets[0] else "one ray per lane", "packet_union": round(camera_packets[1], 3)},
                       "kernel_ms_rank0": {k: v[0] for k, v in kt.items()}, "kernel_launches_rank0": {k: v[1] for k, v in kt.items()},
                       "display_resolve_ms_rgba8": disp_ms,
                       "gpu_traversal_counters": gpu_counts},

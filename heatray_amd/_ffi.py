@@ -122,7 +122,8 @@ class StepRecord(C.Structure):
 
 
 class KernelTimes(C.Structure):
-    _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4), ("trace_clock_ms", C.c_float), ("trace_clock_launches", C.c_uint32)]
+    _fields_ = [("ms", C.c_float * 4), ("launches", C.c_uint32 * 4), ("trace_clock_ms", C.c_float), ("trace_clock_launches", C.c_uint32),
+                ("camera_packets", C.c_uint32), ("packet_union", C.c_float)]
 
 
 class DisplayParams(C.Structure):
@@ -373,11 +374,13 @@ class Engine:
 
     def kernel_times(self):
         """{kernel: (total_ms, launches)} since the last clear: HIP-event times (zero unless the context was created with
-        HR_CTX_TIME_KERNELS) and, under "trace_clock", k_trace's time by the device clock (always)."""
+        HR_CTX_TIME_KERNELS), under "trace_clock" k_trace's time by the device clock (always), under "camera_packets" whether camera
+        rays are traced as packets at the moment and the union factor the selector's last probe measured."""
         t = KernelTimes()
         self._call("get_kernel_times", C.byref(t))
         d = {n: (t.ms[i], t.launches[i]) for i, n in enumerate(HR_KERNEL_NAMES)}
         d["trace_clock"] = (t.trace_clock_ms, t.trace_clock_launches)
+        d["camera_packets"] = (bool(t.camera_packets), t.packet_union)  # (how camera rays are traced now, the probe's union factor)
         return d
 
     def step_log(self, capacity=4096):

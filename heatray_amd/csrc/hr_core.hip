@@ -158,6 +158,8 @@ struct hr_ctx {
         volatile unsigned long long *hSeq = nullptr;   // [kTableRing], pinned: step number + 1 whose lengths the entry holds
         uint32_t *dCounts = nullptr;                   // the same two arrays as the device addresses them
         unsigned long long *dSeq = nullptr;
+        volatile unsigned long long *hProbe = nullptr; // [kTableRing][3], pinned: the packet probe's totals as of that step's k_trace (packet selector below)
+        unsigned long long *dProbeHost = nullptr;      // ... as the device addresses it
         int countN[4] = {0, 0, 0, 0};                  // entries of the step table that went with ring entry r
         int countSlot[4][HR_MAX_SEGS];                 // ... their pass slots
         unsigned long long countOrder[4][HR_MAX_SEGS]; // ... and passes (order + 1)
@@ -259,6 +261,29 @@ struct hr_ctx {
     int tuneRefit = 1;        // HR_TUNE="refit=0": always rebuild
     // pipeline diagnostics (HR_DEBUG_PIPE=1 prints them when the context is destroyed)
     unsigned long long dbgGrowths = 0, dbgGrowBytes = 0, dbgWaits = 0, dbgWaitNs = 0, dbgWaitSpun = 0;
+    // ---- packet selector.  A pass's camera rays can be traced one ray per lane by k_trace, or 64 at a time as a packet by
+    // k_trace_primary (hr_render.hip).  The packet walks the UNION of its rays' node sets: it wins where 8x8 pixels see the same part
+    // of the tree (meshes whose triangles are not much smaller than the patch: c2 +15 %) and loses where every ray meets its own
+    // leaves (the benchmark's triangle fog: -17 %).  Which it is depends on scene, camera and resolution, so it is measured: every
+    // kProbeEvery-th injecting step — and the first after a commit, a resize or a change of camera — a probe kernel on a side stream
+    // makes the camera rays of every 32nd 8x8 patch of one injected pass itself and walks them as packets, writing nothing but
+    //     U = (children the packet entered x its rays) / (children the rays' own box tests entered);
+    // packets are used while U < punion / 100 (c1 1.2, c2 1.5: win; c3 3.0, terrain 6.6: lose; profiles/r4u_packets.txt).  The totals
+    // come back with the queue lengths k_trace reports (no synchronisation).  Either way the hits are the same bits.
+    int tunePackets = 2;   // HR_TUNE="packets=0|1|2": never / always / by the probe (default)
+    int tunePacketUnion = 195; // HR_TUNE="punion=N": packets while U < N / 100
+    bool packetsOn = false;
+    int probeCountdown = 0;              // injecting steps until the next probe
+    bool probePending = false;
+    unsigned long long probeStep = 0;    // step (of group 0) that carried the pending probe
+    unsigned long long probeSeen[3] = {0, 0, 0}; // totals of the report the last decision was taken on
+    unsigned long long probeWaves = 0;   // waves of the pending probe: it is complete when the third total has grown by as many
+    double lastUnion = 0.0;              // U of the last probe (HR_DEBUG_PIPE prints it)
+    float probeCamera[21] = {0};         // fov, aspect, focus distance, aperture, view matrix, interactive mode of the probed pass
+    unsigned long long *dProbe = nullptr; // three device counters the probe launches add to (never reset)
+    hipStream_t probeStream = nullptr;   // the probe runs beside the pipeline: it makes its own camera rays and writes only the counters
+    hipEvent_t evProbeA = nullptr, evProbeB = nullptr; // scene and tables as the group's stream sees them -> probe may start; probe done
+    bool probeGuard = false;             // evProbeB has not been waited for yet (drainPipeline does: the scene may change afterwards)
     int tunePloc = 1, tunePlocRadius = 16; // HR_TUNE="ploc=0|1|2,plocr=N": tree builder (hr_build.hip: buildLBVH keeps the cheaper of the radix tree and PLOC)
     int tuneGuardPct = 125;   // HR_TUNE="guard=N": a refit whose boxes' area exceeds N % of the built tree's rebuilds instead (profiles/r3j_instanced_refit.txt)
     // persistent device arrays of the committed scene (grow-only capacities, reused across commits)
@@ -554,7 +579,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -582,13 +607,17 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hSeq, sizeof(unsigned long long) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipHostGetDevicePointer((void **)&G.dCounts, G.hCounts, 0) == hipSuccess &&
                    hipHostGetDevicePointer((void **)&G.dSeq, (void *)G.hSeq, 0) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hProbe, sizeof(unsigned long long) * kTableRing * 3, hipHostMallocDefault) == hipSuccess &&
+                   hipHostGetDevicePointer((void **)&G.dProbeHost, (void *)G.hProbe, 0) == hipSuccess;
         if (groupsOk)
-            for (int k = 0; k < kTableRing; ++k) G.hSeq[k] = 0ull;
+            for (int k = 0; k < kTableRing; ++k) G.hSeq[k] = 0ull, G.hProbe[3 * k] = 0ull, G.hProbe[3 * k + 1] = 0ull, G.hProbe[3 * k + 2] = 0ull;
         std::memset(G.statusOrder, 0, sizeof(G.statusOrder));
     }
     if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
         hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, sizeof(uint32_t) * 6 * kBoundSlots) != hipSuccess ||
-        hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters) * kMaxSlots) != hipSuccess ||
+        hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dProbe, 32) != hipSuccess || hipMemset(c->dProbe, 0, 32) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->probeStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->evProbeA, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->evProbeB, hipEventDisableTiming) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters) * kMaxSlots) != hipSuccess ||
         hipMalloc(&c->dStepLog, sizeof(unsigned long long) * 3 * kStepLogCap) != hipSuccess) {
         delete c;
         return HR_ERR_DEVICE;
@@ -608,6 +637,9 @@ int hr_ctx_destroy(hr_ctx *c)
                 c->dbgGrowths, (double)c->dbgGrowBytes / 1048576.0, c->dbgWaits, c->dbgWaitSpun, (double)c->dbgWaitNs * 1e-6);
     drainPipeline(c);
     hipStreamSynchronize(c->stream);
+    if (c->probeStream) hipStreamSynchronize(c->probeStream), hipStreamDestroy(c->probeStream);
+    if (c->evProbeA) hipEventDestroy(c->evProbeA);
+    if (c->evProbeB) hipEventDestroy(c->evProbeB);
     c->drainTimes();
     for (hipEvent_t e : c->eventPool) hipEventDestroy(e);
     if (c->evPack) hipEventDestroy(c->evPack);
@@ -629,11 +661,12 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->dMaterials), hipFree(c->dTextures), hipFree(c->dSeq), hipFree(c->dAperture), hipFree(c->dSeqOffsets);
     hipFree(c->dTexDensity);
     for (Texture &t : c->textures) hipFree(t.dmips);
-    hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dCounters), hipFree(c->dStepLog);
+    hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dProbe), hipFree(c->dCounters), hipFree(c->dStepLog);
     for (hr_ctx::Group &G : c->groups) {
         if (G.hQCount) hipHostFree(G.hQCount);
         if (G.hCounts) hipHostFree(G.hCounts);
         if (G.hSeq) hipHostFree((void *)G.hSeq);
+        if (G.hProbe) hipHostFree((void *)G.hProbe);
         for (hipEvent_t e : G.statusEv)
             if (e) hipEventDestroy(e);
         if (G.stream) hipStreamDestroy(G.stream);
@@ -799,6 +832,7 @@ int hr_frame_resize(hr_ctx *c, int32_t w, int32_t h)
     QUIESCE(c);
     c->W = w, c->H = h;
     c->snapshotEpoch++;
+    c->probeCountdown = 0; // (packet selector: another resolution)
     freeLagged(c->progFrame), freeLagged(c->progDisplay);
     hipFree(c->fbInternal);
     c->fbInternal = nullptr;
@@ -1316,6 +1350,7 @@ int hr_scene_commit(hr_ctx *c)
     HIP_TRY(c, hipEventSynchronize(cs.e1));
     hipEventElapsedTime(&c->info.build_ms, cs.e0, cs.e1);
     c->committed = true;
+    c->probeCountdown = 0; // (packet selector: another tree)
     c->sceneDirty = true;
     c->texDensityStale = true;
     c->topologyDirty = false, c->transformDirty = false;
@@ -1880,6 +1915,7 @@ static int waitCounts(hr_ctx *c, hr_ctx::Group &G, int ring, unsigned long long 
 
 // One macro step of pipeline group g: (raygen of the injected passes) -> trace of every in-flight pass of the group ->
 // shade; passes whose last stage this was become `finished`.
+static const int kProbeEvery = 64; // injecting steps between two probes of the packet selector
 static int macroStep(hr_ctx *c, int g, int nInject)
 {
     hr_ctx::Group &G = c->groups[g];
@@ -1988,6 +2024,18 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         if (wanted && stepIdx > 0) {
             int rc = waitCounts(c, G, prev, stepIdx); // (step stepIdx - 1 wrote stepIdx: its number + 1)
             if (rc) return rc;
+            if (g == 0 && c->probePending) { // complete once every wave of the probe has counted itself
+                const unsigned long long pk = G.hProbe[3 * prev], ry = G.hProbe[3 * prev + 1], done = G.hProbe[3 * prev + 2];
+                if (done - c->probeSeen[2] >= c->probeWaves) {
+                    const unsigned long long dPk = pk - c->probeSeen[0], dRy = ry - c->probeSeen[1];
+                    c->probePending = false, c->probeSeen[0] = pk, c->probeSeen[1] = ry, c->probeSeen[2] = done;
+                    if (dRy > 0) {
+                        c->lastUnion = (double)dPk / (double)dRy;
+                        c->packetsOn = c->lastUnion * 100.0 < (double)c->tunePacketUnion;
+                    }
+                    if (getenv("HR_DEBUG_PIPE")) fprintf(stderr, "packet probe of step %llu (seen at step %llu): union %.3f -> packets %s\n", c->probeStep, stepIdx, c->lastUnion, c->packetsOn ? "on" : "off");
+                }
+            }
             for (int i = 0; i < kMaxSlots; ++i) idxOfSlot[i] = -1;
             for (int j = 0; j < G.countN[prev]; ++j) idxOfSlot[G.countSlot[prev][j]] = j;
         }
@@ -2080,7 +2128,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         sg.qCountOut = &ps.ctr->qCount[(st + 1) % R];
         sg.sCountOut = &ps.ctr->sCount[st % R];
         sg.pCount = &ps.ctr->pCount[st % R], sg.gCount = &ps.ctr->gCount[st % R];
-        sg.hitCap = boundIn[k] ? boundIn[k] : 1u, sg.pad2 = 0;
+        sg.hitCap = boundIn[k] ? boundIn[k] : 1u, sg.packets = 0;
         sg.pp = ps.pp;
         sg.closestEnabled = closest ? 1 : 0;
         G.countSlot[ring][k] = order[k], G.countOrder[ring][k] = ps.order + 1ull;
@@ -2088,6 +2136,26 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             if (order[k] == injectedSlots[j]) injectedSegs[nInjectedSegs++] = k;
     }
     if (nInjectedSegs > 0) tbl.primaryFromSeg = injectedSegs[0]; // (the table is in pass order: the passes injected now are its last entries)
+    // packet selector (above): which of the injected passes' camera rays go through k_trace_primary, and is one of them this step's probe?
+    int probeSeg = -1;
+    bool packetsNow = c->tunePackets == 1 || (c->tunePackets == 2 && c->packetsOn);
+    if (c->tunePackets == 2 && g == 0 && nInjectedSegs > 0 && !c->probePending) {
+        const hr_pass_params &pp = tbl.seg[injectedSegs[0]].pp;
+        float cam[21] = {pp.fov_tan, pp.aspect_ratio, pp.focus_distance, pp.aperture_radius};
+        std::memcpy(cam + 4, pp.view_matrix, sizeof(pp.view_matrix));
+        cam[20] = (float)pp.interactive_mode;
+        // another camera sees another part of the tree: probe again, but not more often than every eighth injecting step (a camera in motion)
+        if (std::memcmp(cam, c->probeCamera, sizeof(cam)) != 0 && c->probeCountdown > 0 && c->probeCountdown <= kProbeEvery - 8) c->probeCountdown = 0;
+        if (c->probeCountdown <= 0) {
+            probeSeg = injectedSegs[0];
+            std::memcpy(c->probeCamera, cam, sizeof(cam));
+        } else {
+            c->probeCountdown--;
+        }
+    }
+    for (int j = 0; j < nInjectedSegs; ++j)
+        if (packetsNow) tbl.seg[injectedSegs[j]].packets = 1;
+    tbl.probe = c->dProbe, tbl.hostProbe = G.dProbeHost + 3 * ring;
     G.countN[ring] = n;
     tbl.hostCounts = G.dCounts + (size_t)ring * kMaxSegs, tbl.hostSeq = G.dSeq + ring, tbl.seqValue = stepIdx + 1ull;
     tbl.stepLog = c->dStepLog, tbl.nInjectedNow = (uint32_t)nInjected, tbl.padL = 0;
@@ -2112,6 +2180,20 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         c->timeNext(HR_KERNEL_TRACE, G.stream);
     else
         c->timeBegin(HR_KERNEL_TRACE, G.stream);
+    if (probeSeg >= 0) {
+        // (probeSeen holds the totals of the report the previous decision was taken on: probes never overlap, that probe was complete)
+        HIP_TRY(c, hipEventRecord(c->evProbeA, G.stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->probeStream, c->evProbeA, 0));
+        c->probeWaves = (unsigned long long)launchPacketProbe(c->probeStream, c->dScene, c->nodes, c->tris, tbl.seg[probeSeg].pp, fr, c->dProbe);
+        HIP_TRY(c, hipEventRecord(c->evProbeB, c->probeStream));
+        c->probeGuard = true, c->probePending = true, c->probeStep = stepIdx, c->probeCountdown = kProbeEvery;
+    }
+    if (packetsNow)
+        for (int j0 = 0; j0 < nInjectedSegs; j0 += kMaxBatch) {
+            SegList segs{};
+            for (int j = j0; j < nInjectedSegs && segs.n < kMaxBatch; ++j) segs.seg[segs.n++] = injectedSegs[j];
+            launchTracePrimary(cfg, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
+        }
     launchTrace(cfg, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
     c->timeNext(HR_KERNEL_SHADE, G.stream);
     launchShade(cfg, c->dScene, dTbl, c->dStats);
@@ -2212,6 +2294,10 @@ static int drainPipeline(hr_ctx *c)
     if (rc) return rc;
     if (occupiedSlots(c) > 0) FAIL(c, HR_ERR_DEVICE, "internal: finished passes left unresolved");
     c->oldestWaitingNs = 0;
+    if (c->probeGuard) { // (a probe nobody has waited for: whatever follows on the caller's stream — frees after a synchronise included — comes after it)
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evProbeB, 0));
+        c->probeGuard = false;
+    }
     // whatever the caller does next on its stream (clear, scene edits, new tables) has to be seen by the groups
     for (int g = 0; g < kMaxGroups; ++g) c->groups[g].needUserSync = true;
     return HR_OK;
@@ -2342,6 +2428,8 @@ int hr_get_kernel_times(hr_ctx *c, hr_kernel_times *out)
     for (const Stats &p : parts) ticks += p.traceTicks, launches += p.traceLaunches;
     out->trace_clock_ms = (float)((double)ticks * 1e-5); // 100 MHz: 10 ns per tick
     out->trace_clock_launches = (uint32_t)launches;
+    out->camera_packets = (c->tunePackets == 1 || (c->tunePackets == 2 && c->packetsOn)) ? 1u : 0u;
+    out->packet_union = (float)c->lastUnion;
     return HR_OK;
 }
 

@@ -51,7 +51,7 @@ struct SegDev {
     uint32_t *pCount;    // entries at the front of hitIdx (k_shade_sort appends, k_shade_hit<.., 0> reads)
     uint32_t *gCount;    // entries at the back of hitIdx
     uint32_t hitCap;     // capacity of hitIdx (= of the ray queues)
-    uint32_t pad2;
+    uint32_t packets;    // this step traces the entry's closest-hit queue (camera rays) as packets (k_trace_primary): k_trace leaves it out
     hr_pass_params pp;   // per-pass uniforms
     int32_t closestEnabled; // 0 in a pass's last step (only its occlusion rays remain)
     int32_t pad;
@@ -83,7 +83,12 @@ struct StepTable {
     unsigned long long seqValue;
     // log of the k_trace launches since the last hr_clear (hr_get_step_log): k_shade_sort appends (first start, last end) by the device clock
     unsigned long long *stepLog; // kStepLogCap x {start tick, end tick, passes in the table | passes injected << 32}
-    uint32_t nInjectedNow, padL;
+    uint32_t nInjectedNow;
+    uint32_t padL;
+    // k_packet_probe adds (children a packet entered x its rays, child boxes the rays themselves entered, 1 per finished wave) to
+    // probe[0..2]; k_trace's first workgroup copies the totals to pinned host memory with the queue lengths (hr_core.hip: the packet selector)
+    unsigned long long *probe;
+    unsigned long long *hostProbe;
     // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
     // kTraceHeadsMax), each with a cursor on a cache line of its own — none of them shares its 128-byte line with the header above
     // or with seg[] below, which every wave reads while the cursors are hammered by atomics.  ONE cursor serialises at ~12 ns per atomic:
@@ -124,6 +129,10 @@ void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &
 void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *frame, float *packed, int unpack, float *full);
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out);
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
+void launchTracePrimary(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, const SegList &segs, const FrameDev &fr,
+                        Stats *stats);
+int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, const FrameDev &fr,
+                      unsigned long long *probe);
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,
                       int anyHit, hr_hit *out);

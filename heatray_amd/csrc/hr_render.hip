@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_display(FrameDev fr, hr_display_para
 // -------------------------------------------------------------------------------------------- trace
 // Work items of one launch: for every in-flight pass k, its closest-hit queue followed by its occlusion
 // queue.  segStart[2k] / segStart[2k+1] are the first global indices of the two.
-HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxSegs+1 */, bool closestOnly)
+HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxSegs+1 */, bool closestOnly, bool skipPackets = false)
 {
     // Queue lengths are read by one thread per queue, all at once (a serial loop over up to 96 passes, two dependent
     // global loads each, used to cost ~0.15 ms at the start of every launch on a small shard); then the first wave turns
@@ -254,7 +254,7 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
     const int n = tbl->nSeg;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         const SegDev &sg = tbl->seg[k];
-        segStart[2 * k] = sg.closestEnabled ? *sg.qCountIn : 0u;
+        segStart[2 * k] = (sg.closestEnabled && !(skipPackets && sg.packets)) ? *sg.qCountIn : 0u;
         segStart[2 * k + 1] = closestOnly ? 0u : *sg.sCountIn;
     }
     __syncthreads();
@@ -303,7 +303,10 @@ __device__ __attribute__((noinline)) void reportQueueLengths(const StepTable *tb
 {
     if (!tbl->hostCounts) return;
     for (int k = (int)threadIdx.x; k < tbl->nSeg; k += kTraceBlock)
-        __hip_atomic_store(&tbl->hostCounts[k], segStart[2 * k + 1] - segStart[2 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&tbl->hostCounts[k], tbl->seg[k].closestEnabled ? *tbl->seg[k].qCountIn : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x < 3 && tbl->hostProbe) // (the packet probe's totals so far)
+        __hip_atomic_store(&tbl->hostProbe[threadIdx.x], __hip_atomic_load(&tbl->probe[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(tbl->hostSeq, tbl->seqValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
     const unsigned long long clk0 = wall_clock64();
-    buildSegStarts(tbl, segStart, false);
+    buildSegStarts(tbl, segStart, false, true); // (camera rays traced as packets: k_trace_primary has done them)
     const int nSeg2 = 2 * tbl->nSeg;
     if (blockIdx.x == 0) reportQueueLengths(tbl, segStart);
     const uint32_t total = segStart[nSeg2];
@@ -773,6 +776,213 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------- trace, camera rays
+// The closest-hit rays of a pass's FIRST stage are camera rays: 64 consecutive entries of that queue are (what the root cull left of)
+// 8x8-pixel patches, in patch order (ownedPixel).  Such a wave walks the tree as ONE packet: a single traversal state per wave — the
+// node reference and the stack are wave-uniform, the node arrives through the scalar cache (no texture addresser), every lane tests the
+// node's four child boxes with its own ray, and a child is entered when ANY lane's ray enters it.  A lane whose ray misses a subtree the
+// wave walks anyway tests boxes and triangles it cannot hit: the hit is defined by the triangle test alone (hr_trace.h), so the result
+// is the same closest hit, bit for bit; what it costs is the union of the 64 rays' node sets instead of their sum — and one node fetch,
+// one box decode and one stack for 64 rays.  Children are ordered by the entry distance of the first lane that enters each.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HR_CONSTANT __attribute__((address_space(4))) // (uniform address + constant address space = scalar loads)
+#else
+#define HR_CONSTANT
+#endif
+typedef const Node4 HR_CONSTANT *ConstNodes;
+typedef const Tri HR_CONSTANT *ConstTris;
+static const int kPacketBlock = 64;
+
+struct LaneStack { // wave-uniform stack held in the LANES of three registers: entry i is lane (i & 63) of register (i >> 6)
+    int r0, r1, r2;
+    static HRD void writeLane(int &r, int v, int l) // (clang has no builtin for it; value and lane are wave-uniform)
+    {
+        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(v), "s"(l) : "m0"); // (one SGPR operand per instruction: the lane goes through M0)
+    }
+    HRD void push(int sp, int v)
+    {
+        if (sp < 64)
+            writeLane(r0, v, sp);
+        else if (sp < 128)
+            writeLane(r1, v, sp - 64);
+        else
+            writeLane(r2, v, sp - 128);
+    }
+    HRD int at(int sp) const
+    {
+        if (sp < 64) return __builtin_amdgcn_readlane(r0, sp);
+        if (sp < 128) return __builtin_amdgcn_readlane(r1, sp - 64);
+        return __builtin_amdgcn_readlane(r2, sp - 128);
+    }
+};
+static_assert(kStackLDS + kStackOvf <= 192, "the packet stack holds the deepest tree the builder can make");
+
+HRD void cswapS(uint32_t &a, uint32_t &b)
+{
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    a = lo, b = hi;
+}
+
+// One packet: every lane walks the wave's traversal with its own ray (o, d, tmax; a lane without a ray passes tmax = 0: it enters
+// nothing and hits nothing).  PROBE also counts, per node step, the children the PACKET entered (`entered`, wave-uniform) and the
+// children this lane's own box test entered (`own`): what the packet costs against its rays traced one by one.
+template <bool STATS, bool PROBE>
+HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 o, v3 d, float tmax, uint32_t skipPrim, HitRec &best, uint32_t &nv, uint32_t &nt,
+                        uint32_t &entered, uint32_t &own)
+{
+    const float tmin = S.rayEps;
+    float tlim = tmax;
+    const float idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
+    const RayK rk = rayFrame(o, idx, idy, idz);
+    best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
+    LaneStack stk{0, 0, 0};
+    int sp = 0;
+    int cur = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
+    while (cur != kSentinel) {
+        cur = __builtin_amdgcn_readfirstlane(cur);
+        if (cur >= 0) {
+            if (STATS) ++nv;
+            const float4 a = nodes[cur].a;
+            const uint4 qb = nodes[cur].b, qc = nodes[cur].c;
+            const uint32_t meta = __float_as_uint(a.w);
+            const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
+            const int innerBase = (int)qc.z, leafKey = (int)qc.w;
+            const float bx = __uint_as_float((meta & 0xFFu) << 23) * rk.idx;
+            const float by = __uint_as_float(((meta >> 8) & 0xFFu) << 23) * rk.idy;
+            const float bz = __uint_as_float(((meta >> 16) & 0xFFu) << 23) * rk.idz;
+            const float ax = __builtin_fmaf(a.x, rk.idx, -rk.oix), ay = __builtin_fmaf(a.y, rk.idy, -rk.oiy), az = __builtin_fmaf(a.z, rk.idz, -rk.oiz);
+            const uint32_t nX = rk.idx < 0.0f ? qb.w : qb.x, fX = rk.idx < 0.0f ? qb.x : qb.w;
+            const uint32_t nY = rk.idy < 0.0f ? qc.x : qb.y, fY = rk.idy < 0.0f ? qb.y : qc.x;
+            const uint32_t nZ = rk.idz < 0.0f ? qc.y : qb.z, fZ = rk.idz < 0.0f ? qb.z : qc.y;
+            uint32_t key[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float tnx = __builtin_fmaf((float)byteOf(nX, c), bx, ax), tfx = __builtin_fmaf((float)byteOf(fX, c), bx, ax);
+                const float tny = __builtin_fmaf((float)byteOf(nY, c), by, ay), tfy = __builtin_fmaf((float)byteOf(fY, c), by, ay);
+                const float tnz = __builtin_fmaf((float)byteOf(nZ, c), bz, az), tfz = __builtin_fmaf((float)byteOf(fZ, c), bz, az);
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
+                const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
+                const bool enters = tn <= tf && (uint32_t)c < nValid;
+                const unsigned long long m = __ballot(enters);
+                if (PROBE) own += enters ? 1u : 0u, entered += m ? 1u : 0u;
+                // the wave's key of the child: the entry distance of the first lane that enters it
+                key[c] = m ? (((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+            }
+            cswapS(key[0], key[1]), cswapS(key[2], key[3]), cswapS(key[0], key[2]), cswapS(key[1], key[3]), cswapS(key[1], key[2]);
+#pragma unroll
+            for (int j = 3; j >= 1; --j)
+                if (key[j] != 0xFFFFFFFFu) {
+                    const int sl = (int)(key[j] & 3u);
+                    stk.push(sp, (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl);
+                    ++sp;
+                }
+            if (key[0] != 0xFFFFFFFFu) {
+                const int sl = (int)(key[0] & 3u);
+                cur = (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl;
+            } else if (sp > 0) {
+                cur = stk.at(--sp);
+            } else {
+                cur = kSentinel;
+            }
+        } else {
+            const int enc = ~cur;
+            const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
+            for (int k = 0; k < count; ++k) {
+                const float4 tp = tris[first + k].p, tq = tris[first + k].q, trr = tris[first + k].r;
+                if (STATS) ++nt;
+                const uint32_t prim = __float_as_uint(trr.y);
+                if (prim == skipPrim) continue;
+                const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
+                // Möller–Trumbore; the operation order is part of the arithmetic contract (hr_trace.h)
+                const v3 pvec = cross(d, e2);
+                const float det = dot(e1, pvec);
+                if (det == 0.0f) continue;
+                const float inv = 1.0f / det;
+                const v3 tvec = o - v0;
+                const float u = dot(tvec, pvec) * inv;
+                if (!(u >= 0.0f) || u > 1.0f) continue;
+                const v3 qvec = cross(tvec, e1);
+                const float v = dot(d, qvec) * inv;
+                if (!(v >= 0.0f) || u + v > 1.0f) continue;
+                const float t = dot(e2, qvec) * inv;
+                if (!(t > tmin) || !(t < tmax)) continue;
+                const uint32_t bp = best.prim & 0x7FFFFFFFu;
+                if (best.prim == kMissPrim || t < best.t || (t == best.t && prim < bp)) {
+                    best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
+                    best.t = t, best.u = u, best.v = v;
+                    tlim = t;
+                }
+            }
+            cur = sp > 0 ? stk.at(--sp) : kSentinel;
+        }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kPacketBlock) void k_trace_primary(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
+                                                               StepTable *__restrict__ tbl, SegList segs, Stats *stats)
+{
+    const SceneDev &S = *Sp;
+    const SegDev &sg = tbl->seg[segs.seg[blockIdx.y]];
+    // this launch is the front part of the step's trace: its first waves' start is the start of the step's k_trace launch on the
+    // device clock (StepTable::clkStart; hr_get_step_log and the HIP-event bucket HR_KERNEL_TRACE then cover the same two kernels)
+    if (blockIdx.y == 0 && blockIdx.x < (uint32_t)kClkSlots && threadIdx.x == 0)
+        __hip_atomic_fetch_min(&tbl->clkStart[blockIdx.x], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t n = *sg.qCountIn;
+    const uint32_t lane = laneId();
+    const uint32_t base = blockIdx.x * 64u;
+    if (base >= n) return;
+    stats += blockIdx.x & (kStatSlots - 1);
+    const bool valid = base + lane < n;
+    const uint32_t local = valid ? base + lane : n - 1u;
+    const float4 ra = G(sg.qin.A)[local], rb = G(sg.qin.B)[local];
+    const uint32_t skipPrim = (uint32_t)G(sg.qin.D)[local].z;
+    HitRec best;
+    uint32_t nv = 0, nt = 0, entered = 0, own = 0;
+    packetTraverse<STATS, false>(S, (ConstNodes)(uintptr_t)nodesG, (ConstTris)(uintptr_t)trisG, v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), valid ? ra.w : 0.0f, skipPrim,
+                                 best, nv, nt, entered, own);
+    if (valid) G(sg.hits)[local] = best;
+    const uint32_t nValidLanes = (uint32_t)__popcll(__ballot(valid));
+    if (lane == 0) {
+        atomicAdd(&stats->raysClosest, (unsigned long long)nValidLanes);
+        if (STATS) { // per ray: the node steps and triangle tests its lane executed (the packet's union, not the ray's own set)
+            atomicAdd(&stats->nodeVisits, (unsigned long long)nv * nValidLanes);
+            atomicAdd(&stats->triTests, (unsigned long long)nt * nValidLanes);
+        }
+    }
+}
+
+// The selector's probe (hr_core.hip): a launch of its own on a side stream that depends on nothing the pipeline writes.  It generates
+// the camera rays of every kProbeStride-th 8x8 patch of one pass itself, walks them as packets and writes nothing but three totals:
+// probe[0] += children the packet entered x its rays, probe[1] += children the rays' own box tests entered, probe[2] += 1 per wave.
+static const int kProbeStride = 32;
+__global__ __launch_bounds__(kPacketBlock) void k_packet_probe(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
+                                                              hr_pass_params pp, FrameDev fr, unsigned long long *probe)
+{
+    const SceneDev &S = *Sp;
+    int x = 0, y = 0;
+    const bool inFrame = ownedPixel(fr, blockIdx.x * 64u * (uint32_t)kProbeStride + threadIdx.x, x, y);
+    Ray r;
+    r.valid = false;
+    bool active = inFrame;
+    if (active) active = generatePrimary(S, pp, fr.W, fr.H, x, y, r);
+    if (active && S.nTris > 0 && S.rootLeafCount == 0 && rootMissed(S.nodes, r.o, r.d, S.rayEps, r.maxT)) active = false; // (k_raygen's cull)
+    uint32_t entered = 0, own = 0;
+    if (__ballot(active)) {
+        HitRec best;
+        uint32_t nv = 0, nt = 0;
+        packetTraverse<false, true>(S, (ConstNodes)(uintptr_t)nodesG, (ConstTris)(uintptr_t)trisG, active ? r.o : v3(0.0f), active ? r.d : v3(0.0f, 0.0f, 1.0f),
+                                    active ? r.maxT : 0.0f, 0xFFFFFFFFu, best, nv, nt, entered, own);
+    }
+    const uint32_t nRays = (uint32_t)__popcll(__ballot(active));
+    own = waveSum(active ? own : 0u);
+    if (laneId() == 0) {
+        if (nRays) atomicAdd(&probe[0], (unsigned long long)entered * nRays), atomicAdd(&probe[1], (unsigned long long)own);
+        __threadfence();
+        atomicAdd(&probe[2], 1ull);
+    }
+}
+
 // ------------------------------------------------------------------------------------------- shade
 #ifndef HR_SHADE_BLOCK
 #define HR_SHADE_BLOCK 256
@@ -1094,6 +1304,30 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, co
         hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
     else
         hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
+}
+
+void launchTracePrimary(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, const SegList &segs, const FrameDev &fr,
+                        Stats *stats)
+{
+    const int threads = ownedThreads(fr);
+    if (threads <= 0 || segs.n <= 0) return;
+    const dim3 grid((threads + kPacketBlock - 1) / kPacketBlock, segs.n);
+    if (cfg.collectStats)
+        hipLaunchKernelGGL(k_trace_primary<true>, grid, dim3(kPacketBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, stats);
+    else
+        hipLaunchKernelGGL(k_trace_primary<false>, grid, dim3(kPacketBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, stats);
+}
+
+// returns the number of waves launched: each adds one to probe[2] when it is done
+int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, const FrameDev &fr,
+                      unsigned long long *probe)
+{
+    const int threads = ownedThreads(fr);
+    if (threads <= 0) return 0;
+    const int packets = (threads + kPacketBlock - 1) / kPacketBlock;
+    const int grid = (packets + kProbeStride - 1) / kProbeStride;
+    hipLaunchKernelGGL(k_packet_probe, dim3(grid), dim3(kPacketBlock), 0, stream, S, nodes, tris, pp, fr, probe);
+    return grid;
 }
 
 template <int MODE> static void launchShadeHit(const LaunchCfg &cfg, int grid, const SceneDev *S, const StepTable *tbl, Stats *stats)

@@ -1392,6 +1392,35 @@ def test_step_log_resolved_counter_and_the_kernels_own_clock(golden):
     g.close()
 
 
+@pytest.mark.parametrize("tune", ["packets=2", "packets=1", "packets=0"])
+def test_camera_rays_as_packets_where_the_probe_says_so_same_bits_either_way(monkeypatch, golden, tune):
+    # hr_core.hip's packet selector: a pass's camera rays walk the tree 64 at a time (k_trace_primary) where a probe finds the rays of an
+    # 8x8 patch visiting nearly the same nodes — a box of large triangles — and one ray per lane where every ray meets its own leaves — a
+    # fog of triangles far smaller than a pixel patch.  Forced on, forced off or chosen: the frame is the oracle's, bit for bit.
+    monkeypatch.setenv("HR_TUNE", tune)
+    box = scenes.cornell_box(width=256, height=256, bounces=3, passes=40)
+    fog = scenes.triangle_soup(150000, width=384, height=256, bounces=3, passes=40, env=True)
+    for sc, wants_packets in ((box, True), (fog, False)):
+        g, o = core.create_engine(), oracle_lib.engine()
+        lut = golden["multiscatter_lut"]
+        sc.apply(g, lut=lut, tables=host_tables(sc)), sc.apply(o, lut=lut, tables=host_tables(sc))
+        n = 3 * g.pass_batch(sc.options.max_ray_depth) + 1  # (the probe of the first batch has reported by the third)
+        for s in range(n):
+            g.render_pass(sc.options.pass_params(s))
+        on, union = g.kernel_times()["camera_packets"]
+        if tune == "packets=2":
+            assert union > 1.0 and on == wants_packets and (union < 1.95) == wants_packets, (sc.name, on, union)
+        else:
+            assert on == (tune == "packets=1")
+        for s in range(min(n, 6)):
+            o.render_pass(sc.options.pass_params(s))
+        g.clear()
+        for s in range(min(n, 6)):
+            g.render_pass(sc.options.pass_params(s))
+        assert g.readback().tobytes() == o.readback().tobytes(), (sc.name, tune)
+        g.close(), o.close()
+
+
 def test_large_scene_3m_triangles(golden):
     # maximum-size end of the range (tools/big_scene_check.py goes to 30 M): device LBVH + collapse of 3 M triangles, hits against
     # the oracle's own tree and a render, bit for bit

@@ -51,6 +51,29 @@ KERNEL(k_cmp_u32_s, asm volatile("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(r
 KERNEL(k_rcp, asm volatile("v_rcp_f32 %0, %0" : "+v"(r[k])))
 KERNEL(k_ldexp, asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(r[k]) : "v"(a)))
 
+// round 4 (packet traversal): what moving a wave-uniform value costs
+KERNEL(k_readlane, { unsigned t; asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(t) : "v"(r[k])); asm volatile("" :: "s"(t)); })
+KERNEL(k_readlane_use, { unsigned t; asm volatile("v_readlane_b32 %0, %1, 5\n s_nop 3\n v_fma_f32 %1, %0, %2, %1" : "=&s"(t), "+v"(r[k]) : "v"(a)); })
+KERNEL(k_fma_sgpr, asm volatile("v_fma_f32 %0, %1, %0, %2" : "+v"(r[k]) : "s"(a), "v"(b)))
+KERNEL(k_cvt_ubyte_sgpr, asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(r[k]) : "s"(a)))
+__global__ __launch_bounds__(256) void k_lds_bcast(unsigned *out, unsigned a, unsigned b)
+{
+    __shared__ float4 tab[64];
+    tab[threadIdx.x & 63] = make_float4((float)threadIdx.x, 1.0f, 2.0f, 3.0f);
+    __syncthreads();
+    float4 acc = make_float4(0, 0, 0, 0);
+    unsigned idx = a & 7u; // wave-uniform address
+    for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            float4 v;
+            asm volatile("ds_read_b128 %0, %1 offset:%2\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(idx * 16u), "n"((j & 31) * 16));
+            acc.x += v.x;
+        }
+    }
+    if (acc.x == 12345.0f) out[0] = 1;
+}
+
 int main()
 {
     hipDeviceProp_t prop;
@@ -66,7 +89,7 @@ int main()
         {"v_cmp_le_f32", k_cmp}, {"v_lshl_or_b32", k_lshl_or}, {"v_cndmask_b32_e64 (sgpr mask)", k_cndmask_s}, {"v_cmp_lt_u32 + v_cndmask_b32 (pair)", k_cmp_cnd},
         {"v_min_f32", k_min_f32}, {"v_max_f32", k_max_f32}, {"v_min3_f32", k_min3_f32}, {"v_mov_b32", k_mov}, {"v_and_b32", k_and}, {"v_lshl_add_u32", k_lshl_add},
         {"v_sub_f32", k_sub_f32}, {"v_perm_b32", k_perm}, {"v_mad_u32_u24", k_mad_u24}, {"v_cmp_lt_u32_e64 (sgpr dst)", k_cmp_u32_s}, {"v_rcp_f32", k_rcp},
-        {"v_ldexp_f32", k_ldexp}};
+        {"v_ldexp_f32", k_ldexp}, {"v_readlane_b32 (sgpr dst)", k_readlane}, {"v_readlane_b32 + s_nop 3 + v_fma_f32 using it", k_readlane_use}, {"v_fma_f32 (one sgpr operand)", k_fma_sgpr}, {"v_cvt_f32_ubyte1 (sgpr source)", k_cvt_ubyte_sgpr}, {"ds_read_b128 uniform address + wait (64 per iteration = 1 op here)", k_lds_bcast}};
     // reference clock from the FMA kernel: 2 cycles per wave64 FMA with many waves resident (profiles/r2_calib_valu.json)
     printf("{\"cus\": %d, \"ops\": [", cus);
     double fmaNs = 0;
