@@ -797,7 +797,7 @@ struct LaneStack { // wave-uniform stack held in the LANES of three registers: e
     int r0, r1, r2;
     static HRD void writeLane(int &r, int v, int l) // (clang has no builtin for it; value and lane are wave-uniform)
     {
-        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(v), "s"(l) : "m0"); // (one SGPR operand per instruction: the lane goes through M0)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(r) : "s"(v), "s"(l) : "m0"); // (one SGPR operand per instruction: the lane goes through M0)
     }
     HRD void push(int sp, int v)
     {
