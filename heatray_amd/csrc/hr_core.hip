@@ -2024,7 +2024,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         if (wanted && stepIdx > 0) {
             int rc = waitCounts(c, G, prev, stepIdx); // (step stepIdx - 1 wrote stepIdx: its number + 1)
             if (rc) return rc;
-            if (g == 0 && c->probePending) { // complete once every wave of the probe has counted itself
+            if (g == 0 && c->probePending && stepIdx > c->probeStep) { // (steps from the probe's own on report the totals) complete once every wave of the probe has counted itself
                 const unsigned long long pk = G.hProbe[3 * prev], ry = G.hProbe[3 * prev + 1], done = G.hProbe[3 * prev + 2];
                 if (done - c->probeSeen[2] >= c->probeWaves) {
                     const unsigned long long dPk = pk - c->probeSeen[0], dRy = ry - c->probeSeen[1];
@@ -2155,7 +2155,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     }
     for (int j = 0; j < nInjectedSegs; ++j)
         if (packetsNow) tbl.seg[injectedSegs[j]].packets = 1;
-    tbl.probe = c->dProbe, tbl.hostProbe = G.dProbeHost + 3 * ring;
+    tbl.probe = c->dProbe, tbl.hostProbe = (g == 0 && (c->probePending || probeSeg >= 0)) ? G.dProbeHost + 3 * ring : nullptr; // (reported only while a probe is awaited)
     G.countN[ring] = n;
     tbl.hostCounts = G.dCounts + (size_t)ring * kMaxSegs, tbl.hostSeq = G.dSeq + ring, tbl.seqValue = stepIdx + 1ull;
     tbl.stepLog = c->dStepLog, tbl.nInjectedNow = (uint32_t)nInjected, tbl.padL = 0;
