@@ -1421,6 +1421,31 @@ def test_camera_rays_as_packets_where_the_probe_says_so_same_bits_either_way(mon
         g.close(), o.close()
 
 
+def test_packet_selector_follows_the_scene_on_one_context(golden):
+    # a commit makes the selector probe again: the same context goes from packets (a box of large triangles) to one ray per lane (a fog of
+    # tiny ones) and back, and renders the oracle's frame each time
+    box = scenes.cornell_box(width=256, height=256, bounces=2, passes=40)
+    fog = scenes.triangle_soup(150000, width=256, height=256, bounces=2, passes=40, env=True)
+    g = core.create_engine()
+    lut = golden["multiscatter_lut"]
+    for sc, wants_packets in ((box, True), (fog, False), (box, True)):
+        g.clear_scene()
+        sc.apply(g, lut=lut, tables=host_tables(sc))
+        n = 3 * g.pass_batch(sc.options.max_ray_depth) + 1
+        for s in range(n):
+            g.render_pass(sc.options.pass_params(s))
+        on, union = g.kernel_times()["camera_packets"]
+        assert on == wants_packets and (union < 1.95) == wants_packets, (sc.name, on, union)
+        o = oracle_lib.engine()
+        sc.apply(o, lut=lut, tables=host_tables(sc))
+        g.clear()
+        for s in range(4):
+            g.render_pass(sc.options.pass_params(s)), o.render_pass(sc.options.pass_params(s))
+        assert g.readback().tobytes() == o.readback().tobytes(), sc.name
+        o.close()
+    g.close()
+
+
 def test_large_scene_3m_triangles(golden):
     # maximum-size end of the range (tools/big_scene_check.py goes to 30 M): device LBVH + collapse of 3 M triangles, hits against
     # the oracle's own tree and a render, bit for bit
