@@ -45,6 +45,29 @@ def test_struct_sizes_match_the_c_layout():
     assert ctypes.sizeof(ffi.Hit) == 16
 
 
+def test_every_mirrored_struct_has_the_size_and_field_offsets_gcc_gives_the_header(tmp_path):
+    # the ctypes mirrors against the header itself: a C program prints sizeof and the offset of every field the mirror names
+    import subprocess
+    pairs = [("hr_ctx_desc", ffi.CtxDesc), ("hr_mesh_desc", ffi.MeshDesc), ("hr_scene_info", ffi.SceneInfo), ("hr_texture_desc", ffi.TextureDesc),
+             ("hr_material", ffi.Material), ("hr_lights", ffi.Lights), ("hr_pass_params", ffi.PassParams), ("hr_pass_stats", ffi.PassStats),
+             ("hr_kernel_times", ffi.KernelTimes), ("hr_step_record", ffi.StepRecord), ("hr_display_params", ffi.DisplayParams), ("hr_hit", ffi.Hit)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "hrcore.h"', "int main(void) {"]
+    for cname, mirror in pairs:
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True, capture_output=True, text=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, mirror in pairs:
+        assert int(got[cname]) == ctypes.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(mirror, fname).offset, (cname, fname)
+
+
 def test_no_device_means_loud_failure():
     import torch
     if torch.cuda.is_available():
