@@ -271,7 +271,7 @@ struct hr_ctx {
     // packets are used while U < punion / 100 (c1 1.2, c2 1.5: win; c3 3.0, terrain 6.6: lose; profiles/r4u_packets.txt).  The totals
     // come back with the queue lengths k_trace reports (no synchronisation).  Either way the hits are the same bits.
     int tunePackets = 2;   // HR_TUNE="packets=0|1|2": never / always / by the probe (default)
-    int tunePacketUnion = 195; // HR_TUNE="punion=N": packets while U < N / 100
+    int tunePacketUnion = 220; // HR_TUNE="punion=N": packets while U < N / 100 (measured break-even ~2.3: terrain at 1.97 +7..11 %, c5 at 2.07 +3..4 %)
     bool packetsOn = false;
     int probeCountdown = 0;              // injecting steps until the next probe
     bool probePending = false;
@@ -1916,6 +1916,8 @@ static int waitCounts(hr_ctx *c, hr_ctx::Group &G, int ring, unsigned long long 
 // One macro step of pipeline group g: (raygen of the injected passes) -> trace of every in-flight pass of the group ->
 // shade; passes whose last stage this was become `finished`.
 static const int kProbeEvery = 64; // injecting steps between two probes of the packet selector
+static int packetLog2(const hr_ctx *c);
+static bool packetsInUse(const hr_ctx *c);
 static int macroStep(hr_ctx *c, int g, int nInject)
 {
     hr_ctx::Group &G = c->groups[g];
@@ -2138,8 +2140,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     if (nInjectedSegs > 0) tbl.primaryFromSeg = injectedSegs[0]; // (the table is in pass order: the passes injected now are its last entries)
     // packet selector (above): which of the injected passes' camera rays go through k_trace_primary, and is one of them this step's probe?
     int probeSeg = -1;
-    bool packetsNow = c->tunePackets == 1 || (c->tunePackets == 2 && c->packetsOn);
-    if (c->tunePackets == 2 && g == 0 && nInjectedSegs > 0 && !c->probePending) {
+    bool packetsNow = packetsInUse(c) && nInjectedSegs > 0 && tbl.seg[injectedSegs[0]].pp.interactive_mode == 0; // (interactive sub-passes of one sample share no pixels)
+    if (c->tunePackets == 2 && g == 0 && nInjectedSegs > 0 && !c->probePending && tbl.seg[injectedSegs[0]].pp.interactive_mode == 0) {
         const hr_pass_params &pp = tbl.seg[injectedSegs[0]].pp;
         float cam[21] = {pp.fov_tan, pp.aspect_ratio, pp.focus_distance, pp.aperture_radius};
         std::memcpy(cam + 4, pp.view_matrix, sizeof(pp.view_matrix));
@@ -2166,7 +2168,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     G.tableUsed[ring] = true;
     if (c->pending.size() > 8192) c->drainTimes();
     bool timing = false; // (the kernels of a step are enqueued back to back: n + 1 timing events for n kernels)
-    for (int j0 = 0; j0 < nInjectedSegs; j0 += kMaxBatch) { // one launch for the passes injected this step
+    for (int j0 = 0; j0 < nInjectedSegs && !packetsNow; j0 += kMaxBatch) { // one launch for the passes injected this step (as packets: below, with their traversal)
         SegList segs{};
         for (int j = j0; j < nInjectedSegs && segs.n < kMaxBatch; ++j) segs.seg[segs.n++] = injectedSegs[j];
         if (timing)
@@ -2184,15 +2186,18 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         // (probeSeen holds the totals of the report the previous decision was taken on: probes never overlap, that probe was complete)
         HIP_TRY(c, hipEventRecord(c->evProbeA, G.stream));
         HIP_TRY(c, hipStreamWaitEvent(c->probeStream, c->evProbeA, 0));
-        c->probeWaves = (unsigned long long)launchPacketProbe(c->probeStream, c->dScene, c->nodes, c->tris, tbl.seg[probeSeg].pp, fr, c->dProbe);
+        c->probeWaves = (unsigned long long)launchPacketProbe(c->probeStream, c->dScene, c->nodes, c->tris, tbl.seg[probeSeg].pp, packetLog2(c), fr, c->dProbe);
         HIP_TRY(c, hipEventRecord(c->evProbeB, c->probeStream));
         c->probeGuard = true, c->probePending = true, c->probeStep = stepIdx, c->probeCountdown = kProbeEvery;
     }
     if (packetsNow)
-        for (int j0 = 0; j0 < nInjectedSegs; j0 += kMaxBatch) {
+        for (int j0 = 0; j0 < nInjectedSegs;) { // the injected passes in groups of 16, 8, 4, 2, 1: ray generation and the camera rays' traversal in one launch each
+            int take = 1;
+            while (2 * take <= nInjectedSegs - j0 && 2 * take <= kMaxBatch) take *= 2;
             SegList segs{};
-            for (int j = j0; j < nInjectedSegs && segs.n < kMaxBatch; ++j) segs.seg[segs.n++] = injectedSegs[j];
-            launchTracePrimary(cfg, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
+            for (int j = j0; j < j0 + take; ++j) segs.seg[segs.n++] = injectedSegs[j];
+            launchRaygenPackets(cfg, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
+            j0 += take;
         }
     launchTrace(cfg, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
     c->timeNext(HR_KERNEL_SHADE, G.stream);
@@ -2258,9 +2263,26 @@ static int injectBatch(hr_ctx *c, int n, int perGroupLimit)
     return macroStep(c, g, n);
 }
 
+// Passes injected together when their camera rays travel as packets: a wave holds 2^k passes of 64 >> k pixels (hr_render.hip:
+// k_raygen_packets), so the batch is the power of two next to the usual one (12 -> 16, 3 -> 4, 5 -> 4), sixteen per launch at most.
+static int packetBatch(const hr_ctx *c)
+{
+    const int b = c->injectBatch < 1 ? 1 : c->injectBatch;
+    int up = 1;
+    while (up < b) up <<= 1;
+    return (4 * b >= 3 * up) ? up : up / 2;
+}
+static int packetLog2(const hr_ctx *c)
+{
+    int k = 0;
+    while ((2 << k) <= packetBatch(c) && k < 4) ++k;
+    return k;
+}
+static bool packetsInUse(const hr_ctx *c) { return c->tunePackets == 1 || (c->tunePackets == 2 && c->packetsOn); }
+
 static int batchFor(const hr_ctx *c, int stages)
 {
-    int batch = c->injectBatch;
+    int batch = packetsInUse(c) ? packetBatch(c) : c->injectBatch;
     int perGroup = slotLimit(c) / c->nGroups;
     if (perGroup > kMaxSegs) perGroup = kMaxSegs;
     if (batch * stages > perGroup) batch = perGroup / stages;
@@ -2428,7 +2450,7 @@ int hr_get_kernel_times(hr_ctx *c, hr_kernel_times *out)
     for (const Stats &p : parts) ticks += p.traceTicks, launches += p.traceLaunches;
     out->trace_clock_ms = (float)((double)ticks * 1e-5); // 100 MHz: 10 ns per tick
     out->trace_clock_launches = (uint32_t)launches;
-    out->camera_packets = (c->tunePackets == 1 || (c->tunePackets == 2 && c->packetsOn)) ? 1u : 0u;
+    out->camera_packets = packetsInUse(c) ? (uint32_t)packetBatch(c) : 0u;
     out->packet_union = (float)c->lastUnion;
     return HR_OK;
 }

@@ -129,9 +129,9 @@ void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &
 void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *frame, float *packed, int unpack, float *full);
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out);
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
-void launchTracePrimary(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, const SegList &segs, const FrameDev &fr,
-                        Stats *stats);
-int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, const FrameDev &fr,
+void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, const SegList &segs, const FrameDev &fr,
+                         Stats *stats); // segs.n: a power of two
+int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, int passesLog2, const FrameDev &fr,
                       unsigned long long *probe);
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,

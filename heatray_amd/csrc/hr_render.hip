@@ -918,37 +918,83 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
     }
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kPacketBlock) void k_trace_primary(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
-                                                               StepTable *__restrict__ tbl, SegList segs, Stats *stats)
+// pixel j (Morton order: 2x2, 4x2, 4x4 ... blocks are contiguous ranges) of an 8x8 patch
+HRD uint32_t mortonPixel(uint32_t j)
 {
+    const uint32_t px = (j & 1u) | ((j >> 1) & 2u) | ((j >> 2) & 4u), py = ((j >> 1) & 1u) | ((j >> 2) & 2u) | ((j >> 3) & 4u);
+    return py * 8u + px;
+}
+
+// Ray generation and the camera rays' traversal in one kernel, for 2^passesLog2 passes injected together (segs.n of them): a wave is
+// the rays of (64 >> passesLog2) neighbouring pixels — a 2x2 block for sixteen passes, the 8x8 patch for one — in all these passes.
+// The rays a pixel sends in consecutive passes differ by the sub-pixel jitter (and the lens sample) only: no other 64 rays of a
+// render are as close to each other, and the packet's union of node sets shrinks accordingly (c3, the triangle fog: 3.0 x its rays'
+// own node tests for one pass of an 8x8 patch, 1.8 x for sixteen passes of 2x2 pixels; profiles/r4u_packets.txt).  Everything
+// k_raygen does happens here the same way (perspective.rlsl, the pass sample's zero, the root cull with its miss shader); queue slots
+// are reserved per pass and workgroup through LDS counters.  k_trace leaves these passes' first-stage queues alone (SegDev::packets).
+static const int kRpBlock = 256;
+template <bool STATS>
+__global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
+                                                            StepTable *__restrict__ tbl, SegList segs, int passesLog2, FrameDev fr, Stats *stats)
+{
+    __shared__ uint32_t cnt[kMaxBatch], firstSlot[kMaxBatch];
     const SceneDev &S = *Sp;
-    const SegDev &sg = tbl->seg[segs.seg[blockIdx.y]];
     // this launch is the front part of the step's trace: its first waves' start is the start of the step's k_trace launch on the
-    // device clock (StepTable::clkStart; hr_get_step_log and the HIP-event bucket HR_KERNEL_TRACE then cover the same two kernels)
-    if (blockIdx.y == 0 && blockIdx.x < (uint32_t)kClkSlots && threadIdx.x == 0)
+    // device clock (StepTable::clkStart; hr_get_step_log and the HIP-event bucket HR_KERNEL_TRACE then cover the same kernels)
+    if (blockIdx.x < (uint32_t)kClkSlots && threadIdx.x == 0)
         __hip_atomic_fetch_min(&tbl->clkStart[blockIdx.x], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t n = *sg.qCountIn;
-    const uint32_t lane = laneId();
-    const uint32_t base = blockIdx.x * 64u;
-    if (base >= n) return;
+    if (threadIdx.x < (uint32_t)kMaxBatch) cnt[threadIdx.x] = 0u;
     stats += blockIdx.x & (kStatSlots - 1);
-    const bool valid = base + lane < n;
-    const uint32_t local = valid ? base + lane : n - 1u;
-    const float4 ra = G(sg.qin.A)[local], rb = G(sg.qin.B)[local];
-    const uint32_t skipPrim = (uint32_t)G(sg.qin.D)[local].z;
+    const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    const uint32_t nPass = 1u << passesLog2, pass = lane & (nPass - 1u), npx = 64u >> passesLog2;
+    const uint32_t m = (blockIdx.x * (uint32_t)(kRpBlock / 64) + wave) * npx + (lane >> passesLog2); // owned pixel, patches in Morton order
+    const SegDev &seg = tbl->seg[segs.seg[pass]];
+    int x = 0, y = 0;
+    const bool inFrame = ownedPixel(fr, (m & ~63u) + mortonPixel(m & 63u), x, y);
+    const uint32_t pixel = (uint32_t)(y * fr.W + x);
+    Ray r;
+    r.valid = false;
+    bool active = inFrame;
+    if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
+    if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
+    if (inFrame && seg.passbufB) {
+        const size_t framePixels = (size_t)(seg.passbufB - seg.passbuf) >> 2;
+        for (int j = 1; j <= 3; ++j) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel + j * framePixels] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    bool enqueue = active; // (k_raygen's root cull, same decision, same miss shader)
+    uint32_t nAcc = 0;
+    if (active && S.nTris > 0 && S.rootLeafCount == 0 && rootMissed(S.nodes, r.o, r.d, S.rayEps, r.maxT)) {
+        enqueue = false;
+        if (r.missKind == MISS_ENV) {
+            ShaderT<0> sh(S, seg.pp, G(seg.passbuf) + (size_t)pixel * 4);
+            sh.performAccumulate(sh.environmentRadiance(r.d, r.weight));
+            nAcc = sh.nAccum;
+        }
+    }
+    __syncthreads();
+    const uint32_t rank = enqueue ? atomicAdd(&cnt[pass], 1u) : 0u;
+    __syncthreads();
+    if (threadIdx.x < nPass) firstSlot[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(tbl->seg[segs.seg[threadIdx.x]].qCountIn, cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+    const uint32_t slot = firstSlot[pass] + rank;
+    if (enqueue) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
+    const unsigned long long enqMask = __ballot(enqueue);
+    const uint32_t n = waveSum(active ? 1u : 0u), nEnq = (uint32_t)__popcll(enqMask);
+    nAcc = waveSum(nAcc);
+    if (lane == 0) {
+        if (n) atomicAdd(&stats->paths, (unsigned long long)n);
+        if (n) atomicAdd(&stats->raysClosest, (unsigned long long)n); // (the culled ones were traced by the root test, the others are traced below)
+        if (nAcc) atomicAdd(&stats->accumulates, (unsigned long long)nAcc);
+    }
+    if (enqMask == 0ull) return;
     HitRec best;
     uint32_t nv = 0, nt = 0, entered = 0, own = 0;
-    packetTraverse<STATS, false>(S, (ConstNodes)(uintptr_t)nodesG, (ConstTris)(uintptr_t)trisG, v3(ra.x, ra.y, ra.z), v3(rb.x, rb.y, rb.z), valid ? ra.w : 0.0f, skipPrim,
-                                 best, nv, nt, entered, own);
-    if (valid) G(sg.hits)[local] = best;
-    const uint32_t nValidLanes = (uint32_t)__popcll(__ballot(valid));
-    if (lane == 0) {
-        atomicAdd(&stats->raysClosest, (unsigned long long)nValidLanes);
-        if (STATS) { // per ray: the node steps and triangle tests its lane executed (the packet's union, not the ray's own set)
-            atomicAdd(&stats->nodeVisits, (unsigned long long)nv * nValidLanes);
-            atomicAdd(&stats->triTests, (unsigned long long)nt * nValidLanes);
-        }
+    packetTraverse<STATS, false>(S, (ConstNodes)(uintptr_t)nodesG, (ConstTris)(uintptr_t)trisG, enqueue ? r.o : v3(0.0f), enqueue ? r.d : v3(0.0f, 0.0f, 1.0f),
+                                 enqueue ? r.maxT : 0.0f, 0xFFFFFFFFu, best, nv, nt, entered, own);
+    if (enqueue) G(seg.hits)[slot] = best;
+    if (STATS && lane == 0) { // per ray: the node steps and triangle tests its lane executed (the packet's union, not the ray's own set)
+        atomicAdd(&stats->nodeVisits, (unsigned long long)nv * nEnq);
+        atomicAdd(&stats->triTests, (unsigned long long)nt * nEnq);
     }
 }
 
@@ -957,11 +1003,15 @@ __global__ __launch_bounds__(kPacketBlock) void k_trace_primary(const SceneDev *
 // probe[0] += children the packet entered x its rays, probe[1] += children the rays' own box tests entered, probe[2] += 1 per wave.
 static const int kProbeStride = 32;
 __global__ __launch_bounds__(kPacketBlock) void k_packet_probe(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
-                                                              hr_pass_params pp, FrameDev fr, unsigned long long *probe)
+                                                              hr_pass_params pp, int passesLog2, FrameDev fr, unsigned long long *probe)
 {
     const SceneDev &S = *Sp;
     int x = 0, y = 0;
-    const bool inFrame = ownedPixel(fr, blockIdx.x * 64u * (uint32_t)kProbeStride + threadIdx.x, x, y);
+    // the wave's 64 rays: 2^passesLog2 consecutive passes of 64 >> passesLog2 neighbouring pixels (0: one pass of an 8x8 patch)
+    const uint32_t lane = threadIdx.x, pass = lane & ((1u << passesLog2) - 1u), pix = lane >> passesLog2, npx = 64u >> passesLog2;
+    const uint32_t group = blockIdx.x & ((1u << passesLog2) - 1u); // which of the patch's pixel groups this wave samples
+    pp.sample_index += (int)pass;
+    const bool inFrame = ownedPixel(fr, blockIdx.x * 64u * (uint32_t)kProbeStride + mortonPixel(group * npx + pix), x, y);
     Ray r;
     r.valid = false;
     bool active = inFrame;
@@ -1306,27 +1356,30 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, co
         hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
 }
 
-void launchTracePrimary(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, const SegList &segs, const FrameDev &fr,
-                        Stats *stats)
+void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, const SegList &segs, const FrameDev &fr,
+                         Stats *stats)
 {
     const int threads = ownedThreads(fr);
     if (threads <= 0 || segs.n <= 0) return;
-    const dim3 grid((threads + kPacketBlock - 1) / kPacketBlock, segs.n);
+    int passesLog2 = 0;
+    while ((2 << passesLog2) <= segs.n) ++passesLog2; // (the caller passes a power of two)
+    const int pixelsPerBlock = (kRpBlock / 64) * (64 >> passesLog2);
+    const dim3 grid((threads + pixelsPerBlock - 1) / pixelsPerBlock);
     if (cfg.collectStats)
-        hipLaunchKernelGGL(k_trace_primary<true>, grid, dim3(kPacketBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, stats);
+        hipLaunchKernelGGL(k_raygen_packets<true>, grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
     else
-        hipLaunchKernelGGL(k_trace_primary<false>, grid, dim3(kPacketBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, stats);
+        hipLaunchKernelGGL(k_raygen_packets<false>, grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
 }
 
 // returns the number of waves launched: each adds one to probe[2] when it is done
-int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, const FrameDev &fr,
+int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, int passesLog2, const FrameDev &fr,
                       unsigned long long *probe)
 {
     const int threads = ownedThreads(fr);
     if (threads <= 0) return 0;
     const int packets = (threads + kPacketBlock - 1) / kPacketBlock;
     const int grid = (packets + kProbeStride - 1) / kProbeStride;
-    hipLaunchKernelGGL(k_packet_probe, dim3(grid), dim3(kPacketBlock), 0, stream, S, nodes, tris, pp, fr, probe);
+    hipLaunchKernelGGL(k_packet_probe, dim3(grid), dim3(kPacketBlock), 0, stream, S, nodes, tris, pp, passesLog2, fr, probe);
     return grid;
 }
 
