@@ -219,7 +219,7 @@ def pmc_legs(args, keep_dir=None):
         trace_ids = sorted({r_[0] for r_ in rows if r_[1] == "k_trace"})
         first = trace_ids[-n_trace] if 0 < n_trace <= len(trace_ids) else (trace_ids[0] if trace_ids else 0)
         # the timed region starts with the ray generation of its first macro step, launched right before that k_trace
-        gens = [r_[0] for r_ in rows if r_[1] == "k_raygen" and r_[0] < first and r_[0] > (trace_ids[-n_trace - 1] if n_trace < len(trace_ids) else -1)]
+        gens = [r_[0] for r_ in rows if r_[1] in ("k_raygen", "k_raygen_packets") and r_[0] < first and r_[0] > (trace_ids[-n_trace - 1] if n_trace < len(trace_ids) else -1)]
         start = min(gens) if gens else first
         res["passes"][name] = {"rays": cj["extra"]["rays"], "steps": cj["steps"], "warmup": cj["warmup"], "counters": ctrs, "k_trace_launches_counted": n_trace,
                                "dispatches_in_process": len({r_[0] for r_ in rows}), "dispatches_counted": len({r_[0] for r_ in rows if r_[0] >= start})}
@@ -627,7 +627,11 @@ def main():
             src = None
             per_ray = per_ray_all = valu_per_ray = None
             if pmc and not pmc.get("failed"):
-                kt_c = pmc["kernels"].get("k_trace", {})
+                # the traversal: k_trace, and with it k_raygen_packets when the selector sends the camera rays that way (ray generation fused in)
+                kt_own = pmc["kernels"].get("k_trace", {})
+                kt_c = dict(kt_own)
+                for ck, cv_ in pmc["kernels"].get("k_raygen_packets", {}).items():
+                    kt_c[ck] = kt_c.get(ck, 0.0) + cv_
                 rays_f, rays_w = pmc["passes"]["fetch"]["rays"], pmc["passes"]["write"]["rays"]
                 if "FETCH_SIZE" in kt_c and "WRITE_SIZE" in kt_c:
                     # FETCH_SIZE / WRITE_SIZE are in KiB; + half of the streamed queue reads (48 B per ray) that FETCH_SIZE under-counts
@@ -654,11 +658,14 @@ def main():
                 traffic_run = per_ray * run_rays
                 achieved = traffic_run / wall_s / 1e9
                 roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": traffic_run / n_trace, "kernel": "k_trace",
+                            "traffic": traffic_run / n_trace, "kernel": "k_trace" if not camera_packets[0] else "k_trace + k_raygen_packets (the traversal: camera rays as packets, the rest one ray per lane)",
                             "definition": "counter-based: (FETCH_SIZE + WRITE_SIZE + half the streamed 48 B/ray queue reads) per ray x rays of the timed "
                                           "region / wall time of the timed region; includes Infinity-Cache hits (upper bound of HBM bytes)",
                             "traffic_source": src, "hbm_side_bytes_per_ray": per_ray, "wall_ms": wall_s * 1e3,
-                            "avg_launch_ms": avg_ms, "launches": n_trace, "rays_per_launch": run_rays / n_trace,
+                            "avg_launch_ms": avg_ms, "launches": n_trace, "rays_per_launch": (run_rays - (float(st.paths) if camera_packets[0] else 0.0)) / n_trace,
+                            "camera_packet_launches": None if not (camera_packets[0] and kt["raygen"][1]) else {"kernel": "k_raygen_packets", "launches": kt["raygen"][1], "avg_launch_ms": kt["raygen"][0] / max(kt["raygen"][1], 1),
+                                                                                         "rays_per_launch": float(st.paths) / max(kt["raygen"][1], 1),
+                                                                                         "note": "HIP events; ray generation and the camera rays' traversal; avg_launch_ms / launches / rays_per_launch above are k_trace's own"},
                             "avg_launch_ms_source": "HIP events on the kernel's stream" if time_kernels else "device clock read inside k_trace (no events on the stream)",
                             "avg_launch_ms_device_clock": trace_clock[0] / max(trace_clock[1], 1),
                             "kernel_time_over_wall_time": sum(v[0] for v in kt.values()) / (wall_s * 1e3)}
@@ -681,13 +688,18 @@ def main():
                                         "note": "issue-rate ceiling of plain FMAs at the calibrated clock; the instruction mix of k_trace occupies a SIMD "
                                                 "for 3.3-4 cycles per instruction (tools/calib_ops.hip) at a shader clock of ~2.3 GHz (tools/tailprof.py): see `units` for busy fractions"}
                 if pmc and not pmc.get("failed") and "rays" in pmc["passes"].get("units", {}):
-                    ku = pmc["kernels"].get("k_trace", {})
+                    ku = dict(pmc["kernels"].get("k_trace", {}))
+                    for ck, cv_ in pmc["kernels"].get("k_raygen_packets", {}).items():
+                        ku[ck] = ku.get(ck, 0.0) + cv_
                     if ku.get("GRBM_GUI_ACTIVE") and ku.get("TA_TA_BUSY_sum") is not None:
                         n_xcd = 8.0   # GRBM_GUI_ACTIVE is reported summed over the XCDs; TA counters over the CUs; SQ_ACTIVE_* in quad-cycles
                         n_cus = float(getattr(torch.cuda.get_device_properties(dev), "multi_processor_count", 256))
                         cyc = ku["GRBM_GUI_ACTIVE"] / n_xcd
                         roofline["units"] = {
-                            "kernel": "k_trace", "kernel_cycles": cyc,
+                            "kernel": "k_trace" if not camera_packets[0] else "k_trace + k_raygen_packets", "kernel_cycles": cyc,
+                            "per_kernel": {kn: {"cycles": kd["GRBM_GUI_ACTIVE"] / n_xcd, "ta_busy": kd.get("TA_TA_BUSY_sum", 0.0) / n_cus / (kd["GRBM_GUI_ACTIVE"] / n_xcd),
+                                                "valu_busy": kd.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_cus * 4.0) / (kd["GRBM_GUI_ACTIVE"] / n_xcd)}
+                                           for kn, kd in pmc["kernels"].items() if kn in ("k_trace", "k_raygen_packets") and kd.get("GRBM_GUI_ACTIVE")},
                             "ta_busy": ku["TA_TA_BUSY_sum"] / n_cus / cyc,
                             "valu_busy": ku.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_cus * 4.0) / cyc,
                             "ta_wave_loads_per_ray": ku.get("TA_FLAT_READ_WAVEFRONTS_sum", 0.0) / pmc["passes"]["units"]["rays"],
@@ -791,7 +803,8 @@ def main():
             "passes_to_converge": conv,
             "extra": {"rays": total_rays, "paths_per_s": total_paths / elapsed, "closest_rays": total_closest,
                       "rays_per_path": total_rays / max(total_paths, 1.0), "bvh_build_ms": info.build_ms,
-                      "camera_rays": {"traced_as": "packets" if camera_packets[0] else "one ray per lane", "packet_union": round(camera_packets[1], 3)},
+                      "camera_rays": {"traced_as": f"packets of {int(camera_packets[2])} passes x {64 // max(int(camera_packets[2]), 1)} pixels" if camera_packets[0] else "one ray per lane",
+                                      "packet_union": round(camera_packets[1], 3)},
                       "kernel_ms_rank0": {k: v[0] for k, v in kt.items()}, "kernel_launches_rank0": {k: v[1] for k, v in kt.items()},
                       "display_resolve_ms_rgba8": disp_ms,
                       "gpu_traversal_counters": gpu_counts},

@@ -380,7 +380,7 @@ class Engine:
         self._call("get_kernel_times", C.byref(t))
         d = {n: (t.ms[i], t.launches[i]) for i, n in enumerate(HR_KERNEL_NAMES)}
         d["trace_clock"] = (t.trace_clock_ms, t.trace_clock_launches)
-        d["camera_packets"] = (bool(t.camera_packets), t.packet_union)  # (how camera rays are traced now, the probe's union factor)
+        d["camera_packets"] = (bool(t.camera_packets), t.packet_union, t.camera_packets)  # (camera rays as packets now?, the probe's union factor, passes per packet)
         return d
 
     def step_log(self, capacity=4096):

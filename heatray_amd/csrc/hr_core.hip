@@ -2168,15 +2168,26 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     G.tableUsed[ring] = true;
     if (c->pending.size() > 8192) c->drainTimes();
     bool timing = false; // (the kernels of a step are enqueued back to back: n + 1 timing events for n kernels)
-    for (int j0 = 0; j0 < nInjectedSegs && !packetsNow; j0 += kMaxBatch) { // one launch for the passes injected this step (as packets: below, with their traversal)
+    for (int j0 = 0; j0 < nInjectedSegs;) { // one launch for the passes injected this step
+        // (as packets: ray generation and the camera rays' traversal in one launch per group of 16, 8, 4, 2, 1 passes — the bucket
+        // HR_KERNEL_RAYGEN then holds both, HR_KERNEL_TRACE and the step's device clock stay k_trace's own)
+        int take = 1;
+        if (packetsNow)
+            while (2 * take <= nInjectedSegs - j0 && 2 * take <= kMaxBatch) take *= 2;
+        else
+            take = nInjectedSegs - j0 < kMaxBatch ? nInjectedSegs - j0 : kMaxBatch;
         SegList segs{};
-        for (int j = j0; j < nInjectedSegs && segs.n < kMaxBatch; ++j) segs.seg[segs.n++] = injectedSegs[j];
+        for (int j = j0; j < j0 + take; ++j) segs.seg[segs.n++] = injectedSegs[j];
+        j0 += take;
         if (timing)
             c->timeNext(HR_KERNEL_RAYGEN, G.stream);
         else
             c->timeBegin(HR_KERNEL_RAYGEN, G.stream);
         timing = true;
-        launchRaygen(cfg, c->dScene, dTbl, segs, fr, c->dStats);
+        if (packetsNow)
+            launchRaygenPackets(cfg, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
+        else
+            launchRaygen(cfg, c->dScene, dTbl, segs, fr, c->dStats);
     }
     if (timing)
         c->timeNext(HR_KERNEL_TRACE, G.stream);
@@ -2190,15 +2201,6 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         HIP_TRY(c, hipEventRecord(c->evProbeB, c->probeStream));
         c->probeGuard = true, c->probePending = true, c->probeStep = stepIdx, c->probeCountdown = kProbeEvery;
     }
-    if (packetsNow)
-        for (int j0 = 0; j0 < nInjectedSegs;) { // the injected passes in groups of 16, 8, 4, 2, 1: ray generation and the camera rays' traversal in one launch each
-            int take = 1;
-            while (2 * take <= nInjectedSegs - j0 && 2 * take <= kMaxBatch) take *= 2;
-            SegList segs{};
-            for (int j = j0; j < j0 + take; ++j) segs.seg[segs.n++] = injectedSegs[j];
-            launchRaygenPackets(cfg, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
-            j0 += take;
-        }
     launchTrace(cfg, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
     c->timeNext(HR_KERNEL_SHADE, G.stream);
     launchShade(cfg, c->dScene, dTbl, c->dStats);

@@ -935,14 +935,10 @@ HRD uint32_t mortonPixel(uint32_t j)
 static const int kRpBlock = 256;
 template <bool STATS>
 __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
-                                                            StepTable *__restrict__ tbl, SegList segs, int passesLog2, FrameDev fr, Stats *stats)
+                                                            const StepTable *__restrict__ tbl, SegList segs, int passesLog2, FrameDev fr, Stats *stats)
 {
     __shared__ uint32_t cnt[kMaxBatch], firstSlot[kMaxBatch];
     const SceneDev &S = *Sp;
-    // this launch is the front part of the step's trace: its first waves' start is the start of the step's k_trace launch on the
-    // device clock (StepTable::clkStart; hr_get_step_log and the HIP-event bucket HR_KERNEL_TRACE then cover the same kernels)
-    if (blockIdx.x < (uint32_t)kClkSlots && threadIdx.x == 0)
-        __hip_atomic_fetch_min(&tbl->clkStart[blockIdx.x], wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < (uint32_t)kMaxBatch) cnt[threadIdx.x] = 0u;
     stats += blockIdx.x & (kStatSlots - 1);
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
@@ -1356,8 +1352,8 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, co
         hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
 }
 
-void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, const SegList &segs, const FrameDev &fr,
-                         Stats *stats)
+void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, const StepTable *tbl, const SegList &segs,
+                         const FrameDev &fr, Stats *stats)
 {
     const int threads = ownedThreads(fr);
     if (threads <= 0 || segs.n <= 0) return;

@@ -385,11 +385,12 @@ typedef struct hr_pass_stats {
  * the stream, which a small tile shard's dependent launches feel), trace_clock_* from the constant 100 MHz device clock
  * read inside k_trace itself (first workgroup's start to last workgroup's end; always on, nothing on the stream).
  * OpenRL's counterpart: RL_RENDER_FRAME_TIME / RL_PROFILE (rl.h:346-355), which Heatray never queries.
- * camera_packets / packet_union: a pass's camera rays (perspective.rlsl:39-93: 8x8-pixel patches per wave) are either traced like
- * every other ray or, where a probe finds the 64 rays of a patch walking nearly the same nodes, as one packet per wave (one node fetch
- * and one stack for 64 rays); the probe runs beside the pipeline after a commit, a resize, a change of camera and every 64th batch.
+ * camera_packets / packet_union: the camera rays (perspective.rlsl:39-93) of the passes injected together are either traced like
+ * every other ray or, where a probe finds the rays of a few neighbouring pixels in these passes walking nearly the same nodes, as one
+ * packet per wave (one node fetch and one stack for 64 rays; ray generation and this traversal are then one kernel, timed under
+ * HR_KERNEL_RAYGEN); the probe runs beside the pipeline after a commit, a resize, a change of camera and every 64th batch.
  * The hits — and so the image — are the same bits either way. */
-#define HR_KERNEL_RAYGEN 0
+#define HR_KERNEL_RAYGEN 0  /* ray generation; with camera_packets, the camera rays' traversal too */
 #define HR_KERNEL_TRACE 1   /* closest-hit + occlusion traversal (one kernel) */
 #define HR_KERNEL_SHADE 2
 #define HR_KERNEL_RESOLVE 3 /* finished pass samples -> accumulation buffer */
@@ -400,7 +401,7 @@ typedef struct hr_kernel_times {
     float trace_clock_ms;          /* k_trace (with the packet kernel in front of it, when camera rays go that way), device clock */
     uint32_t trace_clock_launches;
     /* how the camera rays are traced at the moment (chosen by a measurement, see below) and the measurement itself */
-    uint32_t camera_packets;       /* 1: 64 camera rays walk the tree as one packet; 0: one ray per lane like every other ray */
+    uint32_t camera_packets;       /* n > 0: 64 camera rays — n passes of 64 / n neighbouring pixels — walk the tree as one packet; 0: one ray per lane like every other ray */
     float packet_union;            /* last probe: node tests a packet makes per ray / node tests the ray's own traversal needs (0: no probe yet) */
 } hr_kernel_times;
 

@@ -1408,7 +1408,7 @@ def test_camera_rays_as_packets_where_the_probe_says_so_same_bits_either_way(mon
         n = 3 * g.pass_batch(sc.options.max_ray_depth) + 1  # (the probe of the first batch has reported by the third)
         for s in range(n):
             g.render_pass(sc.options.pass_params(s))
-        on, union = g.kernel_times()["camera_packets"]
+        on, union, _ = g.kernel_times()["camera_packets"]
         if tune.startswith("packets=2"):
             limit = 1.01 if "punion" in tune else 2.2
             assert union > 1.0 and on == (union < limit), (sc.name, on, union)
@@ -1440,7 +1440,7 @@ def test_packet_selector_follows_the_scene_on_one_context(monkeypatch, golden):
         n = 3 * g.pass_batch(sc.options.max_ray_depth) + 1
         for s in range(n):
             g.render_pass(sc.options.pass_params(s))
-        on, union = g.kernel_times()["camera_packets"]
+        on, union, _ = g.kernel_times()["camera_packets"]
         assert on == wants_packets and (union < 1.15) == wants_packets, (sc.name, on, union)
         o = oracle_lib.engine()
         sc.apply(o, lut=lut, tables=host_tables(sc))
