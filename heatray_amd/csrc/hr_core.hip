@@ -158,6 +158,8 @@ struct hr_ctx {
         volatile unsigned long long *hSeq = nullptr;   // [kTableRing], pinned: step number + 1 whose lengths the entry holds
         uint32_t *dCounts = nullptr;                   // the same two arrays as the device addresses them
         unsigned long long *dSeq = nullptr;
+        hipStream_t streamB = nullptr;                 // HR_TUNE corun=1: the fused packet kernel of a step runs here, beside k_trace (experiment)
+        hipEvent_t evFork = nullptr, evJoin = nullptr;
         volatile unsigned long long *hProbe = nullptr; // [kTableRing][3], pinned: the packet probe's totals as of that step's k_trace (packet selector below)
         unsigned long long *dProbeHost = nullptr;      // ... as the device addresses it
         int countN[4] = {0, 0, 0, 0};                  // entries of the step table that went with ring entry r
@@ -271,12 +273,24 @@ struct hr_ctx {
     // packets are used while U < punion / 100 (c1 1.2, c2 1.5: win; c3 3.0, terrain 6.6: lose; profiles/r4u_packets.txt).  The totals
     // come back with the queue lengths k_trace reports (no synchronisation).  Either way the hits are the same bits.
     int tunePackets = 2;   // HR_TUNE="packets=0|1|2": never / always / by the probe (default)
+    // The packet kernel is VALU-bound and leaves the texture addressers idle (busy 1.0 / 0.16); k_trace without the camera rays is the
+    // other way round (0.70 / 0.94).  So a step's packet kernel runs BESIDE its k_trace, on a second stream (fork after the table copy,
+    // join before the shading kernels), and k_trace leaves it room: 3 workgroups per CU instead of 5 when the camera rays are a good part
+    // of the step's work, 4 when they are little (a step that injects few passes beside many in flight); c3 2100 -> 2390 Mrays/s at 128
+    // passes, 2025 -> 2150 at 20 (profiles/r4v_corun.txt).
+    // Only where k_trace IS bound by the addressers, i.e. where rays walk far: the probe also reports how many child boxes a camera ray
+    // enters (c3 76, c5 75, c3d 162: +8..13 %; c2 35: no difference; terrain 10, c1 5: k_trace is VALU-bound itself there and loses 6 %).
+    int tuneCorun = 1;       // HR_TUNE="corun=0|1|2": never (the packet kernel in front of k_trace on the group's stream) / by the probe / always
+    int tuneCorunMin = 50;   // HR_TUNE="cmin=N": beside k_trace when a probed camera ray enters at least N child boxes
+    int tuneCorunBlocks = 0; // HR_TUNE="cblocks=N": fix k_trace's workgroups per CU in such a step (0: 3 or 4 by the step's mix)
     int tunePacketUnion = 220; // HR_TUNE="punion=N": packets while U < N / 100 (measured break-even ~2.3: terrain at 1.97 +7..11 %, c5 at 2.07 +3..4 %)
     bool packetsOn = false;
+    uint32_t lastCameraCount = 0; // camera rays per pass behind the root cull, as last reported
     int probeCountdown = 0;              // injecting steps until the next probe
     bool probePending = false;
     unsigned long long probeStep = 0;    // step (of group 0) that carried the pending probe
-    unsigned long long probeSeen[3] = {0, 0, 0}; // totals of the report the last decision was taken on
+    unsigned long long probeSeen[4] = {0, 0, 0, 0}; // totals of the report the last decision was taken on
+    double lastOwnPerRay = 0.0;         // child boxes a probed camera ray entered: how long the scene's traversals are
     unsigned long long probeWaves = 0;   // waves of the pending probe: it is complete when the third total has grown by as many
     double lastUnion = 0.0;              // U of the last probe (HR_DEBUG_PIPE prints it)
     float probeCamera[21] = {0};         // fov, aspect, focus distance, aperture, view matrix, interactive mode of the probed pass
@@ -579,7 +593,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -596,6 +610,8 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             int least = 0, greatest = 0;
             groupsOk = groupsOk && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
             groupsOk = groupsOk && hipStreamCreateWithPriority(&G.stream, hipStreamNonBlocking, c->tunePrio ? greatest : 0) == hipSuccess;
+            groupsOk = groupsOk && hipStreamCreateWithPriority(&G.streamB, hipStreamNonBlocking, c->tunePrio ? greatest : 0) == hipSuccess &&
+                       hipEventCreateWithFlags(&G.evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&G.evJoin, hipEventDisableTiming) == hipSuccess;
         }
         groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
@@ -607,15 +623,15 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hSeq, sizeof(unsigned long long) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipHostGetDevicePointer((void **)&G.dCounts, G.hCounts, 0) == hipSuccess &&
                    hipHostGetDevicePointer((void **)&G.dSeq, (void *)G.hSeq, 0) == hipSuccess;
-        groupsOk = groupsOk && hipHostMalloc((void **)&G.hProbe, sizeof(unsigned long long) * kTableRing * 3, hipHostMallocDefault) == hipSuccess &&
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hProbe, sizeof(unsigned long long) * kTableRing * 4, hipHostMallocDefault) == hipSuccess &&
                    hipHostGetDevicePointer((void **)&G.dProbeHost, (void *)G.hProbe, 0) == hipSuccess;
         if (groupsOk)
-            for (int k = 0; k < kTableRing; ++k) G.hSeq[k] = 0ull, G.hProbe[3 * k] = 0ull, G.hProbe[3 * k + 1] = 0ull, G.hProbe[3 * k + 2] = 0ull;
+            for (int k = 0; k < kTableRing; ++k) G.hSeq[k] = 0ull, G.hProbe[4 * k] = 0ull, G.hProbe[4 * k + 1] = 0ull, G.hProbe[4 * k + 2] = 0ull, G.hProbe[4 * k + 3] = 0ull;
         std::memset(G.statusOrder, 0, sizeof(G.statusOrder));
     }
     if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
         hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, sizeof(uint32_t) * 6 * kBoundSlots) != hipSuccess ||
-        hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dProbe, 32) != hipSuccess || hipMemset(c->dProbe, 0, 32) != hipSuccess ||
+        hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dProbe, 64) != hipSuccess || hipMemset(c->dProbe, 0, 64) != hipSuccess ||
         hipStreamCreateWithFlags(&c->probeStream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->evProbeA, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->evProbeB, hipEventDisableTiming) != hipSuccess || hipMalloc(&c->dCounters, sizeof(Counters) * kMaxSlots) != hipSuccess ||
         hipMalloc(&c->dStepLog, sizeof(unsigned long long) * 3 * kStepLogCap) != hipSuccess) {
@@ -670,6 +686,9 @@ int hr_ctx_destroy(hr_ctx *c)
         for (hipEvent_t e : G.statusEv)
             if (e) hipEventDestroy(e);
         if (G.stream) hipStreamDestroy(G.stream);
+        if (G.streamB) hipStreamDestroy(G.streamB);
+        if (G.evFork) hipEventDestroy(G.evFork);
+        if (G.evJoin) hipEventDestroy(G.evJoin);
         hipFree(G.dTables);
         if (G.hTables) hipHostFree(G.hTables);
         if (G.evUser) hipEventDestroy(G.evUser);
@@ -2027,15 +2046,16 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             int rc = waitCounts(c, G, prev, stepIdx); // (step stepIdx - 1 wrote stepIdx: its number + 1)
             if (rc) return rc;
             if (g == 0 && c->probePending && stepIdx > c->probeStep) { // (steps from the probe's own on report the totals) complete once every wave of the probe has counted itself
-                const unsigned long long pk = G.hProbe[3 * prev], ry = G.hProbe[3 * prev + 1], done = G.hProbe[3 * prev + 2];
+                const unsigned long long pk = G.hProbe[4 * prev], ry = G.hProbe[4 * prev + 1], done = G.hProbe[4 * prev + 2], nr = G.hProbe[4 * prev + 3];
                 if (done - c->probeSeen[2] >= c->probeWaves) {
-                    const unsigned long long dPk = pk - c->probeSeen[0], dRy = ry - c->probeSeen[1];
-                    c->probePending = false, c->probeSeen[0] = pk, c->probeSeen[1] = ry, c->probeSeen[2] = done;
+                    const unsigned long long dPk = pk - c->probeSeen[0], dRy = ry - c->probeSeen[1], dNr = nr - c->probeSeen[3];
+                    c->probePending = false, c->probeSeen[0] = pk, c->probeSeen[1] = ry, c->probeSeen[2] = done, c->probeSeen[3] = nr;
                     if (dRy > 0) {
                         c->lastUnion = (double)dPk / (double)dRy;
                         c->packetsOn = c->lastUnion * 100.0 < (double)c->tunePacketUnion;
+                        c->lastOwnPerRay = dNr ? (double)dRy / (double)dNr : 0.0;
                     }
-                    if (getenv("HR_DEBUG_PIPE")) fprintf(stderr, "packet probe of step %llu (seen at step %llu): union %.3f -> packets %s\n", c->probeStep, stepIdx, c->lastUnion, c->packetsOn ? "on" : "off");
+                    if (getenv("HR_DEBUG_PIPE")) fprintf(stderr, "packet probe of step %llu (seen at step %llu): union %.3f, %.1f child boxes entered per ray -> packets %s\n", c->probeStep, stepIdx, c->lastUnion, c->lastOwnPerRay, c->packetsOn ? "on" : "off");
                 }
             }
             for (int i = 0; i < kMaxSlots; ++i) idxOfSlot[i] = -1;
@@ -2050,6 +2070,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
                 if (j >= 0 && G.countOrder[prev][j] == ps.order + 1ull) {
                     const uint32_t seen = G.hCounts[(size_t)prev * kMaxSegs + j]; // length of its closest-hit queue one stage ago
                     b = seen < b ? seen : b;
+                    if (ps.step == 1 && seen < P) c->lastCameraCount = seen; // (camera rays that passed the root cull: what a packet kernel traces per pass)
                 }
             }
             boundIn[k] = b;
@@ -2155,9 +2176,10 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             c->probeCountdown--;
         }
     }
+    const bool corunNow = packetsNow && (c->tuneCorun == 2 || (c->tuneCorun == 1 && c->lastOwnPerRay >= (double)c->tuneCorunMin));
     for (int j = 0; j < nInjectedSegs; ++j)
-        if (packetsNow) tbl.seg[injectedSegs[j]].packets = 1;
-    tbl.probe = c->dProbe, tbl.hostProbe = (g == 0 && (c->probePending || probeSeg >= 0)) ? G.dProbeHost + 3 * ring : nullptr; // (reported only while a probe is awaited)
+        if (packetsNow) tbl.seg[injectedSegs[j]].packets = corunNow ? 2 : 1;
+    tbl.probe = c->dProbe, tbl.hostProbe = (g == 0 && (c->probePending || probeSeg >= 0)) ? G.dProbeHost + 4 * ring : nullptr; // (reported only while a probe is awaited)
     G.countN[ring] = n;
     tbl.hostCounts = G.dCounts + (size_t)ring * kMaxSegs, tbl.hostSeq = G.dSeq + ring, tbl.seqValue = stepIdx + 1ull;
     tbl.stepLog = c->dStepLog, tbl.nInjectedNow = (uint32_t)nInjected, tbl.padL = 0;
@@ -2168,6 +2190,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     G.tableUsed[ring] = true;
     if (c->pending.size() > 8192) c->drainTimes();
     bool timing = false; // (the kernels of a step are enqueued back to back: n + 1 timing events for n kernels)
+    bool forked = false;
     for (int j0 = 0; j0 < nInjectedSegs;) { // one launch for the passes injected this step
         // (as packets: ray generation and the camera rays' traversal in one launch per group of 16, 8, 4, 2, 1 passes — the bucket
         // HR_KERNEL_RAYGEN then holds both, HR_KERNEL_TRACE and the step's device clock stay k_trace's own)
@@ -2179,6 +2202,17 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         SegList segs{};
         for (int j = j0; j < j0 + take; ++j) segs.seg[segs.n++] = injectedSegs[j];
         j0 += take;
+        if (corunNow) { // beside k_trace: fork after the table copy, join before the shading kernels
+            LaunchCfg cb = cfg;
+            cb.stream = G.streamB;
+            if (!forked) {
+                HIP_TRY(c, hipEventRecord(G.evFork, G.stream));
+                HIP_TRY(c, hipStreamWaitEvent(G.streamB, G.evFork, 0));
+                forked = true;
+            }
+            launchRaygenPackets(cb, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
+            continue;
+        }
         if (timing)
             c->timeNext(HR_KERNEL_RAYGEN, G.stream);
         else
@@ -2189,6 +2223,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         else
             launchRaygen(cfg, c->dScene, dTbl, segs, fr, c->dStats);
     }
+    if (forked) HIP_TRY(c, hipEventRecord(G.evJoin, G.streamB));
     if (timing)
         c->timeNext(HR_KERNEL_TRACE, G.stream);
     else
@@ -2201,7 +2236,22 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         HIP_TRY(c, hipEventRecord(c->evProbeB, c->probeStream));
         c->probeGuard = true, c->probePending = true, c->probeStep = stepIdx, c->probeCountdown = kProbeEvery;
     }
-    launchTrace(cfg, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
+    {
+        LaunchCfg ct = cfg;
+        if (forked) {
+            // camera rays of this step (what the passes injected before sent through the root cull, or half the pixels while unknown)
+            // against the rays k_trace carries (two per entry of the closest-hit queues' bounds: the ray and its occlusion ray)
+            double others = 0.0;
+            for (int k = 0; k < n; ++k)
+                if (c->slots[order[k]].step > 0) others += 2.0 * (double)boundIn[k];
+            const double cam = (double)nInjectedSegs * (double)(c->lastCameraCount ? c->lastCameraCount : P / 2u);
+            int blocks = cam > 0.2 * others ? 3 : 4;
+            if (c->tuneCorunBlocks > 0) blocks = c->tuneCorunBlocks;
+            if (blocks < ct.traceBlocksPerCU) ct.traceBlocksPerCU = blocks;
+        }
+        launchTrace(ct, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
+    }
+    if (forked) HIP_TRY(c, hipStreamWaitEvent(G.stream, G.evJoin, 0));
     c->timeNext(HR_KERNEL_SHADE, G.stream);
     launchShade(cfg, c->dScene, dTbl, c->dStats);
     c->timeEnd(G.stream);

@@ -303,8 +303,9 @@ __device__ __attribute__((noinline)) void reportQueueLengths(const StepTable *tb
 {
     if (!tbl->hostCounts) return;
     for (int k = (int)threadIdx.x; k < tbl->nSeg; k += kTraceBlock)
-        __hip_atomic_store(&tbl->hostCounts[k], tbl->seg[k].closestEnabled ? *tbl->seg[k].qCountIn : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x < 3 && tbl->hostProbe) // (the packet probe's totals so far)
+        __hip_atomic_store(&tbl->hostCounts[k], !tbl->seg[k].closestEnabled ? 0u : (tbl->seg[k].packets == 2u ? tbl->seg[k].hitCap : *tbl->seg[k].qCountIn), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM); // (packets == 2: the packet kernel runs BESIDE this one and is still filling the queue: its capacity is the bound)
+    if (threadIdx.x < 4 && tbl->hostProbe) // (the packet probe's totals so far)
         __hip_atomic_store(&tbl->hostProbe[threadIdx.x], __hip_atomic_load(&tbl->probe[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
@@ -996,7 +997,8 @@ __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__r
 
 // The selector's probe (hr_core.hip): a launch of its own on a side stream that depends on nothing the pipeline writes.  It generates
 // the camera rays of every kProbeStride-th 8x8 patch of one pass itself, walks them as packets and writes nothing but three totals:
-// probe[0] += children the packet entered x its rays, probe[1] += children the rays' own box tests entered, probe[2] += 1 per wave.
+// probe[0] += children the packet entered x its rays, probe[1] += children the rays' own box tests entered, probe[2] += 1 per wave,
+// probe[3] += rays walked.
 static const int kProbeStride = 32;
 __global__ __launch_bounds__(kPacketBlock) void k_packet_probe(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
                                                               hr_pass_params pp, int passesLog2, FrameDev fr, unsigned long long *probe)
@@ -1023,7 +1025,7 @@ __global__ __launch_bounds__(kPacketBlock) void k_packet_probe(const SceneDev *_
     const uint32_t nRays = (uint32_t)__popcll(__ballot(active));
     own = waveSum(active ? own : 0u);
     if (laneId() == 0) {
-        if (nRays) atomicAdd(&probe[0], (unsigned long long)entered * nRays), atomicAdd(&probe[1], (unsigned long long)own);
+        if (nRays) atomicAdd(&probe[0], (unsigned long long)entered * nRays), atomicAdd(&probe[1], (unsigned long long)own), atomicAdd(&probe[3], (unsigned long long)nRays);
         __threadfence();
         atomicAdd(&probe[2], 1ull);
     }
