@@ -619,12 +619,14 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.statusEv[k], hipEventDisableTiming) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hQCount, sizeof(uint32_t) * kTableRing * kMaxSlots * kMaxBounceSlots, hipHostMallocDefault) == hipSuccess;
-        groupsOk = groupsOk && hipHostMalloc((void **)&G.hCounts, sizeof(uint32_t) * kTableRing * kMaxSegs, hipHostMallocDefault) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hCounts, sizeof(uint32_t) * (kTableRing * kMaxSegs + 1), hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hSeq, sizeof(unsigned long long) * kTableRing, hipHostMallocDefault) == hipSuccess;
         groupsOk = groupsOk && hipHostGetDevicePointer((void **)&G.dCounts, G.hCounts, 0) == hipSuccess &&
                    hipHostGetDevicePointer((void **)&G.dSeq, (void *)G.hSeq, 0) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hProbe, sizeof(unsigned long long) * kTableRing * 4, hipHostMallocDefault) == hipSuccess &&
                    hipHostGetDevicePointer((void **)&G.dProbeHost, (void *)G.hProbe, 0) == hipSuccess;
+        if (groupsOk)
+            G.hCounts[kTableRing * kMaxSegs] = 0u; // (the last word: StepTable::hostCameraCount)
         if (groupsOk)
             for (int k = 0; k < kTableRing; ++k) G.hSeq[k] = 0ull, G.hProbe[4 * k] = 0ull, G.hProbe[4 * k + 1] = 0ull, G.hProbe[4 * k + 2] = 0ull, G.hProbe[4 * k + 3] = 0ull;
         std::memset(G.statusOrder, 0, sizeof(G.statusOrder));
@@ -2179,6 +2181,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     const bool corunNow = packetsNow && (c->tuneCorun == 2 || (c->tuneCorun == 1 && c->lastOwnPerRay >= (double)c->tuneCorunMin));
     for (int j = 0; j < nInjectedSegs; ++j)
         if (packetsNow) tbl.seg[injectedSegs[j]].packets = corunNow ? 2 : 1;
+    tbl.hostCameraCount = corunNow ? G.dCounts + (size_t)kTableRing * kMaxSegs : nullptr;
     tbl.probe = c->dProbe, tbl.hostProbe = (g == 0 && (c->probePending || probeSeg >= 0)) ? G.dProbeHost + 4 * ring : nullptr; // (reported only while a probe is awaited)
     G.countN[ring] = n;
     tbl.hostCounts = G.dCounts + (size_t)ring * kMaxSegs, tbl.hostSeq = G.dSeq + ring, tbl.seqValue = stepIdx + 1ull;
@@ -2243,7 +2246,9 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             // against the rays k_trace carries (two per entry of the closest-hit queues' bounds: the ray and its occlusion ray)
             double others = 0.0;
             for (int k = 0; k < n; ++k)
-                if (c->slots[order[k]].step > 0) others += 2.0 * (double)boundIn[k];
+                if (c->slots[order[k]].step > 0) others += 2.0 * (double)((c->slots[order[k]].step == 1 && c->lastCameraCount && boundIn[k] > c->lastCameraCount) ? c->lastCameraCount : boundIn[k]);
+            const uint32_t late = ((volatile uint32_t *)G.hCounts)[(size_t)kTableRing * kMaxSegs]; // (k_shade_sort's hint: camera rays per pass behind the root cull)
+            if (late) c->lastCameraCount = late;
             const double cam = (double)nInjectedSegs * (double)(c->lastCameraCount ? c->lastCameraCount : P / 2u);
             int blocks = cam > 0.2 * others ? 3 : 4;
             if (c->tuneCorunBlocks > 0) blocks = c->tuneCorunBlocks;

@@ -89,6 +89,7 @@ struct StepTable {
     // probe[0..2]; k_trace's first workgroup copies the totals to pinned host memory with the queue lengths (hr_core.hip: the packet selector)
     unsigned long long *probe;
     unsigned long long *hostProbe;
+    uint32_t *hostCameraCount; // pinned: camera rays per pass behind the root cull, as the step's shading kernel last saw them in queues a packet kernel filled (a hint for the host's scheduling, no ordering)
     // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
     // kTraceHeadsMax), each with a cursor on a cache line of its own — none of them shares its 128-byte line with the header above
     // or with seg[] below, which every wave reads while the cursors are hammered by atomics.  ONE cursor serialises at ~12 ns per atomic:

@@ -1111,6 +1111,12 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
             unsigned long long *rec = tbl->stepLog + 3ull * (idx % (unsigned long long)kStepLogCap);
             rec[0] = lo, rec[1] = hi, rec[2] = (unsigned long long)(uint32_t)nSeg | ((unsigned long long)tbl->nInjectedNow << 32);
         }
+        if (tbl->hostCameraCount) { // (the packet kernel ran beside k_trace, whose report could only give these queues' capacity)
+            unsigned long long sum = 0, cnt = 0;
+            for (int k = tbl->primaryFromSeg; k < nSeg; ++k)
+                if (tbl->seg[k].packets == 2u) sum += *tbl->seg[k].qCountIn, ++cnt;
+            if (cnt) __hip_atomic_store(tbl->hostCameraCount, (uint32_t)(sum / cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? *tbl->seg[k].qCountIn : 0u; });
     const uint32_t total = start[nSeg];

@@ -1392,12 +1392,14 @@ def test_step_log_resolved_counter_and_the_kernels_own_clock(golden):
     g.close()
 
 
-@pytest.mark.parametrize("tune", ["packets=2", "packets=2,punion=101", "packets=1", "packets=0", "packets=1,batch=5", "packets=1,batch=2"])
+@pytest.mark.parametrize("tune", ["packets=2", "packets=2,punion=101", "packets=1", "packets=0", "packets=1,batch=5", "packets=1,batch=2", "packets=1,corun=2",
+                                  "packets=1,corun=2,cblocks=1", "packets=1,corun=0"])
 def test_camera_rays_as_packets_where_the_probe_says_so_same_bits_either_way(monkeypatch, golden, tune):
     # hr_core.hip's packet selector: a pass's camera rays walk the tree 64 at a time — the rays of a few neighbouring pixels in the passes
     # injected together (k_raygen_packets) — where a probe finds such a wave's rays visiting nearly the same nodes (union factor below the
-    # threshold), and one ray per lane (k_trace) elsewhere.  Forced on (in groups of 16, 4 + 1, 2 passes), forced off or chosen, with the
-    # default threshold or one nothing can meet: the frame is the oracle's, bit for bit.
+    # threshold), and one ray per lane (k_trace) elsewhere.  Forced on (in groups of 16, 4 + 1, 2 passes; the packet kernel beside k_trace
+    # on a second stream or in front of it), forced off or chosen, with the default threshold or one nothing can meet: the frame is the
+    # oracle's, bit for bit.
     monkeypatch.setenv("HR_TUNE", tune)
     box = scenes.cornell_box(width=256, height=256, bounces=3, passes=40)
     fog = scenes.triangle_soup(150000, width=384, height=256, bounces=3, passes=40, env=True)
