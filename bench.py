@@ -663,9 +663,10 @@ def main():
                                           "region / wall time of the timed region; includes Infinity-Cache hits (upper bound of HBM bytes)",
                             "traffic_source": src, "hbm_side_bytes_per_ray": per_ray, "wall_ms": wall_s * 1e3,
                             "avg_launch_ms": avg_ms, "launches": n_trace, "rays_per_launch": (run_rays - (float(st.paths) if camera_packets[0] else 0.0)) / n_trace,
-                            "camera_packet_launches": None if not (camera_packets[0] and kt["raygen"][1]) else {"kernel": "k_raygen_packets", "launches": kt["raygen"][1], "avg_launch_ms": kt["raygen"][0] / max(kt["raygen"][1], 1),
-                                                                                         "rays_per_launch": float(st.paths) / max(kt["raygen"][1], 1),
-                                                                                         "note": "HIP events; ray generation and the camera rays' traversal; avg_launch_ms / launches / rays_per_launch above are k_trace's own"},
+                            "camera_packet_launches": None if not (camera_packets[0] and kt["raygen"][1]) else {
+                                "kernel": "k_raygen_packets", "event_bucket_raygen_ms": kt["raygen"][0], "event_bucket_raygen_launches": kt["raygen"][1], "camera_rays": float(st.paths),
+                                "note": "ray generation and the camera rays' traversal in one kernel; where it runs beside k_trace on a second stream the event bucket holds only "
+                                        "the time it outlasts k_trace (its own duration: the rocprofv3 kernel stats); avg_launch_ms / launches / rays_per_launch above are k_trace's own"},
                             "avg_launch_ms_source": "HIP events on the kernel's stream" if time_kernels else "device clock read inside k_trace (no events on the stream)",
                             "avg_launch_ms_device_clock": trace_clock[0] / max(trace_clock[1], 1),
                             "kernel_time_over_wall_time": sum(v[0] for v in kt.values()) / (wall_s * 1e3)}
@@ -688,15 +689,15 @@ def main():
                                         "note": "issue-rate ceiling of plain FMAs at the calibrated clock; the instruction mix of k_trace occupies a SIMD "
                                                 "for 3.3-4 cycles per instruction (tools/calib_ops.hip) at a shader clock of ~2.3 GHz (tools/tailprof.py): see `units` for busy fractions"}
                 if pmc and not pmc.get("failed") and "rays" in pmc["passes"].get("units", {}):
-                    ku = dict(pmc["kernels"].get("k_trace", {}))
-                    for ck, cv_ in pmc["kernels"].get("k_raygen_packets", {}).items():
-                        ku[ck] = ku.get(ck, 0.0) + cv_
+                    ku = dict(pmc["kernels"].get("k_trace", {}))  # (the dominant kernel; the packet kernel, when in use, is listed beside it)
                     if ku.get("GRBM_GUI_ACTIVE") and ku.get("TA_TA_BUSY_sum") is not None:
                         n_xcd = 8.0   # GRBM_GUI_ACTIVE is reported summed over the XCDs; TA counters over the CUs; SQ_ACTIVE_* in quad-cycles
                         n_cus = float(getattr(torch.cuda.get_device_properties(dev), "multi_processor_count", 256))
                         cyc = ku["GRBM_GUI_ACTIVE"] / n_xcd
                         roofline["units"] = {
-                            "kernel": "k_trace" if not camera_packets[0] else "k_trace + k_raygen_packets", "kernel_cycles": cyc,
+                            "kernel": "k_trace", "kernel_cycles": cyc,
+                            "note": None if not camera_packets[0] else "camera rays travel as packets in k_raygen_packets (per_kernel): VALU-bound, addressers idle — the complement of "
+                                    "k_trace, beside which it runs on a second stream in the timed run; the counter passes serialise the two, so each line describes its kernel alone",
                             "per_kernel": {kn: {"cycles": kd["GRBM_GUI_ACTIVE"] / n_xcd, "ta_busy": kd.get("TA_TA_BUSY_sum", 0.0) / n_cus / (kd["GRBM_GUI_ACTIVE"] / n_xcd),
                                                 "valu_busy": kd.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_cus * 4.0) / (kd["GRBM_GUI_ACTIVE"] / n_xcd)}
                                            for kn, kd in pmc["kernels"].items() if kn in ("k_trace", "k_raygen_packets") and kd.get("GRBM_GUI_ACTIVE")},

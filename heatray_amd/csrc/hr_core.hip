@@ -2256,7 +2256,10 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         }
         launchTrace(ct, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
     }
-    if (forked) HIP_TRY(c, hipStreamWaitEvent(G.stream, G.evJoin, 0));
+    if (forked) { // (the bucket HR_KERNEL_TRACE stays k_trace's own launch; what the packet kernel beside it runs longer is booked as ray generation)
+        c->timeNext(HR_KERNEL_RAYGEN, G.stream);
+        HIP_TRY(c, hipStreamWaitEvent(G.stream, G.evJoin, 0));
+    }
     c->timeNext(HR_KERNEL_SHADE, G.stream);
     launchShade(cfg, c->dScene, dTbl, c->dStats);
     c->timeEnd(G.stream);

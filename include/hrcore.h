@@ -388,7 +388,8 @@ typedef struct hr_pass_stats {
  * camera_packets / packet_union: the camera rays (perspective.rlsl:39-93) of the passes injected together are either traced like
  * every other ray or, where a probe finds the rays of a few neighbouring pixels in these passes walking nearly the same nodes, as one
  * packet per wave (one node fetch and one stack for 64 rays; ray generation and this traversal are then one kernel, timed under
- * HR_KERNEL_RAYGEN); the probe runs beside the pipeline after a commit, a resize, a change of camera and every 64th batch.
+ * HR_KERNEL_RAYGEN — where rays walk far it runs BESIDE k_trace on a second stream, and that bucket holds only the time it outlasts
+ * k_trace); the probe runs beside the pipeline after a commit, a resize, a change of camera and every 64th batch.
  * The hits — and so the image — are the same bits either way. */
 #define HR_KERNEL_RAYGEN 0  /* ray generation; with camera_packets, the camera rays' traversal too */
 #define HR_KERNEL_TRACE 1   /* closest-hit + occlusion traversal (one kernel) */
