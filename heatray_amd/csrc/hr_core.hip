@@ -2205,6 +2205,12 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         SegList segs{};
         for (int j = j0; j < j0 + take; ++j) segs.seg[segs.n++] = injectedSegs[j];
         j0 += take;
+        bool uniformParams = packetsNow;
+        for (int j = 1; j < segs.n && uniformParams; ++j) { // (the usual batch: one camera, one set of options, consecutive sample indices)
+            hr_pass_params a = tbl.seg[segs.seg[0]].pp, b = tbl.seg[segs.seg[j]].pp;
+            a.sample_index = b.sample_index = 0;
+            uniformParams = std::memcmp(&a, &b, sizeof(a)) == 0;
+        }
         if (corunNow) { // beside k_trace: fork after the table copy, join before the shading kernels
             LaunchCfg cb = cfg;
             cb.stream = G.streamB;
@@ -2213,7 +2219,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
                 HIP_TRY(c, hipStreamWaitEvent(G.streamB, G.evFork, 0));
                 forked = true;
             }
-            launchRaygenPackets(cb, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
+            launchRaygenPackets(cb, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats, uniformParams);
             continue;
         }
         if (timing)
@@ -2222,7 +2228,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             c->timeBegin(HR_KERNEL_RAYGEN, G.stream);
         timing = true;
         if (packetsNow)
-            launchRaygenPackets(cfg, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats);
+            launchRaygenPackets(cfg, c->dScene, c->nodes, c->tris, dTbl, segs, fr, c->dStats, uniformParams);
         else
             launchRaygen(cfg, c->dScene, dTbl, segs, fr, c->dStats);
     }

@@ -131,7 +131,7 @@ void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *fram
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out);
 void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
 void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, const StepTable *tbl, const SegList &segs,
-                         const FrameDev &fr, Stats *stats); // segs.n: a power of two
+                         const FrameDev &fr, Stats *stats, bool uniformParams); // segs.n: a power of two; uniformParams: the passes differ in sample_index only
 int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, int passesLog2, const FrameDev &fr,
                       unsigned long long *probe);
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);

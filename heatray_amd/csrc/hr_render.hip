@@ -934,7 +934,9 @@ HRD uint32_t mortonPixel(uint32_t j)
 // k_raygen does happens here the same way (perspective.rlsl, the pass sample's zero, the root cull with its miss shader); queue slots
 // are reserved per pass and workgroup through LDS counters.  k_trace leaves these passes' first-stage queues alone (SegDev::packets).
 static const int kRpBlock = 256;
-template <bool STATS>
+// UNIFORM: the passes differ in their sample index only (the usual batch: same camera, same options), so everything else of the pass
+// parameters is read once per wave through the scalar cache instead of once per lane from sixteen different table entries.
+template <bool STATS, bool UNIFORM>
 __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
                                                             const StepTable *__restrict__ tbl, SegList segs, int passesLog2, FrameDev fr, Stats *stats)
 {
@@ -946,13 +948,15 @@ __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__r
     const uint32_t nPass = 1u << passesLog2, pass = lane & (nPass - 1u), npx = 64u >> passesLog2;
     const uint32_t m = (blockIdx.x * (uint32_t)(kRpBlock / 64) + wave) * npx + (lane >> passesLog2); // owned pixel, patches in Morton order
     const SegDev &seg = tbl->seg[segs.seg[pass]];
+    hr_pass_params pp = UNIFORM ? tbl->seg[segs.seg[0]].pp : seg.pp;
+    if (UNIFORM) pp.sample_index = seg.pp.sample_index;
     int x = 0, y = 0;
     const bool inFrame = ownedPixel(fr, (m & ~63u) + mortonPixel(m & 63u), x, y);
     const uint32_t pixel = (uint32_t)(y * fr.W + x);
     Ray r;
     r.valid = false;
     bool active = inFrame;
-    if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
+    if (active) active = generatePrimary(S, pp, fr.W, fr.H, x, y, r);
     if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
     if (inFrame && seg.passbufB) {
         const size_t framePixels = (size_t)(seg.passbufB - seg.passbuf) >> 2;
@@ -963,7 +967,7 @@ __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__r
     if (active && S.nTris > 0 && S.rootLeafCount == 0 && rootMissed(S.nodes, r.o, r.d, S.rayEps, r.maxT)) {
         enqueue = false;
         if (r.missKind == MISS_ENV) {
-            ShaderT<0> sh(S, seg.pp, G(seg.passbuf) + (size_t)pixel * 4);
+            ShaderT<0> sh(S, pp, G(seg.passbuf) + (size_t)pixel * 4);
             sh.performAccumulate(sh.environmentRadiance(r.d, r.weight));
             nAcc = sh.nAccum;
         }
@@ -1361,7 +1365,7 @@ void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, co
 }
 
 void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, const StepTable *tbl, const SegList &segs,
-                         const FrameDev &fr, Stats *stats)
+                         const FrameDev &fr, Stats *stats, bool uniformParams)
 {
     const int threads = ownedThreads(fr);
     if (threads <= 0 || segs.n <= 0) return;
@@ -1369,10 +1373,14 @@ void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *n
     while ((2 << passesLog2) <= segs.n) ++passesLog2; // (the caller passes a power of two)
     const int pixelsPerBlock = (kRpBlock / 64) * (64 >> passesLog2);
     const dim3 grid((threads + pixelsPerBlock - 1) / pixelsPerBlock);
-    if (cfg.collectStats)
-        hipLaunchKernelGGL(k_raygen_packets<true>, grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
+    if (cfg.collectStats && uniformParams)
+        hipLaunchKernelGGL((k_raygen_packets<true, true>), grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
+    else if (cfg.collectStats)
+        hipLaunchKernelGGL((k_raygen_packets<true, false>), grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
+    else if (uniformParams)
+        hipLaunchKernelGGL((k_raygen_packets<false, true>), grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
     else
-        hipLaunchKernelGGL(k_raygen_packets<false>, grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
+        hipLaunchKernelGGL((k_raygen_packets<false, false>), grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
 }
 
 // returns the number of waves launched: each adds one to probe[2] when it is done
