@@ -263,15 +263,16 @@ struct hr_ctx {
     int tuneRefit = 1;        // HR_TUNE="refit=0": always rebuild
     // pipeline diagnostics (HR_DEBUG_PIPE=1 prints them when the context is destroyed)
     unsigned long long dbgGrowths = 0, dbgGrowBytes = 0, dbgWaits = 0, dbgWaitNs = 0, dbgWaitSpun = 0;
-    // ---- packet selector.  A pass's camera rays can be traced one ray per lane by k_trace, or 64 at a time as a packet by
-    // k_trace_primary (hr_render.hip).  The packet walks the UNION of its rays' node sets: it wins where 8x8 pixels see the same part
-    // of the tree (meshes whose triangles are not much smaller than the patch: c2 +15 %) and loses where every ray meets its own
-    // leaves (the benchmark's triangle fog: -17 %).  Which it is depends on scene, camera and resolution, so it is measured: every
-    // kProbeEvery-th injecting step — and the first after a commit, a resize or a change of camera — a probe kernel on a side stream
-    // makes the camera rays of every 32nd 8x8 patch of one injected pass itself and walks them as packets, writing nothing but
-    //     U = (children the packet entered x its rays) / (children the rays' own box tests entered);
-    // packets are used while U < punion / 100 (c1 1.2, c2 1.5: win; c3 3.0, terrain 6.6: lose; profiles/r4u_packets.txt).  The totals
-    // come back with the queue lengths k_trace reports (no synchronisation).  Either way the hits are the same bits.
+    // ---- packet selector.  The camera rays of the passes injected together can be traced one ray per lane by k_trace, or 64 at a time as a
+    // packet by k_raygen_packets (hr_render.hip): 2^k passes of 64 >> k neighbouring pixels per wave.  The packet walks the UNION of its
+    // rays' node sets: it wins where that union is small against the sum — meshes, and since a pixel's rays in consecutive passes differ by
+    // the jitter only, even the benchmark's triangle fog at 16 passes per packet (1.8 x; one pass of an 8x8 patch: 3.0 x, which loses).
+    // Which it is depends on scene, camera and resolution, so it is measured: every kProbeEvery-th injecting step — and the first after a
+    // commit, a resize or a change of camera — a probe kernel on a side stream makes the camera rays of every 32nd group of pixels of
+    // one injected pass and its companions itself and walks them as packets of the shape in use, writing nothing but
+    //     U = (children the packet entered x its rays) / (children the rays' own box tests entered)
+    // and how many child boxes a ray enters.  Packets are used while U < punion / 100 (profiles/r4u_packets.txt).  The totals come back
+    // with the queue lengths k_trace reports (no synchronisation).  Either way the hits are the same bits.
     int tunePackets = 2;   // HR_TUNE="packets=0|1|2": never / always / by the probe (default)
     // The packet kernel is VALU-bound and leaves the texture addressers idle (busy 1.0 / 0.16); k_trace without the camera rays is the
     // other way round (0.70 / 0.94).  So a step's packet kernel runs BESIDE its k_trace, on a second stream (fork after the table copy,
@@ -2161,7 +2162,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             if (order[k] == injectedSlots[j]) injectedSegs[nInjectedSegs++] = k;
     }
     if (nInjectedSegs > 0) tbl.primaryFromSeg = injectedSegs[0]; // (the table is in pass order: the passes injected now are its last entries)
-    // packet selector (above): which of the injected passes' camera rays go through k_trace_primary, and is one of them this step's probe?
+    // packet selector (above): do the injected passes' camera rays travel as packets (k_raygen_packets), beside k_trace or in front of it, and does this step carry a probe?
     int probeSeg = -1;
     bool packetsNow = packetsInUse(c) && nInjectedSegs > 0 && tbl.seg[injectedSegs[0]].pp.interactive_mode == 0; // (interactive sub-passes of one sample share no pixels)
     if (c->tunePackets == 2 && g == 0 && nInjectedSegs > 0 && !c->probePending && tbl.seg[injectedSegs[0]].pp.interactive_mode == 0) {

@@ -51,7 +51,7 @@ struct SegDev {
     uint32_t *pCount;    // entries at the front of hitIdx (k_shade_sort appends, k_shade_hit<.., 0> reads)
     uint32_t *gCount;    // entries at the back of hitIdx
     uint32_t hitCap;     // capacity of hitIdx (= of the ray queues)
-    uint32_t packets;    // this step traces the entry's closest-hit queue (camera rays) as packets (k_trace_primary): k_trace leaves it out
+    uint32_t packets;    // the entry's closest-hit queue (camera rays) is filled AND traced by k_raygen_packets this step: k_trace leaves it out; 2: that kernel runs beside k_trace (the queue's length is not final when k_trace starts)
     hr_pass_params pp;   // per-pass uniforms
     int32_t closestEnabled; // 0 in a pass's last step (only its occlusion rays remain)
     int32_t pad;

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
     const unsigned long long clk0 = wall_clock64();
-    buildSegStarts(tbl, segStart, false, true); // (camera rays traced as packets: k_trace_primary has done them)
+    buildSegStarts(tbl, segStart, false, true); // (camera rays that travel as packets are k_raygen_packets' business)
     const int nSeg2 = 2 * tbl->nSeg;
     if (blockIdx.x == 0) reportQueueLengths(tbl, segStart);
     const uint32_t total = segStart[nSeg2];
@@ -778,8 +778,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
 }
 
 // ---------------------------------------------------------------------------------- trace, camera rays
-// The closest-hit rays of a pass's FIRST stage are camera rays: 64 consecutive entries of that queue are (what the root cull left of)
-// 8x8-pixel patches, in patch order (ownedPixel).  Such a wave walks the tree as ONE packet: a single traversal state per wave — the
+// The closest-hit rays of a pass's FIRST stage are camera rays, and the camera rays of a few neighbouring pixels in the passes injected
+// together are nearly the same ray (k_raygen_packets below).  64 such rays walk the tree as ONE packet: a single traversal state per wave — the
 // node reference and the stack are wave-uniform, the node arrives through the scalar cache (no texture addresser), every lane tests the
 // node's four child boxes with its own ray, and a child is entered when ANY lane's ray enters it.  A lane whose ray misses a subtree the
 // wave walks anyway tests boxes and triangles it cannot hit: the hit is defined by the triangle test alone (hr_trace.h), so the result
