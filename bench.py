@@ -511,6 +511,11 @@ def main():
     while not args.no_wakeup and n_wake < wake_cap:
         eng.render_pass(sc.options.pass_params(n_wake % passes_total))
         n_wake += 1
+        if n_wake == 3 * post_every and "HR_BENCH_WAKE_MAX" not in os.environ:
+            # by now the library's packet selector has probed this scene and camera; where it sends the camera rays as packets the batch is
+            # the neighbouring power of two (12 -> 16 passes per step): the pipeline's fill and the exchange cadence follow
+            post_every = max(1, eng.pass_batch(sc.options.max_ray_depth))
+            wake_cap = max(wake_cap, (sc.options.max_ray_depth + 3) * post_every)
     eng.flush()
     torch.cuda.synchronize()
     wake_s = time.perf_counter() - t_wake
