@@ -933,7 +933,10 @@ HRD uint32_t mortonPixel(uint32_t j)
 // own node tests for one pass of an 8x8 patch, 1.8 x for sixteen passes of 2x2 pixels; profiles/r4u_packets.txt).  Everything
 // k_raygen does happens here the same way (perspective.rlsl, the pass sample's zero, the root cull with its miss shader); queue slots
 // are reserved per pass and workgroup through LDS counters.  k_trace leaves these passes' first-stage queues alone (SegDev::packets).
-static const int kRpBlock = 256;
+#ifndef HR_RP_BLOCK
+#define HR_RP_BLOCK 256
+#endif
+static const int kRpBlock = HR_RP_BLOCK; // threads per workgroup: queue slots are reserved once per workgroup and pass
 // UNIFORM: the passes differ in their sample index only (the usual batch: same camera, same options), so everything else of the pass
 // parameters is read once per wave through the scalar cache instead of once per lane from sixteen different table entries.
 template <bool STATS, bool UNIFORM>
