@@ -513,9 +513,9 @@ def main():
         n_wake += 1
         if n_wake == 3 * post_every and "HR_BENCH_WAKE_MAX" not in os.environ:
             # by now the library's packet selector has probed this scene and camera; where it sends the camera rays as packets the batch is
-            # the neighbouring power of two (12 -> 16 passes per step): the pipeline's fill and the exchange cadence follow
-            post_every = max(1, eng.pass_batch(sc.options.max_ray_depth))
-            wake_cap = max(wake_cap, (sc.options.max_ray_depth + 3) * post_every)
+            # the neighbouring power of two (12 -> 16 passes per step): the pipeline's fill follows.  (The exchange cadence does not: it is
+            # a count of collectives and must be the same on every rank whatever each rank's probe found on its tiles.)
+            wake_cap = max(wake_cap, (sc.options.max_ray_depth + 3) * max(1, eng.pass_batch(sc.options.max_ray_depth)))
     eng.flush()
     torch.cuda.synchronize()
     wake_s = time.perf_counter() - t_wake
