@@ -110,6 +110,45 @@ HRD bool ownedPixel(const FrameDev &fr, uint32_t gid, int &x, int &y)
 }
 
 // ------------------------------------------------------------------------------------------ raygen
+// One pixel of one pass (perspective.rlsl:39-93), shared by k_raygen and k_raygen_packets: the camera ray, the pass sample's zero
+// (perspective.rlsl:60 accumulate(vec4(0,0,0,1)) for sampled pixels) and the root cull.
+// A camera ray that misses the box of the whole tree is finished here: its traversal would be ONE node step at the root that
+// pushes nothing, then a hit record, then the miss shader in k_shade_sort — a queue slot (64 B), a record and three kernels' worth
+// of loads for a ray whose fate is already known (with the benchmark's camera — SURVEY 8d: distance 3 x the scene's radius, 50 mm lens
+// — that is three camera rays in four).  Its defaultPrimitive's shader runs right here (the sample was just set to zero: same single
+// addition as later), and it still counts as a closest-hit ray: it WAS traced, by the test below.  EXACTLY the traversal's own
+// decision: rootMissed() is the slab test of nodeStep4 on the root's frame box (planes q = 0 and 255), every child plane lies inside
+// it and fma is monotone in q, so a ray it rejects is rejected by all four children of the root.
+struct CameraLane {
+    Ray r;
+    uint32_t pixel;
+    bool active;  // the pixel is sampled this pass
+    bool enqueue; // ... and its ray has to be traced
+    uint32_t nAcc;
+};
+HRD void cameraLane(const SceneDev &S, const hr_pass_params &pp, const SegDev &seg, const FrameDev &fr, bool inFrame, int x, int y, CameraLane &c)
+{
+    c.pixel = (uint32_t)(y * fr.W + x);
+    c.r.valid = false;
+    c.active = inFrame;
+    if (c.active) c.active = generatePrimary(S, pp, fr.W, fr.H, x, y, c.r);
+    if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[c.pixel] = make_float4(0.0f, 0.0f, 0.0f, c.active ? 1.0f : 0.0f);
+    if (inFrame && seg.passbufB) { // HR_ESTIMATOR_ALL_LIGHTS: three more partial sums behind the first
+        const size_t framePixels = (size_t)(seg.passbufB - seg.passbuf) >> 2;
+        for (int j = 1; j <= 3; ++j) G(reinterpret_cast<float4 *>(seg.passbuf))[c.pixel + j * framePixels] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    c.enqueue = c.active;
+    c.nAcc = 0;
+    if (c.active && S.nTris > 0 && S.rootLeafCount == 0 && rootMissed(S.nodes, c.r.o, c.r.d, S.rayEps, c.r.maxT)) {
+        c.enqueue = false;
+        if (c.r.missKind == MISS_ENV) {
+            ShaderT<0> sh(S, pp, G(seg.passbuf) + (size_t)c.pixel * 4);
+            sh.performAccumulate(sh.environmentRadiance(c.r.d, c.r.weight));
+            c.nAcc = sh.nAccum;
+        }
+    }
+}
+
 static const int kRaygenBlock = 1024; // one queue-slot reservation (global atomic) per 1024 pixels
 __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restrict__ Sp, const StepTable *__restrict__ tbl, SegList segs, FrameDev fr,
                                                          Stats *stats)
@@ -120,34 +159,12 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
     const SegDev &seg = tbl->seg[segs.seg[blockIdx.y]]; // blockIdx.y: which of the passes injected this step
     int x = 0, y = 0;
     const bool inFrame = ownedPixel(fr, blockIdx.x * kRaygenBlock + threadIdx.x, x, y);
-    const uint32_t pixel = (uint32_t)(y * fr.W + x);
-    Ray r;
-    r.valid = false;
-    bool active = inFrame;
-    if (active) active = generatePrimary(S, seg.pp, fr.W, fr.H, x, y, r);
-    // the pass's sample starts at zero; perspective.rlsl:60 accumulate(vec4(0,0,0,1)) for sampled pixels
-    if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
-    if (inFrame && seg.passbufB) { // HR_ESTIMATOR_ALL_LIGHTS: three more partial sums behind the first
-        const size_t framePixels = (size_t)(seg.passbufB - seg.passbuf) >> 2;
-        for (int j = 1; j <= 3; ++j) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel + j * framePixels] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    // A camera ray that misses the box of the whole tree is finished here: its traversal would be ONE node step at the root that
-    // pushes nothing, then a hit record, then the miss shader in k_shade_sort — a queue slot (64 B), a record and three kernels' worth
-    // of loads for a ray whose fate this kernel already knows (with the benchmark's camera — SURVEY 8d: distance 3 x the scene's
-    // radius, 50 mm lens — that is three camera rays in four).  Its defaultPrimitive's shader runs right here (the sample was just
-    // set to zero above: same single addition as later), and it still counts as a closest-hit ray: it WAS traced, by the test below.
-    // EXACTLY the traversal's own decision: rootMissed() is the slab test of nodeStep4 on the root's frame box (planes q = 0 and 255),
-    // every child plane lies inside it and fma is monotone in q, so a ray it rejects is rejected by all four children of the root.
-    bool enqueue = active;
-    uint32_t nAcc = 0;
-    if (active && S.nTris > 0 && S.rootLeafCount == 0 && rootMissed(S.nodes, r.o, r.d, S.rayEps, r.maxT)) {
-        enqueue = false;
-        if (r.missKind == MISS_ENV) {
-            ShaderT<0> sh(S, seg.pp, G(seg.passbuf) + (size_t)pixel * 4);
-            sh.performAccumulate(sh.environmentRadiance(r.d, r.weight));
-            nAcc = sh.nAccum;
-        }
-    }
+    CameraLane c;
+    cameraLane(S, seg.pp, seg, fr, inFrame, x, y, c);
+    const Ray &r = c.r;
+    const uint32_t pixel = c.pixel;
+    const bool active = c.active, enqueue = c.enqueue;
+    uint32_t nAcc = c.nAcc;
     const uint32_t slot = blockReserve(enqueue, seg.qCountIn, scratch);
     if (enqueue) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
     const uint32_t n = waveSum(active ? 1u : 0u), nCulled = waveSum((active && !enqueue) ? 1u : 0u);
@@ -931,7 +948,7 @@ HRD uint32_t mortonPixel(uint32_t j)
 // The rays a pixel sends in consecutive passes differ by the sub-pixel jitter (and the lens sample) only: no other 64 rays of a
 // render are as close to each other, and the packet's union of node sets shrinks accordingly (c3, the triangle fog: 3.0 x its rays'
 // own node tests for one pass of an 8x8 patch, 1.8 x for sixteen passes of 2x2 pixels; profiles/r4u_packets.txt).  Everything
-// k_raygen does happens here the same way (perspective.rlsl, the pass sample's zero, the root cull with its miss shader); queue slots
+// k_raygen does happens here through the same function (cameraLane: perspective.rlsl, the pass sample's zero, the root cull with its miss shader); queue slots
 // are reserved per pass and workgroup through LDS counters.  k_trace leaves these passes' first-stage queues alone (SegDev::packets).
 #ifndef HR_RP_BLOCK
 #define HR_RP_BLOCK 256
@@ -955,26 +972,12 @@ __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__r
     if (UNIFORM) pp.sample_index = seg.pp.sample_index;
     int x = 0, y = 0;
     const bool inFrame = ownedPixel(fr, (m & ~63u) + mortonPixel(m & 63u), x, y);
-    const uint32_t pixel = (uint32_t)(y * fr.W + x);
-    Ray r;
-    r.valid = false;
-    bool active = inFrame;
-    if (active) active = generatePrimary(S, pp, fr.W, fr.H, x, y, r);
-    if (inFrame) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel] = make_float4(0.0f, 0.0f, 0.0f, active ? 1.0f : 0.0f);
-    if (inFrame && seg.passbufB) {
-        const size_t framePixels = (size_t)(seg.passbufB - seg.passbuf) >> 2;
-        for (int j = 1; j <= 3; ++j) G(reinterpret_cast<float4 *>(seg.passbuf))[pixel + j * framePixels] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-    bool enqueue = active; // (k_raygen's root cull, same decision, same miss shader)
-    uint32_t nAcc = 0;
-    if (active && S.nTris > 0 && S.rootLeafCount == 0 && rootMissed(S.nodes, r.o, r.d, S.rayEps, r.maxT)) {
-        enqueue = false;
-        if (r.missKind == MISS_ENV) {
-            ShaderT<0> sh(S, pp, G(seg.passbuf) + (size_t)pixel * 4);
-            sh.performAccumulate(sh.environmentRadiance(r.d, r.weight));
-            nAcc = sh.nAccum;
-        }
-    }
+    CameraLane c;
+    cameraLane(S, pp, seg, fr, inFrame, x, y, c);
+    const Ray &r = c.r;
+    const uint32_t pixel = c.pixel;
+    const bool active = c.active, enqueue = c.enqueue;
+    uint32_t nAcc = c.nAcc;
     __syncthreads();
     const uint32_t rank = enqueue ? atomicAdd(&cnt[pass], 1u) : 0u;
     __syncthreads();
