@@ -844,6 +844,46 @@ HRD void cswapS(uint32_t &a, uint32_t &b)
 // One packet: every lane walks the wave's traversal with its own ray (o, d, tmax; a lane without a ray passes tmax = 0: it enters
 // nothing and hits nothing).  PROBE also counts, per node step, the children the PACKET entered (`entered`, wave-uniform) and the
 // children this lane's own box test entered (`own`): what the packet costs against its rays traced one by one.
+// Möller–Trumbore on triangles [first, first + count) of the leaf-ordered array for the lanes with `mine`; the operation order is part of the
+// arithmetic contract (hr_trace.h)
+template <bool STATS>
+HRD void packetTriangles(ConstTris tris, int first, int count, bool mine, v3 o, v3 d, float tmin, float tmax, uint32_t skipPrim, HitRec &best, float &tlim, uint32_t &nt)
+{
+    for (int k = 0; k < count; ++k) {
+        const float4 tp = tris[first + k].p, tq = tris[first + k].q, trr = tris[first + k].r;
+        if (STATS) ++nt;
+        const uint32_t prim = __float_as_uint(trr.y);
+        if (!mine || prim == skipPrim) continue;
+        const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
+        const v3 pvec = cross(d, e2);
+        const float det = dot(e1, pvec);
+        if (det == 0.0f) continue;
+        const float inv = 1.0f / det;
+        const v3 tvec = o - v0;
+        const float u = dot(tvec, pvec) * inv;
+        if (!(u >= 0.0f) || u > 1.0f) continue;
+        const v3 qvec = cross(tvec, e1);
+        const float v = dot(d, qvec) * inv;
+        if (!(v >= 0.0f) || u + v > 1.0f) continue;
+        const float t = dot(e2, qvec) * inv;
+        if (!(t > tmin) || !(t < tmax)) continue;
+        const uint32_t bp = best.prim & 0x7FFFFFFFu;
+        if (best.prim == kMissPrim || t < best.t || (t == best.t && prim < bp)) {
+            best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
+            best.t = t, best.u = u, best.v = v;
+            tlim = t;
+        }
+    }
+}
+
+// One packet: every lane walks the wave's traversal with its own ray (o, d, tmax; a lane without a ray passes tmax = 0: it enters
+// nothing and hits nothing).  A lane tests a triangle only when ITS OWN ray enters the triangle's leaf box — the test k_trace makes for the
+// same ray at the same node — not whenever the packet gets there: float32 Möller–Trumbore accepts, once in ~10^9 rays, a ray that passes
+// a sliver triangle at a distance, and such a phantom hit must not depend on which rays travel together (found by a 600-pass soak: two
+// pixels of 2 M differed between packets and one ray per lane; tools/r4_soak_digest.py).  So leaf children are tested in the node step, right
+// after the four box tests, while the lanes' own results are at hand; only inner children go through the stack.  PROBE also counts, per node step, the
+// children the PACKET entered (`entered`, wave-uniform) and the children this lane's own box test entered (`own`): what the packet costs
+// against its rays traced one by one.
 template <bool STATS, bool PROBE>
 HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 o, v3 d, float tmax, uint32_t skipPrim, HitRec &best, uint32_t &nv, uint32_t &nt,
                         uint32_t &entered, uint32_t &own)
@@ -873,6 +913,7 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
             const uint32_t nY = rk.idy < 0.0f ? qc.x : qb.y, fY = rk.idy < 0.0f ? qb.y : qc.x;
             const uint32_t nZ = rk.idz < 0.0f ? qc.y : qb.z, fZ = rk.idz < 0.0f ? qb.z : qc.y;
             uint32_t key[4];
+            uint32_t ownLeaf = 0u, leafMask = 0u; // leaf children this lane's ray enters / any lane's ray enters (wave-uniform)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float tnx = __builtin_fmaf((float)byteOf(nX, c), bx, ax), tfx = __builtin_fmaf((float)byteOf(fX, c), bx, ax);
@@ -883,54 +924,37 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
                 const bool enters = tn <= tf && (uint32_t)c < nValid;
                 const unsigned long long m = __ballot(enters);
                 if (PROBE) own += enters ? 1u : 0u, entered += m ? 1u : 0u;
-                // the wave's key of the child: the entry distance of the first lane that enters it
-                key[c] = m ? (((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+                key[c] = 0xFFFFFFFFu;
+                if ((uint32_t)c >= nInner) { // a leaf child (one triangle): tested below, by the lanes whose own ray enters its box
+                    ownLeaf |= enters ? (1u << c) : 0u;
+                    leafMask |= m ? (1u << c) : 0u;
+                } else if (m) { // the wave's key of an inner child: the entry distance of the first lane that enters it
+                    key[c] = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c;
+                }
+            }
+            while (leafMask) { // (wave-uniform)
+                const int c = __ffs((int)leafMask) - 1;
+                leafMask &= leafMask - 1u;
+                const int enc = ~(leafKey + c);
+                packetTriangles<STATS>(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, ((ownLeaf >> c) & 1u) != 0u, o, d, tmin, tmax, skipPrim, best, tlim, nt);
             }
             cswapS(key[0], key[1]), cswapS(key[2], key[3]), cswapS(key[0], key[2]), cswapS(key[1], key[3]), cswapS(key[1], key[2]);
 #pragma unroll
             for (int j = 3; j >= 1; --j)
                 if (key[j] != 0xFFFFFFFFu) {
-                    const int sl = (int)(key[j] & 3u);
-                    stk.push(sp, (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl);
+                    stk.push(sp, innerBase + (int)(key[j] & 3u));
                     ++sp;
                 }
             if (key[0] != 0xFFFFFFFFu) {
-                const int sl = (int)(key[0] & 3u);
-                cur = (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl;
+                cur = innerBase + (int)(key[0] & 3u);
             } else if (sp > 0) {
                 cur = stk.at(--sp);
             } else {
                 cur = kSentinel;
             }
-        } else {
+        } else { // the whole scene is one leaf (at most four triangles, no box): every ray tests them all, as k_trace does
             const int enc = ~cur;
-            const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
-            for (int k = 0; k < count; ++k) {
-                const float4 tp = tris[first + k].p, tq = tris[first + k].q, trr = tris[first + k].r;
-                if (STATS) ++nt;
-                const uint32_t prim = __float_as_uint(trr.y);
-                if (prim == skipPrim) continue;
-                const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
-                // Möller–Trumbore; the operation order is part of the arithmetic contract (hr_trace.h)
-                const v3 pvec = cross(d, e2);
-                const float det = dot(e1, pvec);
-                if (det == 0.0f) continue;
-                const float inv = 1.0f / det;
-                const v3 tvec = o - v0;
-                const float u = dot(tvec, pvec) * inv;
-                if (!(u >= 0.0f) || u > 1.0f) continue;
-                const v3 qvec = cross(tvec, e1);
-                const float v = dot(d, qvec) * inv;
-                if (!(v >= 0.0f) || u + v > 1.0f) continue;
-                const float t = dot(e2, qvec) * inv;
-                if (!(t > tmin) || !(t < tmax)) continue;
-                const uint32_t bp = best.prim & 0x7FFFFFFFu;
-                if (best.prim == kMissPrim || t < best.t || (t == best.t && prim < bp)) {
-                    best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
-                    best.t = t, best.u = u, best.v = v;
-                    tlim = t;
-                }
-            }
+            packetTriangles<STATS>(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, true, o, d, tmin, tmax, skipPrim, best, tlim, nt);
             cur = sp > 0 ? stk.at(--sp) : kSentinel;
         }
     }
