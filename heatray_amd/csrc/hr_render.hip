@@ -832,6 +832,15 @@ struct LaneStack { // wave-uniform stack held in the LANES of three registers: e
         if (sp < 128) return __builtin_amdgcn_readlane(r1, sp - 64);
         return __builtin_amdgcn_readlane(r2, sp - 128);
     }
+    // one bit per entry and LANE beside the wave-uniform references: did this lane's own ray enter the box of the child pushed at sp?
+    unsigned long long b0, b1, b2;
+    HRD void setOwn(int sp, bool mine)
+    {
+        const unsigned long long bit = 1ull << (sp & 63);
+        unsigned long long &b = sp < 64 ? b0 : (sp < 128 ? b1 : b2);
+        b = mine ? (b | bit) : (b & ~bit);
+    }
+    HRD bool own(int sp) const { return (((sp < 64 ? b0 : (sp < 128 ? b1 : b2)) >> (sp & 63)) & 1ull) != 0ull; }
 };
 static_assert(kStackLDS + kStackOvf <= 192, "the packet stack holds the deepest tree the builder can make");
 
@@ -880,8 +889,8 @@ HRD void packetTriangles(ConstTris tris, int first, int count, bool mine, v3 o, 
 // nothing and hits nothing).  A lane tests a triangle only when ITS OWN ray enters the triangle's leaf box — the test k_trace makes for the
 // same ray at the same node — not whenever the packet gets there: float32 Möller–Trumbore accepts, once in ~10^9 rays, a ray that passes
 // a sliver triangle at a distance, and such a phantom hit must not depend on which rays travel together (found by a 600-pass soak: two
-// pixels of 2 M differed between packets and one ray per lane; tools/r4_soak_digest.py).  So leaf children are tested in the node step, right
-// after the four box tests, while the lanes' own results are at hand; only inner children go through the stack.  PROBE also counts, per node step, the
+// pixels of 2 M differed between packets and one ray per lane; tools/r4_soak_digest.py).  So the stack carries, beside each wave-uniform
+// child reference, one bit per lane: did this lane's own ray enter that child's box.  PROBE also counts, per node step, the
 // children the PACKET entered (`entered`, wave-uniform) and the children this lane's own box test entered (`own`): what the packet costs
 // against its rays traced one by one.
 template <bool STATS, bool PROBE>
@@ -893,9 +902,10 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
     const float idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
     const RayK rk = rayFrame(o, idx, idy, idz);
     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
-    LaneStack stk{0, 0, 0};
+    LaneStack stk{0, 0, 0, 0ull, 0ull, 0ull};
     int sp = 0;
     int cur = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
+    bool mineCur = true; // this lane's own ray entered the box of `cur` (a root leaf has no box: every ray tests it)
     while (cur != kSentinel) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         if (cur >= 0) {
@@ -913,7 +923,7 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
             const uint32_t nY = rk.idy < 0.0f ? qc.x : qb.y, fY = rk.idy < 0.0f ? qb.y : qc.x;
             const uint32_t nZ = rk.idz < 0.0f ? qc.y : qb.z, fZ = rk.idz < 0.0f ? qb.z : qc.y;
             uint32_t key[4];
-            uint32_t ownLeaf = 0u, leafMask = 0u; // leaf children this lane's ray enters / any lane's ray enters (wave-uniform)
+            uint32_t ownBits = 0u; // children this lane's own ray enters
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float tnx = __builtin_fmaf((float)byteOf(nX, c), bx, ax), tfx = __builtin_fmaf((float)byteOf(fX, c), bx, ax);
@@ -924,38 +934,38 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
                 const bool enters = tn <= tf && (uint32_t)c < nValid;
                 const unsigned long long m = __ballot(enters);
                 if (PROBE) own += enters ? 1u : 0u, entered += m ? 1u : 0u;
-                key[c] = 0xFFFFFFFFu;
-                if ((uint32_t)c >= nInner) { // a leaf child (one triangle): tested below, by the lanes whose own ray enters its box
-                    ownLeaf |= enters ? (1u << c) : 0u;
-                    leafMask |= m ? (1u << c) : 0u;
-                } else if (m) { // the wave's key of an inner child: the entry distance of the first lane that enters it
-                    key[c] = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c;
-                }
-            }
-            while (leafMask) { // (wave-uniform)
-                const int c = __ffs((int)leafMask) - 1;
-                leafMask &= leafMask - 1u;
-                const int enc = ~(leafKey + c);
-                packetTriangles<STATS>(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, ((ownLeaf >> c) & 1u) != 0u, o, d, tmin, tmax, skipPrim, best, tlim, nt);
+                ownBits |= enters ? (1u << c) : 0u;
+                // the wave's key of the child: the entry distance of the first lane that enters it
+                key[c] = m ? (((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
             }
             cswapS(key[0], key[1]), cswapS(key[2], key[3]), cswapS(key[0], key[2]), cswapS(key[1], key[3]), cswapS(key[1], key[2]);
 #pragma unroll
             for (int j = 3; j >= 1; --j)
                 if (key[j] != 0xFFFFFFFFu) {
-                    stk.push(sp, innerBase + (int)(key[j] & 3u));
+                    const int sl = (int)(key[j] & 3u);
+                    stk.push(sp, (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl);
+                    stk.setOwn(sp, ((ownBits >> sl) & 1u) != 0u);
                     ++sp;
                 }
             if (key[0] != 0xFFFFFFFFu) {
-                cur = innerBase + (int)(key[0] & 3u);
+                const int sl = (int)(key[0] & 3u);
+                cur = (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl;
+                mineCur = ((ownBits >> sl) & 1u) != 0u;
             } else if (sp > 0) {
-                cur = stk.at(--sp);
+                --sp;
+                cur = stk.at(sp), mineCur = stk.own(sp);
             } else {
                 cur = kSentinel;
             }
-        } else { // the whole scene is one leaf (at most four triangles, no box): every ray tests them all, as k_trace does
+        } else { // a leaf: its triangle(s), for the lanes whose own ray entered its box
             const int enc = ~cur;
-            packetTriangles<STATS>(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, true, o, d, tmin, tmax, skipPrim, best, tlim, nt);
-            cur = sp > 0 ? stk.at(--sp) : kSentinel;
+            packetTriangles<STATS>(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, mineCur, o, d, tmin, tmax, skipPrim, best, tlim, nt);
+            if (sp > 0) {
+                --sp;
+                cur = stk.at(sp), mineCur = stk.own(sp);
+            } else {
+                cur = kSentinel;
+            }
         }
     }
 }

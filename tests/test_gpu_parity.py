@@ -1456,6 +1456,24 @@ def test_packet_selector_follows_the_scene_on_one_context(monkeypatch, golden):
     g.close()
 
 
+def test_frames_do_not_depend_on_how_camera_rays_travel(monkeypatch):
+    # One ray per lane, packets in front of k_trace, packets beside it: the same frame, bit for bit, over a run long enough that float32
+    # Moeller-Trumbore's phantom hits on sliver triangles occur (a ray that passes a sliver at a distance can be accepted: once in ~10^9
+    # rays on the benchmark soup).  A packet lane therefore tests a triangle only when its own ray enters the triangle's box, as k_trace
+    # does for that ray; before that rule a 600-pass run at 1080p differed in two pixels (profiles/r4x_soak_digests.txt).
+    frames = []
+    for tune in ("packets=0", "packets=1,corun=0", "packets=1,corun=2"):
+        monkeypatch.setenv("HR_TUNE", tune)
+        sc = scenes.triangle_soup(1_000_000, width=1920, height=1080, bounces=2, passes=160, env=True)
+        g = core.create_engine()
+        sc.apply(g)
+        for s in range(160):
+            g.render_pass(sc.options.pass_params(s))
+        frames.append(g.readback().copy())
+        g.close()
+    assert frames[0].tobytes() == frames[1].tobytes() == frames[2].tobytes()
+
+
 def test_large_scene_3m_triangles(golden):
     # maximum-size end of the range (tools/big_scene_check.py goes to 30 M): device LBVH + collapse of 3 M triangles, hits against
     # the oracle's own tree and a render, bit for bit
