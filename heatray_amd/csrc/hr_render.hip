@@ -944,7 +944,7 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
                 if (key[j] != 0xFFFFFFFFu) {
                     const int sl = (int)(key[j] & 3u);
                     stk.push(sp, (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl);
-                    stk.setOwn(sp, ((ownBits >> sl) & 1u) != 0u);
+                    if ((uint32_t)sl >= nInner) stk.setOwn(sp, ((ownBits >> sl) & 1u) != 0u); // (only a leaf's bit is ever read)
                     ++sp;
                 }
             if (key[0] != 0xFFFFFFFFu) {
@@ -953,7 +953,8 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
                 mineCur = ((ownBits >> sl) & 1u) != 0u;
             } else if (sp > 0) {
                 --sp;
-                cur = stk.at(sp), mineCur = stk.own(sp);
+                cur = stk.at(sp);
+                if (cur < 0) mineCur = stk.own(sp);
             } else {
                 cur = kSentinel;
             }
@@ -962,7 +963,8 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
             packetTriangles<STATS>(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, mineCur, o, d, tmin, tmax, skipPrim, best, tlim, nt);
             if (sp > 0) {
                 --sp;
-                cur = stk.at(sp), mineCur = stk.own(sp);
+                cur = stk.at(sp);
+                if (cur < 0) mineCur = stk.own(sp);
             } else {
                 cur = kSentinel;
             }
