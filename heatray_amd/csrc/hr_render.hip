@@ -926,17 +926,19 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
             uint32_t ownBits = 0u; // children this lane's own ray enters
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+                key[c] = 0xFFFFFFFFu;
+                if ((uint32_t)c >= nValid) continue; // (wave-uniform: a node has 3.2 children on average, the slots behind them cost nothing here)
                 const float tnx = __builtin_fmaf((float)byteOf(nX, c), bx, ax), tfx = __builtin_fmaf((float)byteOf(fX, c), bx, ax);
                 const float tny = __builtin_fmaf((float)byteOf(nY, c), by, ay), tfy = __builtin_fmaf((float)byteOf(fY, c), by, ay);
                 const float tnz = __builtin_fmaf((float)byteOf(nZ, c), bz, az), tfz = __builtin_fmaf((float)byteOf(fZ, c), bz, az);
                 const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
                 const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
-                const bool enters = tn <= tf && (uint32_t)c < nValid;
+                const bool enters = tn <= tf;
                 const unsigned long long m = __ballot(enters);
                 if (PROBE) own += enters ? 1u : 0u, entered += m ? 1u : 0u;
                 ownBits |= enters ? (1u << c) : 0u;
                 // the wave's key of the child: the entry distance of the first lane that enters it
-                key[c] = m ? (((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+                if (m) key[c] = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c;
             }
             cswapS(key[0], key[1]), cswapS(key[2], key[3]), cswapS(key[0], key[2]), cswapS(key[1], key[3]), cswapS(key[1], key[2]);
 #pragma unroll
