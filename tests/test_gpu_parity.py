@@ -1456,6 +1456,26 @@ def test_packet_selector_follows_the_scene_on_one_context(monkeypatch, golden):
     g.close()
 
 
+@pytest.mark.parametrize("tune", ["packets=1,corun=0", "packets=1,corun=2", "packets=0"])
+def test_passes_of_one_batch_may_differ_in_everything(monkeypatch, golden, tune):
+    # The passes a packet spans usually differ in their sample index only (then their parameters come through the scalar cache); nothing in the
+    # API says they must: here every pass of a batch has its own field of view, focus, aperture and depth-of-field sample — each lane
+    # reads its own pass's block — and the frame is the oracle's.
+    monkeypatch.setenv("HR_TUNE", tune)
+    sc = scenes.multi_material(width=160, height=96, bounces=3, passes=24)
+    g, o = core.create_engine(), oracle_lib.engine()
+    lut = golden["multiscatter_lut"]
+    sc.apply(g, lut=lut, tables=host_tables(sc)), sc.apply(o, lut=lut, tables=host_tables(sc))
+    for s in range(19):
+        sc.options.focal_length = 35.0 + 3.0 * (s % 5)
+        sc.options.fstop = 2.0 + (s % 3)
+        sc.options.focus_distance = 2.0 + 0.25 * (s % 4)
+        pp = sc.options.pass_params(s)
+        g.render_pass(pp), o.render_pass(pp)
+    assert g.readback().tobytes() == o.readback().tobytes()
+    g.close(), o.close()
+
+
 def test_frames_do_not_depend_on_how_camera_rays_travel(monkeypatch):
     # One ray per lane, packets in front of k_trace, packets beside it: the same frame, bit for bit, over a run long enough that float32
     # Moeller-Trumbore's phantom hits on sliver triangles occur (a ray that passes a sliver at a distance can be accepted: once in ~10^9
