@@ -1476,6 +1476,19 @@ def test_passes_of_one_batch_may_differ_in_everything(monkeypatch, golden, tune)
     g.close(), o.close()
 
 
+@pytest.mark.parametrize("tune,expect", [("packets=0", {(1920, 1080): 12, (3840, 2160): 3, (256, 256): 32, (2560, 1440): 7}),
+                                         ("packets=1", {(1920, 1080): 16, (3840, 2160): 4, (256, 256): 32, (2560, 1440): 8})])
+def test_batch_is_the_neighbouring_power_of_two_while_packets_are_in_use(monkeypatch, tune, expect):
+    # hr_frame_pass_batch: 12 x 1080p pixels' worth of camera rays per macro step; a packet spans 2^k passes, so with packets the batch is the
+    # power of two next to that figure (3/4 of the way up rounds up: 12 -> 16, 3 -> 4, 7 -> 8; 5 would go to 4)
+    monkeypatch.setenv("HR_TUNE", tune)
+    g = core.create_engine()
+    for (w, h), want in expect.items():
+        g.resize(w, h)
+        assert g.pass_batch(3) == want, (tune, w, h, g.pass_batch(3))
+    g.close()
+
+
 def test_frames_do_not_depend_on_how_camera_rays_travel(monkeypatch):
     # One ray per lane, packets in front of k_trace, packets beside it: the same frame, bit for bit, over a run long enough that float32
     # Moeller-Trumbore's phantom hits on sliver triangles occur (a ray that passes a sliver at a distance can be accepted: once in ~10^9
