@@ -575,10 +575,17 @@ def main():
         log = eng.step_log()
         batch_stats = None
         if log:
-            full = max(r[2] for r in log)
-            per_pass = [(log[i + 1][0] - log[i][0]) / log[i][3] for i in range(len(log) - 1) if log[i][2] == full and log[i][3] > 0 and log[i + 1][2] == full]
+            # (records come sorted by start with their pipeline group: the period is taken between consecutive steps of ONE group, and
+            # with G groups stepping in turn a group's period covers the passes all G of them injected meanwhile)
+            full_depth = max(r[2] for r in log)
+            groups = sorted({r[4] for r in log})
+            per_pass = []
+            for gr in groups:
+                lg = [r for r in log if r[4] == gr]
+                per_pass += [(lg[i + 1][0] - lg[i][0]) / (lg[i][3] * len(groups)) for i in range(len(lg) - 1)
+                             if lg[i][2] == full_depth and lg[i][3] > 0 and lg[i + 1][2] == full_depth]
             tr = sorted(r[1] for r in log)
-            batch_stats = {"macro_steps": len(log), "passes_in_flight_max": full, "steady_state_steps": len(per_pass),
+            batch_stats = {"macro_steps": len(log), "passes_in_flight_max": full_depth, "pipeline_groups": len(groups), "steady_state_steps": len(per_pass),
                            "k_trace_launch_ms": {"min": tr[0], "median": float(np.median(tr)), "max": tr[-1]},
                            "min": min(per_pass) if len(per_pass) >= 2 else None, "median": float(np.median(per_pass)) if len(per_pass) >= 2 else None,
                            "max": max(per_pass) if len(per_pass) >= 2 else None,

@@ -51,7 +51,7 @@ i32p = C.POINTER(C.c_int32)
 
 class CtxDesc(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("tile_size", C.c_int32),
-                ("stream", C.c_void_p), ("flags", C.c_uint32)]
+                ("stream", C.c_void_p), ("flags", C.c_uint32), ("memory_budget", C.c_uint64)]
 
 
 class MeshDesc(C.Structure):
@@ -118,7 +118,7 @@ class PassStats(C.Structure):
 
 
 class StepRecord(C.Structure):
-    _fields_ = [("start_ms", C.c_double), ("trace_ms", C.c_float), ("passes_in_flight", C.c_int32), ("passes_injected", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("start_ms", C.c_double), ("trace_ms", C.c_float), ("passes_in_flight", C.c_int32), ("passes_injected", C.c_int32), ("group", C.c_int32)]
 
 
 class KernelTimes(C.Structure):
@@ -153,8 +153,9 @@ class Hit(C.Structure):
 HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
 
 # every symbol include/hrcore.h declares (suffix after the prefix)
+HR_ABI_VERSION = 5  # include/hrcore.h: checked against the loaded library before the first call (Engine.__init__)
 ABI_SYMBOLS = [
-    "ctx_create", "ctx_destroy", "last_error", "ctx_set_stream", "frame_resize", "frame_bind_external",
+    "abi_version", "ctx_create", "ctx_destroy", "last_error", "ctx_set_stream", "frame_resize", "frame_bind_external",
     "frame_device_ptr", "geom_add", "geom_remove", "geom_set_transform", "scene_clear", "scene_commit",
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
     "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
@@ -179,11 +180,17 @@ def _ptr(a, typ=f32p):
 class Engine:
     """Thin object wrapper over one hr_ctx (or ora_ctx)."""
 
-    def __init__(self, lib, prefix, device_id=0, rank=0, world=1, tile_size=32, stream=None, flags=0):
+    def __init__(self, lib, prefix, device_id=0, rank=0, world=1, tile_size=32, stream=None, flags=0, memory_budget=0):
         self._lib = lib
         self._p = prefix
         self._ctx = C.c_void_p()
-        desc = CtxDesc(device_id, rank, world, tile_size, stream, flags)
+        ver = getattr(lib, prefix + "abi_version", None)
+        if ver is None:
+            raise EngineError(f"{prefix}abi_version missing: the library predates this binding (ABI {HR_ABI_VERSION})")
+        ver.restype = C.c_uint32
+        if ver() != HR_ABI_VERSION:
+            raise EngineError(f"{prefix}abi_version() = {ver()}, this binding was written against {HR_ABI_VERSION}: rebuild the library")
+        desc = CtxDesc(device_id, rank, world, tile_size, stream, flags, int(memory_budget))
         rc = self._fn("ctx_create")(C.byref(desc), C.byref(self._ctx))
         if rc != HR_OK:
             self._ctx = C.c_void_p()
@@ -384,11 +391,11 @@ class Engine:
         return d
 
     def step_log(self, capacity=4096):
-        """[(start_ms, trace_ms, passes_in_flight, passes_injected)] of the macro steps since the last clear (newest 4096)."""
+        """[(start_ms, trace_ms, passes_in_flight, passes_injected, group)] of the macro steps since the last clear (newest 4096), sorted by start."""
         recs = (StepRecord * capacity)()
         n = C.c_int32()
         self._call("get_step_log", recs, C.c_int32(capacity), C.byref(n))
-        return [(r.start_ms, r.trace_ms, r.passes_in_flight, r.passes_injected) for r in recs[: n.value]]
+        return [(r.start_ms, r.trace_ms, r.passes_in_flight, r.passes_injected, r.group) for r in recs[: n.value]]
 
     def synchronize(self):
         self._call("synchronize")

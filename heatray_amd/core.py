@@ -25,8 +25,8 @@ def load_library():
     return _LIB
 
 
-def create_engine(device_id=0, rank=0, world=1, tile_size=32, stream=None, collect_stats=False, time_kernels=False):
+def create_engine(device_id=0, rank=0, world=1, tile_size=32, stream=None, collect_stats=False, time_kernels=False, memory_budget=0):
     from ._ffi import HR_CTX_COLLECT_STATS, HR_CTX_TIME_KERNELS
     flags = (HR_CTX_COLLECT_STATS if collect_stats else 0) | (HR_CTX_TIME_KERNELS if time_kernels else 0)
     return Engine(load_library(), "hr_", device_id=device_id, rank=rank, world=world, tile_size=tile_size,
-                  stream=stream, flags=flags)
+                  stream=stream, flags=flags, memory_budget=memory_budget)

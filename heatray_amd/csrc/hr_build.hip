@@ -168,7 +168,7 @@ __global__ void k_scene_consts(const uint32_t *__restrict__ bounds, SceneConsts 
     c.eps = 1e-4f * c.diag;
     c.areaSum = 0.0f, c.triAreaSum = 0.0f, c.pad1 = 0u;
     *out = c;
-    if (scene) scene->rayEps = c.eps;
+    if (scene) scene->rayEps = c.eps, scene->hitPad = 0.5f * c.pad;
 }
 void launchSceneConsts(hipStream_t st, const uint32_t *bounds, SceneConsts *out, SceneDev *scene)
 {
@@ -926,6 +926,11 @@ __global__ __launch_bounds__(kPlocTail) void k_ploc_tail(uint32_t *__restrict__ 
         __threadfence();
         __syncthreads();
         m = (int)kTotal, base += mTotal, cur ^= 1;
+        // An iteration that merged nothing would repeat itself for ever, one workgroup spinning until the GPU is reset.  The pair key
+        // reads the same from both ends, so it cannot happen for ordered areas — but NaN boxes (non-finite vertices) are not ordered.
+        // mTotal comes from LDS totals every thread has read alike: a uniform exit; state[1] != n - 1 then tells buildPLOC (rc 7:
+        // the radix tree is kept).
+        if (mTotal == 0u) break;
     }
     if (t == 0) state[0] = (uint32_t)m, state[1] = base;
 }

@@ -6,6 +6,7 @@
 #include "hr_kernels.h"
 #include "hr_trace.h"
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -113,6 +114,7 @@ struct hr_ctx {
         RayQueue qcur{};       // closest-hit rays of the pass's next stage
         ShadowQueue scur{};    // occlusion rays of the pass's next stage
         uint32_t capCur = 0;   // rays qcur can hold (= upper bound of what it holds)
+        uint32_t sCapCur = 0;  // occlusion rays scur can hold
         float *passbuf = nullptr;
         float *passbufB = nullptr; // second partial sum (allLightsUsed): passbuf + W * H * 4, same allocation
         Counters *ctr = nullptr;
@@ -187,6 +189,16 @@ struct hr_ctx {
     uint32_t *dZero = nullptr;    // a zero word (occlusion count of a pass's first step)
     Counters *dCounters = nullptr; // one per pass slot, contiguous (copied to the host in one piece in pass-through scenes)
     unsigned long long *dStepLog = nullptr; // kStepLogCap records of three words (StepTable::stepLog)
+    // Sticky report of a ray queue that turned out longer than its capacity (hr_render.hip: queueOverflow): four pinned, coherent words
+    // the kernels write — kind of queue, step, table entry, count.  Checked wherever the caller learns about finished work.
+    volatile uint32_t *hOverflow = nullptr;
+    uint32_t *dOverflowHost = nullptr; // ... as the device addresses them
+    // hr_ctx_desc::memory_budget: device bytes the pipeline may hold for rays and pass buffers (0: unlimited).  Bounds the passes
+    // injected per step (budgetBatch): first by what a batch needs when every queue is as long as it can get, then — once a full
+    // pipeline has shown the real lengths — by what it was seen to need (rayBytesSeen / batchSeen), with a fifth on top.
+    unsigned long long memBudget = 0;
+    double rayBytesPerPassSeen = 0.0; // arena + scratch bytes (with their headroom) per pass of a step's batch, largest seen with the pipeline full
+    int tuneOverflowTest = 0;          // HR_TUNE="ovf=1|2|3": TEST ONLY — halve one bound so that a queue overflows (1: camera rays, 2: a stage's closest-hit bound, 3: occlusion rays)
 
     // Mesh blocks come out of an arena of 64 MB chunks (bump allocation inside a chunk): a hipMalloc per submesh is a device-wide
     // synchronisation of ~0.1 ms each, which adds up for the scenes the reference loads (hundreds of submeshes).  A chunk whose last
@@ -426,6 +438,18 @@ struct hr_ctx {
 
 static const int kTableRing = 4;
 static int drainPipeline(hr_ctx *c);
+// A kernel found a ray queue longer than its capacity (hr_render.hip: queueOverflow): rays were dropped, the frame is not the render
+// that was asked for.  Sticky until hr_clear; every call that hands finished work to the caller reports it.
+static int overflowCheck(hr_ctx *c)
+{
+    if (!c->hOverflow || c->hOverflow[0] == 0u) return HR_OK;
+    static const char *kinds[] = {"?", "camera rays", "closest-hit queue (input)", "occlusion queue (input)", "closest-hit queue (emitted rays)", "occlusion queue (emitted rays)", "hit list"};
+    const uint32_t kind = c->hOverflow[0];
+    c->err = std::string("ray queue overflow: ") + kinds[kind < 7u ? kind : 0u] + " of table entry " + std::to_string(c->hOverflow[2]) + " in macro step " +
+             std::to_string(c->hOverflow[1] ? c->hOverflow[1] - 1u : 0u) + " held " + std::to_string(c->hOverflow[3]) +
+             " rays, more than the host provided for; rays were dropped (hr_clear resets the frame and this report)";
+    return HR_ERR_DEVICE;
+}
 // finish every enqueued pass and wait for the device: required before anything the in-flight kernels read changes
 static int quiesce(hr_ctx *c)
 {
@@ -514,6 +538,7 @@ static void freeQueues(hr_ctx *c)
     }
     c->nSlotsAllocated = 0;
     c->queueCapacity = 0;
+    c->rayBytesPerPassSeen = 0.0; // (memory budget: back to the guarantee until a full pipeline has been seen again)
 }
 
 // how many passes may be in flight: a slot holds a pass buffer (four partial sums once HR_ESTIMATOR_ALL_LIGHTS has been used); the rays
@@ -557,6 +582,8 @@ template <class T> static int ensureCap(hr_ctx *c, T **p, size_t *cap, size_t ne
 
 extern "C" {
 
+uint32_t hr_abi_version(void) { return HR_ABI_VERSION; }
+
 int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
 {
     if (!out) return HR_ERR_INVALID;
@@ -570,6 +597,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         c->world = desc->world > 0 ? desc->world : 1;
         c->tile = desc->tile_size > 0 ? desc->tile_size : 32;
         c->stream = (hipStream_t)desc->stream;
+        c->memBudget = desc->memory_budget;
         c->collectStats = (desc->flags & HR_CTX_COLLECT_STATS) != 0;
         c->timeKernels = (desc->flags & HR_CTX_TIME_KERNELS) != 0;
     }
@@ -594,11 +622,14 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs), get("ovf=", c->tuneOverflowTest);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
     }
+    // Memory the host READS WHILE A KERNEL THAT WRITES IT IS RUNNING (queue lengths, probe totals, the overflow report): coherent
+    // (uncached on the device side, fine-grained) whatever HIP_HOST_COHERENT says — hipHostMallocDefault leaves that to the environment
+    const unsigned kHostSpun = hipHostMallocCoherent | hipHostMallocMapped;
     bool groupsOk = true;
     for (int g = 0; g < kMaxGroups; ++g) {
         hr_ctx::Group &G = c->groups[g];
@@ -620,11 +651,11 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.statusEv[k], hipEventDisableTiming) == hipSuccess;
         groupsOk = groupsOk && hipHostMalloc((void **)&G.hQCount, sizeof(uint32_t) * kTableRing * kMaxSlots * kMaxBounceSlots, hipHostMallocDefault) == hipSuccess;
-        groupsOk = groupsOk && hipHostMalloc((void **)&G.hCounts, sizeof(uint32_t) * (kTableRing * kMaxSegs + 1), hipHostMallocDefault) == hipSuccess;
-        groupsOk = groupsOk && hipHostMalloc((void **)&G.hSeq, sizeof(unsigned long long) * kTableRing, hipHostMallocDefault) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hCounts, sizeof(uint32_t) * (kTableRing * kMaxSegs + 1), kHostSpun) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hSeq, sizeof(unsigned long long) * kTableRing, kHostSpun) == hipSuccess;
         groupsOk = groupsOk && hipHostGetDevicePointer((void **)&G.dCounts, G.hCounts, 0) == hipSuccess &&
                    hipHostGetDevicePointer((void **)&G.dSeq, (void *)G.hSeq, 0) == hipSuccess;
-        groupsOk = groupsOk && hipHostMalloc((void **)&G.hProbe, sizeof(unsigned long long) * kTableRing * 4, hipHostMallocDefault) == hipSuccess &&
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hProbe, sizeof(unsigned long long) * kTableRing * 4, kHostSpun) == hipSuccess &&
                    hipHostGetDevicePointer((void **)&G.dProbeHost, (void *)G.hProbe, 0) == hipSuccess;
         if (groupsOk)
             G.hCounts[kTableRing * kMaxSegs] = 0u; // (the last word: StepTable::hostCameraCount)
@@ -632,6 +663,9 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
             for (int k = 0; k < kTableRing; ++k) G.hSeq[k] = 0ull, G.hProbe[4 * k] = 0ull, G.hProbe[4 * k + 1] = 0ull, G.hProbe[4 * k + 2] = 0ull, G.hProbe[4 * k + 3] = 0ull;
         std::memset(G.statusOrder, 0, sizeof(G.statusOrder));
     }
+    groupsOk = groupsOk && hipHostMalloc((void **)&c->hOverflow, 4 * sizeof(uint32_t), kHostSpun) == hipSuccess &&
+               hipHostGetDevicePointer((void **)&c->dOverflowHost, (void *)c->hOverflow, 0) == hipSuccess;
+    if (groupsOk) c->hOverflow[0] = c->hOverflow[1] = c->hOverflow[2] = c->hOverflow[3] = 0u;
     if (!groupsOk || hipMalloc(&c->dScene, sizeof(SceneDev)) != hipSuccess ||
         hipMalloc(&c->dStats, sizeof(Stats) * kStatSlots) != hipSuccess || hipMalloc(&c->dScratch, sizeof(uint32_t) * 6 * kBoundSlots) != hipSuccess ||
         hipMalloc(&c->dZero, 64) != hipSuccess || hipMalloc(&c->dProbe, 64) != hipSuccess || hipMemset(c->dProbe, 0, 64) != hipSuccess ||
@@ -681,6 +715,7 @@ int hr_ctx_destroy(hr_ctx *c)
     hipFree(c->dTexDensity);
     for (Texture &t : c->textures) hipFree(t.dmips);
     hipFree(c->dScene), hipFree(c->dStats), hipFree(c->dScratch), hipFree(c->dZero), hipFree(c->dProbe), hipFree(c->dCounters), hipFree(c->dStepLog);
+    if (c->hOverflow) hipHostFree((void *)c->hOverflow);
     for (hr_ctx::Group &G : c->groups) {
         if (G.hQCount) hipHostFree(G.hQCount);
         if (G.hCounts) hipHostFree(G.hCounts);
@@ -800,6 +835,10 @@ int hr_display_readback(hr_ctx *c, const hr_display_params *params, int32_t form
     ENTER(c);
     if (!pixels) FAIL(c, HR_ERR_INVALID, "null output");
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
+    {
+        const int rc = overflowCheck(c);
+        if (rc) return rc;
+    }
     const size_t need = (size_t)c->W * c->H * 16;
     if (c->displayBytes < need) {
         hipFree(c->dDisplay);
@@ -843,7 +882,7 @@ int hr_synchronize(hr_ctx *c)
 {
     ENTER(c);
     QUIESCE(c);
-    return HR_OK;
+    return overflowCheck(c);
 }
 
 // ------------------------------------------------------------------------------------------ frame
@@ -956,6 +995,23 @@ int hr_geom_add(hr_ctx *c, const hr_mesh_desc *d, hr_geom_id *out)
         for (int i = 0; i < d->n_indices; ++i) worst = d->indices[i] > worst ? d->indices[i] : worst;
         if (d->n_indices > 0 && worst >= (uint32_t)d->n_vertices) FAIL(c, HR_ERR_INVALID, "index out of range");
     }
+    {
+        // positions must be finite: a NaN box has no order, and the tree builders' progress arguments (and every slab test) assume one
+        const int sb = d->position_stride == 0 ? 12 : d->position_stride;
+        if (sb < 12) FAIL(c, HR_ERR_INVALID, "attribute stride smaller than the attribute");
+        float worst = 0.0f;
+        bool nan = false;
+        for (int i = 0; i < d->n_vertices; ++i) {
+            float p[3];
+            std::memcpy(p, (const char *)d->positions + (size_t)i * (size_t)sb, 12);
+            const float m = std::fmax(std::fabs(p[0]), std::fmax(std::fabs(p[1]), std::fabs(p[2]))); // (fmax drops a NaN operand: checked apart)
+            worst = m > worst ? m : worst;
+            nan = nan || p[0] != p[0] || p[1] != p[1] || p[2] != p[2];
+        }
+        if (nan || !(worst <= 3.0e37f)) FAIL(c, HR_ERR_INVALID, "vertex positions must be finite");
+        for (int k = 0; k < 16; ++k)
+            if (!(std::fabs(d->world_from_entity[k]) <= 3.0e37f)) FAIL(c, HR_ERR_INVALID, "world_from_entity must be finite");
+    }
     const float *src[6] = {d->positions, d->normals, d->uvs, d->tangents, d->bitangents, d->colors};
     const int32_t strideB[6] = {d->position_stride, d->normal_stride, d->uv_stride, d->tangent_stride, d->bitangent_stride, d->color_stride};
     const int comps[6] = {3, 3, 2, 3, 3, 3};
@@ -1058,6 +1114,8 @@ int hr_geom_set_transform(hr_ctx *c, hr_geom_id id, const float m[16])
 {
     ENTER(c);
     if (id < 0 || id >= (int)c->geoms.size() || !c->geoms[id].alive || !m) FAIL(c, HR_ERR_INVALID, "bad geom id");
+    for (int k = 0; k < 16; ++k)
+        if (!(std::fabs(m[k]) <= 3.0e37f)) FAIL(c, HR_ERR_INVALID, "world_from_entity must be finite");
     std::memcpy(c->geoms[id].world, m, 16 * sizeof(float));
     c->committed = false, c->transformDirty = true;
     return HR_OK;
@@ -1080,11 +1138,12 @@ struct CacheHeader {
     char magic[8];
     uint32_t version, nodeBytes;
     unsigned long long key;
-    uint32_t nTris, nNodes, levels, rootLeafCount, triSlots, pad;
+    uint32_t nTris, nNodes, levels, rootLeafCount, triSlots, builder; // builder: which binary tree was collapsed (BuildResult::builder)
     uint32_t levelStart[kMaxLevels + 1];
+    float costRadix, costPloc;     // the candidates' costs as hr_scene_info reports them
     unsigned long long payloadSum; // checksum of everything behind the header (the key covers the SCENE, not the file)
 };
-const uint32_t kCacheVersion = 3;
+const uint32_t kCacheVersion = 4; // 4: two candidate builders (round 4) — the header says which tree the file holds, the key which builder options made it
 
 // 64-bit checksum of the payload, eight bytes at a time (the files are tens to hundreds of MB)
 unsigned long long payloadChecksum(const char *p, size_t bytes)
@@ -1167,6 +1226,8 @@ static int sceneKey(hr_ctx *c, unsigned long long *key)
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(dKey);
     HIP_TRY(c, e);
+    // (which tree a build produces also depends on the builder options: a file made with other ones is another scene's as far as the cache goes)
+    mix(&c->tunePloc, sizeof(c->tunePloc)), mix(&c->tunePlocRadius, sizeof(c->tunePlocRadius));
     *key = host ^ (dev * 0x9E3779B97F4A7C15ull);
     return HR_OK;
 }
@@ -1203,6 +1264,7 @@ static bool loadTree(hr_ctx *c, unsigned long long key, uint32_t nTris, BuildRes
         return false;
     }
     br.nNodes = (int32_t)h.nNodes, br.levels = (int32_t)h.levels, br.rootLeafCount = (int32_t)h.rootLeafCount, br.triSlots = h.triSlots;
+    br.builder = h.builder == 1u ? 1 : 0, br.costRadix = h.costRadix, br.costPloc = h.costPloc;
     std::memcpy(br.levelStart, h.levelStart, sizeof(br.levelStart));
     *out = br;
     return true;
@@ -1220,6 +1282,7 @@ static void saveTree(hr_ctx *c, unsigned long long key, uint32_t nTris, const Bu
     std::memcpy(h.magic, "HRBVHTR", 8);
     h.version = kCacheVersion, h.nodeBytes = sizeof(Node4), h.key = key, h.nTris = nTris, h.nNodes = (uint32_t)br.nNodes, h.levels = (uint32_t)br.levels;
     h.rootLeafCount = (uint32_t)br.rootLeafCount, h.triSlots = br.triSlots;
+    h.builder = (uint32_t)br.builder, h.costRadix = br.costRadix, h.costPloc = br.costPloc;
     std::memcpy(h.levelStart, br.levelStart, sizeof(h.levelStart));
     h.payloadSum = payloadChecksum(buf.data(), buf.size());
     const std::string tmp = c->cachePath + ".tmp";
@@ -1286,7 +1349,7 @@ int hr_scene_commit(hr_ctx *c)
     }
     std::memset(&c->info, 0, sizeof(c->info));
     c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
-    c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0, c->hScene.rayEps = 0.0f;
+    c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0, c->hScene.rayEps = 0.0f, c->hScene.hitPad = 0.0f;
     if (nTris == 0) {
         freeTree(c);
     } else {
@@ -1361,6 +1424,7 @@ int hr_scene_commit(hr_ctx *c)
         c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = ext;
         c->hScene.nTris = (int)nTris, c->hScene.nNodes = c->tree.nNodes, c->hScene.rootLeafCount = c->tree.rootLeafCount;
         c->hScene.rayEps = k.eps; // 1e-4 |diagonal|, SURVEY §8a a6
+        c->hScene.hitPad = 0.5f * k.pad; // (hr_trace.h: hitInTriBox)
         for (int q = 0; q < 3; ++q) c->info.aabb_min[q] = k.lo[q], c->info.aabb_max[q] = k.hi[q];
         c->info.n_triangles = nTris, c->info.n_nodes = (uint64_t)c->tree.nNodes, c->info.ray_epsilon = k.eps;
         c->info.bvh_levels = (uint32_t)c->tree.levels;
@@ -1372,6 +1436,7 @@ int hr_scene_commit(hr_ctx *c)
     HIP_TRY(c, hipEventSynchronize(cs.e1));
     hipEventElapsedTime(&c->info.build_ms, cs.e0, cs.e1);
     c->committed = true;
+    c->rayBytesPerPassSeen = 0.0; // (memory budget: another scene, other queue lengths)
     c->probeCountdown = 0; // (packet selector: another tree)
     c->sceneDirty = true;
     c->texDensityStale = true;
@@ -1763,6 +1828,10 @@ int hr_clear(hr_ctx *c)
     if (c->W <= 0) FAIL(c, HR_ERR_INVALID, "no frame");
     int rc = drainPipeline(c);
     if (rc) return rc;
+    if (c->hOverflow && c->hOverflow[0]) { // a dropped-rays report: the frame starts afresh and so does the report, once nothing that could repeat it is running
+        QUIESCE(c);
+        c->hOverflow[0] = c->hOverflow[1] = c->hOverflow[2] = c->hOverflow[3] = 0u;
+    }
     HIP_TRY(c, hipMemsetAsync(c->fb(), 0, (size_t)c->W * c->H * 4 * sizeof(float), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->dStats, 0, sizeof(Stats) * kStatSlots, c->stream));
     c->resolvedAtClear = c->nextResolveOrder;
@@ -1829,7 +1898,7 @@ static int ensureRegion(hr_ctx *c, hr_ctx::Group &G, hr_ctx::Group::Region &r, s
     // step carries one more generation of passes — for the benchmark soup the steady state needs 27 % more than the step that
     // triggered the last growth (profiles/r4m_mem.txt); a step that needs more regrows once more
     size_t want = need + need / 3;
-    if (hadCap && want < hadCap + hadCap / 2) want = hadCap + hadCap / 2; // (a region that has to grow again grows by half at least: few events)
+    if (hadCap && !c->memBudget && want < hadCap + hadCap / 2) want = hadCap + hadCap / 2; // (a region that has to grow again grows by half at least: few events; under a memory budget only by what is needed)
     want = (want + ((size_t)2 << 20)) & ~(((size_t)2 << 20) - 1);
     hipError_t e = hipMalloc((void **)&r.base, want);
     size_t got = want;
@@ -1938,6 +2007,7 @@ static int waitCounts(hr_ctx *c, hr_ctx::Group &G, int ring, unsigned long long 
 // One macro step of pipeline group g: (raygen of the injected passes) -> trace of every in-flight pass of the group ->
 // shade; passes whose last stage this was become `finished`.
 static const int kProbeEvery = 64; // injecting steps between two probes of the packet selector
+static int stagesOf(const hr_ctx *c, const hr_pass_params &pp);
 static int packetLog2(const hr_ctx *c);
 static bool packetsInUse(const hr_ctx *c);
 static int macroStep(hr_ctx *c, int g, int nInject)
@@ -1987,7 +2057,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         }
         waited[nInjected] = ps.everResolved ? ps.resolvedEv : nullptr;
         ps.active = true, ps.finished = false, ps.group = g, ps.step = 0, ps.nIter = pp.max_ray_depth + 1, ps.pp = pp;
-        ps.qcur = RayQueue{}, ps.scur = ShadowQueue{}, ps.capCur = 0;
+        ps.qcur = RayQueue{}, ps.scur = ShadowQueue{}, ps.capCur = 0, ps.sCapCur = 0;
         ps.order = c->injected++;
         injectedSlots[nInjected++] = slot;
     }
@@ -2037,7 +2107,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     const int ring = (int)(stepIdx % kTableRing);
     if (G.tableUsed[ring]) HIP_TRY(c, hipEventSynchronize(G.tableCopied[ring])); // staging entry free again (4 steps old)
     // ---- ray memory of this step (Group::arena): every queue sized by an upper bound of what can arrive in it
-    const uint32_t P = c->queueCapacity ? c->queueCapacity : 1u;
+    const uint32_t P = c->tuneOverflowTest == 1 ? c->queueCapacity / 8u + 1u : (c->queueCapacity ? c->queueCapacity : 1u); // (ovf=1, TEST ONLY: camera rays do not fit)
     const size_t kS = c->allLightsUsed ? 4 : 1;
     uint32_t boundIn[kMaxSegs];
     {
@@ -2076,6 +2146,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
                     if (ps.step == 1 && seen < P) c->lastCameraCount = seen; // (camera rays that passed the root cull: what a packet kernel traces per pass)
                 }
             }
+            // TEST ONLY (HR_TUNE="ovf=": tests/test_gpu_parity.py forces every kind of overflow once): half of what the bound should be
+            if (c->tuneOverflowTest == 2 && ps.step == 1) b = b / 2u + 1u;
             boundIn[k] = b;
         }
     }
@@ -2087,6 +2159,15 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         if (closest) {
             needScratch += align256((size_t)boundIn[k] * hitRecordSize()) + align256((size_t)boundIn[k] * 4);
             needArena += rayQueueBytes(boundIn[k]) + shadowQueueBytes((size_t)boundIn[k] * kS);
+        }
+    }
+    if (c->memBudget && n > 0) {
+        // what a pass of the batch costs in ray memory, seen with this group's pipeline full (as many generations in flight as a pass has
+        // stages): the regions' sizes this step asks for, with the headroom ensureRegion adds, over the passes per generation
+        const int S = stagesOf(c, c->slots[order[0]].pp);
+        if (n >= S && c->slots[order[0]].step >= S - 2) {
+            const double perPass = (4.0 / 3.0) * (2.0 * (double)(needArena > G.arenaHighWater ? needArena : G.arenaHighWater) + (double)needScratch) / ((double)n / (double)S);
+            if (perPass > c->rayBytesPerPassSeen) c->rayBytesPerPassSeen = perPass;
         }
     }
     hr_ctx::Group::Region &arena = G.arena[stepIdx & 1ull];
@@ -2127,6 +2208,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         const bool closest = c->hasPassthrough || st < ps.nIter;
         sg.qin = st == 0 ? carveRayQueue(pScratch, P) : ps.qcur; // (a new pass's camera rays live for this step only)
         sg.sqIn = ps.scur;                                        // (nothing to trace there in a pass's first step: sCountIn is the zero word)
+        sg.qinCap = st == 0 ? P : ps.capCur, sg.sInCap = st == 0 ? 0u : ps.sCapCur, sg.sOutCap = 0u;
         sg.qout = RayQueue{}, sg.sqOut = ShadowQueue{}, sg.hits = nullptr, sg.hitIdx = nullptr;
         if (closest) {
             sg.hits = (HitRec *)pScratch, pScratch += align256((size_t)boundIn[k] * hitRecordSize());
@@ -2134,6 +2216,9 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             sg.qout = carveRayQueue(pArena, boundIn[k]);
             sg.sqOut = carveShadowQueue(pArena, (size_t)boundIn[k] * kS);
             ps.qcur = sg.qout, ps.scur = sg.sqOut, ps.capCur = boundIn[k];
+            sg.sOutCap = (uint32_t)((size_t)boundIn[k] * kS);
+            if (c->tuneOverflowTest == 3 && st == 0) sg.sOutCap = sg.sOutCap / 8u + 1u; // TEST ONLY: the first hits' occlusion rays do not fit
+            ps.sCapCur = sg.sOutCap;
         }
         sg.passbuf = ps.passbuf;
         sg.passbufB = ps.pp.estimator == HR_ESTIMATOR_ALL_LIGHTS ? ps.passbufB : nullptr;
@@ -2154,7 +2239,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         sg.qCountOut = &ps.ctr->qCount[(st + 1) % R];
         sg.sCountOut = &ps.ctr->sCount[st % R];
         sg.pCount = &ps.ctr->pCount[st % R], sg.gCount = &ps.ctr->gCount[st % R];
-        sg.hitCap = boundIn[k] ? boundIn[k] : 1u, sg.packets = 0;
+        sg.hitCap = closest ? boundIn[k] : 0u, sg.packets = 0; // (capacity of hits, the hit list and qout: what was carved above)
         sg.pp = ps.pp;
         sg.closestEnabled = closest ? 1 : 0;
         G.countSlot[ring][k] = order[k], G.countOrder[ring][k] = ps.order + 1ull;
@@ -2186,7 +2271,8 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     tbl.probe = c->dProbe, tbl.hostProbe = (g == 0 && (c->probePending || probeSeg >= 0)) ? G.dProbeHost + 4 * ring : nullptr; // (reported only while a probe is awaited)
     G.countN[ring] = n;
     tbl.hostCounts = G.dCounts + (size_t)ring * kMaxSegs, tbl.hostSeq = G.dSeq + ring, tbl.seqValue = stepIdx + 1ull;
-    tbl.stepLog = c->dStepLog, tbl.nInjectedNow = (uint32_t)nInjected, tbl.padL = 0;
+    tbl.stepLog = c->dStepLog, tbl.nInjectedNow = (uint32_t)nInjected, tbl.group = (uint32_t)g;
+    tbl.hostOverflow = c->dOverflowHost;
     StepTable *dTbl = G.dTables + ring;
     const size_t tblBytes = offsetof(StepTable, seg) + (size_t)n * sizeof(SegDev);
     HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, tblBytes, hipMemcpyHostToDevice, G.stream));
@@ -2347,9 +2433,36 @@ static int packetLog2(const hr_ctx *c)
 }
 static bool packetsInUse(const hr_ctx *c) { return c->tunePackets == 1 || (c->tunePackets == 2 && c->packetsOn); }
 
+// hr_ctx_desc::memory_budget: how many passes per step fit.  A pass of the batch holds, over the `stages` steps of its life, a pass buffer
+// (S + 2 of them per batch pass are kept: the pipeline's depth and the resolve lag), its camera rays and hit records (scratch), and
+// what each of its closest-hit stages emits (arena: two halves, each with a third of headroom).  Before a full pipeline has been
+// seen, every queue counts as long as it can possibly get (one ray per owned pixel at every stage: the guarantee); afterwards the
+// largest per-pass figure seen, plus a fifth.
+static double budgetBytesPerPass(const hr_ctx *c, int stages)
+{
+    const double P = (double)(c->queueCapacity ? c->queueCapacity : 1u), kS = c->allLightsUsed ? 4.0 : 1.0;
+    const double fb = (double)c->W * c->H * 16.0 * (c->allLightsUsed ? 4.0 : 1.0);
+    const double closestStages = (double)(stages - 1);
+    const double worstRays = (4.0 / 3.0) * (P * 64.0 + closestStages * P * 20.0) + 2.0 * (4.0 / 3.0) * closestStages * P * (64.0 + 48.0 * kS);
+    const double rays = c->rayBytesPerPassSeen > 0.0 ? 1.2 * c->rayBytesPerPassSeen : worstRays;
+    return (double)c->nGroups * ((double)(stages + 2) * fb + rays);
+}
+static int budgetBatch(const hr_ctx *c, int stages)
+{
+    if (!c->memBudget) return 1 << 20;
+    const double fit = (double)c->memBudget / budgetBytesPerPass(c, stages);
+    return fit < 1.0 ? 1 : (fit > 1e6 ? 1 << 20 : (int)fit);
+}
+
 static int batchFor(const hr_ctx *c, int stages)
 {
     int batch = packetsInUse(c) ? packetBatch(c) : c->injectBatch;
+    const int fit = budgetBatch(c, stages);
+    if (batch > fit) {
+        batch = fit;
+        if (packetsInUse(c)) // (a packet holds a power of two of passes)
+            while (batch & (batch - 1)) batch &= batch - 1;
+    }
     int perGroup = slotLimit(c) / c->nGroups;
     if (perGroup > kMaxSegs) perGroup = kMaxSegs;
     if (batch * stages > perGroup) batch = perGroup / stages;
@@ -2436,6 +2549,11 @@ int hr_render_pass(hr_ctx *c, const hr_pass_params *pp)
         if (rc) return rc;
     }
     c->lastDepth = pp->max_ray_depth;
+    if (c->memBudget && (double)c->memBudget < budgetBytesPerPass(c, stagesOf(c, *pp))) {
+        c->err = "hr_ctx_desc.memory_budget (" + std::to_string(c->memBudget >> 20) + " MiB) is less than one pass per pipeline step needs at " + std::to_string(c->W) + "x" +
+                 std::to_string(c->H) + ", depth " + std::to_string(pp->max_ray_depth) + ": " + std::to_string((unsigned long long)budgetBytesPerPass(c, stagesOf(c, *pp)) >> 20) + " MiB";
+        return HR_ERR_INVALID;
+    }
     {
         // All pass slots this depth needs are allocated up front, on the first pass (hipMalloc synchronises the device and
         // takes ~0.1 ms per buffer: allocating slot by slot as the pipeline filled stalled the first 20-odd passes of a render)
@@ -2473,7 +2591,8 @@ int hr_frame_pass_batch(hr_ctx *c, int32_t max_ray_depth, int32_t *batch)
 int hr_flush(hr_ctx *c)
 {
     ENTER(c);
-    return drainPipeline(c);
+    const int rc = drainPipeline(c);
+    return rc ? rc : overflowCheck(c); // (no wait here: what the kernels have reported so far)
 }
 
 int hr_get_stats(hr_ctx *c, hr_pass_stats *out)
@@ -2487,6 +2606,10 @@ int hr_get_stats(hr_ctx *c, hr_pass_stats *out)
     std::vector<Stats> parts(kStatSlots);
     HIP_TRY(c, hipMemcpyAsync(parts.data(), c->dStats, sizeof(Stats) * kStatSlots, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    {
+        const int rc = overflowCheck(c);
+        if (rc) return rc;
+    }
     Stats s{};
     for (const Stats &p : parts) {
         s.paths += p.paths, s.raysClosest += p.raysClosest, s.raysAny += p.raysAny, s.shadedHits += p.shadedHits;
@@ -2537,14 +2660,17 @@ int hr_get_step_log(hr_ctx *c, hr_step_record *out, int32_t capacity, int32_t *n
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     const unsigned long long total = parts[0].traceLaunches;
     const unsigned long long first = total > (unsigned long long)kStepLogCap ? total - (unsigned long long)kStepLogCap : 0ull;
+    // Records are appended when a step's k_trace has ENDED (k_shade_sort writes them), so with several pipeline groups they arrive out of
+    // start order: they are handed out sorted by start, each with its group.
+    std::vector<const unsigned long long *> recs;
+    for (unsigned long long i = first; i < total; ++i) recs.push_back(&log[3 * (size_t)(i % (unsigned long long)kStepLogCap)]);
+    std::stable_sort(recs.begin(), recs.end(), [](const unsigned long long *a, const unsigned long long *b) { return a[0] < b[0]; });
     int32_t n = 0;
-    unsigned long long t0 = 0;
-    for (unsigned long long i = first; i < total && n < capacity; ++i) {
-        const unsigned long long *rec = &log[3 * (size_t)(i % (unsigned long long)kStepLogCap)];
-        if (n == 0) t0 = rec[0];
-        out[n].start_ms = (double)(rec[0] - t0) * 1e-5; // 100 MHz device clock
+    for (const unsigned long long *rec : recs) {
+        if (n >= capacity) break;
+        out[n].start_ms = (double)(rec[0] - recs[0][0]) * 1e-5; // 100 MHz device clock
         out[n].trace_ms = (float)((double)(rec[1] - rec[0]) * 1e-5);
-        out[n].passes_in_flight = (int32_t)(uint32_t)rec[2], out[n].passes_injected = (int32_t)(rec[2] >> 32), out[n].reserved = 0;
+        out[n].passes_in_flight = (int32_t)(rec[2] & 0xFFFFull), out[n].group = (int32_t)((rec[2] >> 16) & 0xFFull), out[n].passes_injected = (int32_t)(rec[2] >> 32);
         ++n;
     }
     *n_records = n;
@@ -2562,6 +2688,10 @@ int hr_readback(hr_ctx *c, const float **rgba, int32_t *w, int32_t *h)
     }
     HIP_TRY(c, hipMemcpyAsync(c->pinned, c->fb(), bytes, hipMemcpyDeviceToHost, c->stream));
     QUIESCE(c);
+    {
+        const int rc = overflowCheck(c);
+        if (rc) return rc;
+    }
     *rgba = c->pinned;
     if (w) *w = c->W;
     if (h) *h = c->H;
@@ -2574,6 +2704,7 @@ int hr_readback_progressive(hr_ctx *c, const float **rgba, int32_t *w, int32_t *
     if (c->W <= 0 || !rgba) FAIL(c, HR_ERR_INVALID, "no frame");
     const size_t bytes = (size_t)c->W * c->H * 4 * sizeof(float);
     int rc = completeForSlowCaller(c);
+    if (rc == HR_OK) rc = overflowCheck(c);
     if (rc) return rc;
     // no drain: the resolves enqueued so far are ordered before this copy on the ctx stream
     rc = ensureLagged(c, c->progFrame, bytes, false);

@@ -54,7 +54,12 @@ struct SegDev {
     uint32_t packets;    // the entry's closest-hit queue (camera rays) is filled AND traced by k_raygen_packets this step: k_trace leaves it out; 2: that kernel runs beside k_trace (the queue's length is not final when k_trace starts)
     hr_pass_params pp;   // per-pass uniforms
     int32_t closestEnabled; // 0 in a pass's last step (only its occlusion rays remain)
-    int32_t pad;
+    // Capacities of the queues beside hitCap (which also bounds hits / hitIdx / qout): every append compares its slot with them and every
+    // reader clamps the counter it reads — a bound that turns out wrong drops rays and raises StepTable::hostOverflow instead of
+    // writing past an arena (hr_render.hip: queueOverflow)
+    uint32_t qinCap;  // rays qin can hold
+    uint32_t sInCap;  // occlusion rays sqIn can hold
+    uint32_t sOutCap; // occlusion rays sqOut can hold
 };
 
 #ifndef HR_MAX_SEGS
@@ -82,13 +87,16 @@ struct StepTable {
     unsigned long long *hostSeq;
     unsigned long long seqValue;
     // log of the k_trace launches since the last hr_clear (hr_get_step_log): k_shade_sort appends (first start, last end) by the device clock
-    unsigned long long *stepLog; // kStepLogCap x {start tick, end tick, passes in the table | passes injected << 32}
+    unsigned long long *stepLog; // kStepLogCap x {start tick, end tick, passes in the table | group << 16 | passes injected << 32}
     uint32_t nInjectedNow;
-    uint32_t padL;
+    uint32_t group; // pipeline group the step belongs to (goes into its log record)
     // k_packet_probe adds (children a packet entered x its rays, child boxes the rays themselves entered, 1 per finished wave) to
     // probe[0..2]; k_trace's first workgroup copies the totals to pinned host memory with the queue lengths (hr_core.hip: the packet selector)
     unsigned long long *probe;
     unsigned long long *hostProbe;
+    // Sticky overflow report (pinned host memory, four words: queue kind, the step's number, table entry, count seen): set by the first
+    // append or read that finds a queue longer than its capacity; hr_flush / hr_readback / hr_synchronize turn it into HR_ERR_DEVICE
+    uint32_t *hostOverflow;
     uint32_t *hostCameraCount; // pinned: camera rays per pass behind the root cull, as the step's shading kernel last saw them in queues a packet kernel filled (a hint for the host's scheduling, no ordering)
     // The work cursors of k_trace: the index space of a launch is cut into 2^headsLog2 equal ranges (32 by default, at most
     // kTraceHeadsMax), each with a cursor on a cache line of its own — none of them shares its 128-byte line with the header above

@@ -81,6 +81,32 @@ HRD uint32_t waveSum(uint32_t v)
     return v;
 }
 
+// ---- queue guards.  Queue capacities are upper bounds the host derives (hr_core.hip::macroStep); should one ever be wrong, the append
+// that does not fit is DROPPED and the reader sees the counter clamped, and the first such event is reported to pinned host memory
+// (kind of queue, step, table entry, count): the next hr_flush / hr_readback / hr_synchronize fails with HR_ERR_DEVICE naming it — instead
+// of a write past the end of an arena (round 4 met one as a memory fault while the packet kernel's partial count served as a bound).
+enum OverflowKind : uint32_t { OVF_CAMERA = 1, OVF_CLOSEST_IN = 2, OVF_OCCLUSION_IN = 3, OVF_CLOSEST_OUT = 4, OVF_OCCLUSION_OUT = 5, OVF_HIT_LIST = 6 };
+__device__ __attribute__((noinline)) void queueOverflow(const StepTable *tbl, uint32_t kind, uint32_t seg, uint32_t count)
+{
+    uint32_t *h = tbl->hostOverflow;
+    if (!h) return;
+    __hip_atomic_store(&h[1], (uint32_t)tbl->seqValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&h[2], seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&h[3], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&h[0], kind, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+HRD uint32_t closestCap(const SegDev &sg) { return sg.qinCap < sg.hitCap ? sg.qinCap : sg.hitCap; } // (hits and the hit list are as long as the step's bound)
+HRD uint32_t closestCount(const SegDev &sg) // rays of the closest-hit queue that are really there
+{
+    const uint32_t n = *sg.qCountIn, cap = closestCap(sg);
+    return n < cap ? n : cap;
+}
+HRD uint32_t occlusionCount(const SegDev &sg)
+{
+    const uint32_t n = *sg.sCountIn;
+    return n < sg.sInCap ? n : sg.sInCap;
+}
+
 HRD uint32_t packMeta(const Ray &r)
 {
     return (uint32_t)(r.sequenceID & 0xFF) | ((uint32_t)(r.depth & 0xFFFF) << 8) | ((uint32_t)r.missKind << 24) | ((uint32_t)r.missIdx << 27);
@@ -166,7 +192,12 @@ __global__ __launch_bounds__(kRaygenBlock) void k_raygen(const SceneDev *__restr
     const bool active = c.active, enqueue = c.enqueue;
     uint32_t nAcc = c.nAcc;
     const uint32_t slot = blockReserve(enqueue, seg.qCountIn, scratch);
-    if (enqueue) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
+    if (enqueue) {
+        if (slot < closestCap(seg))
+            storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
+        else
+            queueOverflow(tbl, OVF_CAMERA, (uint32_t)segs.seg[blockIdx.y], slot + 1u);
+    }
     const uint32_t n = waveSum(active ? 1u : 0u), nCulled = waveSum((active && !enqueue) ? 1u : 0u);
     nAcc = waveSum(nAcc);
     if (laneId() == 0) {
@@ -271,8 +302,12 @@ HRD void buildSegStarts(const StepTable *tbl, uint32_t *segStart /* LDS, 2*kMaxS
     const int n = tbl->nSeg;
     for (int k = threadIdx.x; k < n; k += blockDim.x) {
         const SegDev &sg = tbl->seg[k];
-        segStart[2 * k] = (sg.closestEnabled && !(skipPackets && sg.packets)) ? *sg.qCountIn : 0u;
-        segStart[2 * k + 1] = closestOnly ? 0u : *sg.sCountIn;
+        segStart[2 * k] = (sg.closestEnabled && !(skipPackets && sg.packets)) ? closestCount(sg) : 0u;
+        segStart[2 * k + 1] = closestOnly ? 0u : occlusionCount(sg);
+        if (blockIdx.x == 0) { // (a queue longer than what the host provided for: its tail was dropped when it was written)
+            if (sg.closestEnabled && sg.packets != 2u && *sg.qCountIn > closestCap(sg)) queueOverflow(tbl, OVF_CLOSEST_IN, (uint32_t)k, *sg.qCountIn);
+            if (!closestOnly && *sg.sCountIn > sg.sInCap) queueOverflow(tbl, OVF_OCCLUSION_IN, (uint32_t)k, *sg.sCountIn);
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64) {
@@ -320,7 +355,7 @@ __device__ __attribute__((noinline)) void reportQueueLengths(const StepTable *tb
 {
     if (!tbl->hostCounts) return;
     for (int k = (int)threadIdx.x; k < tbl->nSeg; k += kTraceBlock)
-        __hip_atomic_store(&tbl->hostCounts[k], !tbl->seg[k].closestEnabled ? 0u : (tbl->seg[k].packets == 2u ? tbl->seg[k].hitCap : *tbl->seg[k].qCountIn), __ATOMIC_RELAXED,
+        __hip_atomic_store(&tbl->hostCounts[k], !tbl->seg[k].closestEnabled ? 0u : (tbl->seg[k].packets == 2u ? closestCap(tbl->seg[k]) : closestCount(tbl->seg[k])), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_SYSTEM); // (packets == 2: the packet kernel runs BESIDE this one and is still filling the queue: its capacity is the bound)
     if (threadIdx.x < 4 && tbl->hostProbe) // (the packet probe's totals so far)
         __hip_atomic_store(&tbl->hostProbe[threadIdx.x], __hip_atomic_load(&tbl->probe[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELAXED,
@@ -331,7 +366,7 @@ __device__ __attribute__((noinline)) void reportQueueLengths(const StepTable *tb
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
+__global__ __launch_bounds__(kTraceBlock, 5) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
                                                   StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ int stack[kTraceWaves][kStackLDS][64];
@@ -379,7 +414,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
     HitRec best;
     best.prim = kMissPrim, best.t = 0, best.u = 0, best.v = 0;
     int ovf[kStackOvf];
-    const float tmin = S.rayEps;
+    const float tmin = S.rayEps, hitPad = S.hitPad;
     const int rootRef = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
 
     uint32_t poolLo = 0, poolHi = 0; // wave-uniform: indices this wave has reserved and not handed out yet
@@ -651,6 +686,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(const SceneDev *__restric
                     if (!(v >= 0.0f) || u + v > 1.0f) continue;
                     const float t = dot(e2, qvec) * inv;
                     if (!(t > tmin) || !(t < tmax)) continue;
+                    // (the hit test's second half, hr_trace.h.  On the live triangle: re-reading it from L1 one axis at a time, to shorten
+                    // the live ranges, measured 0.5-1.5 % slower — profiles/r5b_hitbox_ab.txt.  The kernel keeps its five waves per SIMD
+                    // because its launch bounds say so: the compiler then allocates for 96 registers without spilling.)
+                    if (!hitInTriBox(v0, e1, e2, o, d, t, hitPad)) continue;
                     if (isAny) {
                         if ((__float_as_uint(trr.z) & TF_NON_OCCLUDER) && alphaPasses(S, prim, u, v)) continue;
                         best.prim = 0u; // occluded (anything but kMissPrim)
@@ -832,15 +871,6 @@ struct LaneStack { // wave-uniform stack held in the LANES of three registers: e
         if (sp < 128) return __builtin_amdgcn_readlane(r1, sp - 64);
         return __builtin_amdgcn_readlane(r2, sp - 128);
     }
-    // one bit per entry and LANE beside the wave-uniform references: did this lane's own ray enter the box of the child pushed at sp?
-    unsigned long long b0, b1, b2;
-    HRD void setOwn(int sp, bool mine)
-    {
-        const unsigned long long bit = 1ull << (sp & 63);
-        unsigned long long &b = sp < 64 ? b0 : (sp < 128 ? b1 : b2);
-        b = mine ? (b | bit) : (b & ~bit);
-    }
-    HRD bool own(int sp) const { return (((sp < 64 ? b0 : (sp < 128 ? b1 : b2)) >> (sp & 63)) & 1ull) != 0ull; }
 };
 static_assert(kStackLDS + kStackOvf <= 192, "the packet stack holds the deepest tree the builder can make");
 
@@ -850,19 +880,14 @@ HRD void cswapS(uint32_t &a, uint32_t &b)
     a = lo, b = hi;
 }
 
-// One packet: every lane walks the wave's traversal with its own ray (o, d, tmax; a lane without a ray passes tmax = 0: it enters
-// nothing and hits nothing).  PROBE also counts, per node step, the children the PACKET entered (`entered`, wave-uniform) and the
-// children this lane's own box test entered (`own`): what the packet costs against its rays traced one by one.
-// Möller–Trumbore on triangles [first, first + count) of the leaf-ordered array for the lanes with `mine`; the operation order is part of the
-// arithmetic contract (hr_trace.h)
-template <bool STATS>
-HRD void packetTriangles(ConstTris tris, int first, int count, bool mine, v3 o, v3 d, float tmin, float tmax, uint32_t skipPrim, HitRec &best, float &tlim, uint32_t &nt)
+// The hit test (hr_trace.h: Möller–Trumbore, then the hit point inside the triangle's half-padded box; the operation order is part of the
+// arithmetic contract) on triangles [first, first + count) of the leaf-ordered array, every lane with its own ray
+HRD void packetTriangles(ConstTris tris, int first, int count, v3 o, v3 d, float tmin, float tmax, float hitPad, uint32_t skipPrim, HitRec &best, float &tlim)
 {
     for (int k = 0; k < count; ++k) {
         const float4 tp = tris[first + k].p, tq = tris[first + k].q, trr = tris[first + k].r;
-        if (STATS) ++nt;
         const uint32_t prim = __float_as_uint(trr.y);
-        if (!mine || prim == skipPrim) continue;
+        if (prim == skipPrim) continue;
         const v3 v0(tp.x, tp.y, tp.z), e1(tp.w, tq.x, tq.y), e2(tq.z, tq.w, trr.x);
         const v3 pvec = cross(d, e2);
         const float det = dot(e1, pvec);
@@ -876,6 +901,7 @@ HRD void packetTriangles(ConstTris tris, int first, int count, bool mine, v3 o, 
         if (!(v >= 0.0f) || u + v > 1.0f) continue;
         const float t = dot(e2, qvec) * inv;
         if (!(t > tmin) || !(t < tmax)) continue;
+        if (!hitInTriBox(v0, e1, e2, o, d, t, hitPad)) continue;
         const uint32_t bp = best.prim & 0x7FFFFFFFu;
         if (best.prim == kMissPrim || t < best.t || (t == best.t && prim < bp)) {
             best.prim = prim | ((det > 0.0f) ? 0x80000000u : 0u);
@@ -886,13 +912,13 @@ HRD void packetTriangles(ConstTris tris, int first, int count, bool mine, v3 o, 
 }
 
 // One packet: every lane walks the wave's traversal with its own ray (o, d, tmax; a lane without a ray passes tmax = 0: it enters
-// nothing and hits nothing).  A lane tests a triangle only when ITS OWN ray enters the triangle's leaf box — the test k_trace makes for the
-// same ray at the same node — not whenever the packet gets there: float32 Möller–Trumbore accepts, once in ~10^9 rays, a ray that passes
-// a sliver triangle at a distance, and such a phantom hit must not depend on which rays travel together (found by a 600-pass soak: two
-// pixels of 2 M differed between packets and one ray per lane; tools/r4_soak_digest.py).  So the stack carries, beside each wave-uniform
-// child reference, one bit per lane: did this lane's own ray enter that child's box.  PROBE also counts, per node step, the
-// children the PACKET entered (`entered`, wave-uniform) and the children this lane's own box test entered (`own`): what the packet costs
-// against its rays traced one by one.
+// nothing and hits nothing).  A lane tests every triangle the PACKET reaches, whether or not its own ray entered the triangle's box:
+// the hit test's answer does not depend on which triangles a traversal tests (hr_trace.h: hitInTriBox — a hit point lies inside every
+// box above its triangle, so a ray that hits is a ray whose own traversal would have got there; rounds 4's per-lane "own box" bits,
+// which made a lane test exactly what k_trace tests, are gone with the phantom hits they were there for).  STATS counts, per lane, the
+// inner children (`nv`) and leaf children (`nt`) the lane's OWN box test entered — the figures of that ray traced alone; PROBE also
+// counts, per node step, the children the PACKET entered (`entered`, wave-uniform) and the children this lane's own box test entered
+// (`own`): what the packet costs against its rays traced one by one.
 template <bool STATS, bool PROBE>
 HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 o, v3 d, float tmax, uint32_t skipPrim, HitRec &best, uint32_t &nv, uint32_t &nt,
                         uint32_t &entered, uint32_t &own)
@@ -902,14 +928,13 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
     const float idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
     const RayK rk = rayFrame(o, idx, idy, idz);
     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
-    LaneStack stk{0, 0, 0, 0ull, 0ull, 0ull};
+    LaneStack stk{0, 0, 0};
     int sp = 0;
     int cur = (S.nTris == 0) ? kSentinel : (S.rootLeafCount > 0 ? ~(0 | ((S.rootLeafCount - 1) << 28)) : 0);
-    bool mineCur = true; // this lane's own ray entered the box of `cur` (a root leaf has no box: every ray tests it)
+    if (STATS) nv += (cur >= 0 && cur != kSentinel) ? 1u : 0u, nt += cur < 0 ? (uint32_t)S.rootLeafCount : 0u; // (the root)
     while (cur != kSentinel) {
         cur = __builtin_amdgcn_readfirstlane(cur);
         if (cur >= 0) {
-            if (STATS) ++nv;
             const float4 a = nodes[cur].a;
             const uint4 qb = nodes[cur].b, qc = nodes[cur].c;
             const uint32_t meta = __float_as_uint(a.w);
@@ -923,7 +948,6 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
             const uint32_t nY = rk.idy < 0.0f ? qc.x : qb.y, fY = rk.idy < 0.0f ? qb.y : qc.x;
             const uint32_t nZ = rk.idz < 0.0f ? qc.y : qb.z, fZ = rk.idz < 0.0f ? qb.z : qc.y;
             uint32_t key[4];
-            uint32_t ownBits = 0u; // children this lane's own ray enters
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 key[c] = 0xFFFFFFFFu;
@@ -936,7 +960,12 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
                 const bool enters = tn <= tf;
                 const unsigned long long m = __ballot(enters);
                 if (PROBE) own += enters ? 1u : 0u, entered += m ? 1u : 0u;
-                ownBits |= enters ? (1u << c) : 0u;
+                if (STATS) {
+                    if ((uint32_t)c < nInner)
+                        nv += enters ? 1u : 0u;
+                    else
+                        nt += enters ? 1u : 0u;
+                }
                 // the wave's key of the child: the entry distance of the first lane that enters it
                 if (m) key[c] = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) & ~3u) | (uint32_t)c;
             }
@@ -946,27 +975,23 @@ HRD void packetTraverse(const SceneDev &S, ConstNodes nodes, ConstTris tris, v3 
                 if (key[j] != 0xFFFFFFFFu) {
                     const int sl = (int)(key[j] & 3u);
                     stk.push(sp, (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl);
-                    if ((uint32_t)sl >= nInner) stk.setOwn(sp, ((ownBits >> sl) & 1u) != 0u); // (only a leaf's bit is ever read)
                     ++sp;
                 }
             if (key[0] != 0xFFFFFFFFu) {
                 const int sl = (int)(key[0] & 3u);
                 cur = (((uint32_t)sl < nInner) ? innerBase : leafKey) + sl;
-                mineCur = ((ownBits >> sl) & 1u) != 0u;
             } else if (sp > 0) {
                 --sp;
                 cur = stk.at(sp);
-                if (cur < 0) mineCur = stk.own(sp);
             } else {
                 cur = kSentinel;
             }
-        } else { // a leaf: its triangle(s), for the lanes whose own ray entered its box
+        } else { // a leaf: its triangle(s)
             const int enc = ~cur;
-            packetTriangles<STATS>(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, mineCur, o, d, tmin, tmax, skipPrim, best, tlim, nt);
+            packetTriangles(tris, enc & 0x0FFFFFFF, (enc >> 28) + 1, o, d, tmin, tmax, S.hitPad, skipPrim, best, tlim);
             if (sp > 0) {
                 --sp;
                 cur = stk.at(sp);
-                if (cur < 0) mineCur = stk.own(sp);
             } else {
                 cur = kSentinel;
             }
@@ -1022,9 +1047,11 @@ __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__r
     if (threadIdx.x < nPass) firstSlot[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(tbl->seg[segs.seg[threadIdx.x]].qCountIn, cnt[threadIdx.x]) : 0u;
     __syncthreads();
     const uint32_t slot = firstSlot[pass] + rank;
-    if (enqueue) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
+    const bool fits = slot < closestCap(seg);
+    if (enqueue && fits) storeRay(seg.qin, slot, r, pixel, 0xFFFFFFFFu);
+    if (enqueue && !fits) queueOverflow(tbl, OVF_CAMERA, (uint32_t)segs.seg[pass], slot + 1u);
     const unsigned long long enqMask = __ballot(enqueue);
-    const uint32_t n = waveSum(active ? 1u : 0u), nEnq = (uint32_t)__popcll(enqMask);
+    const uint32_t n = waveSum(active ? 1u : 0u);
     nAcc = waveSum(nAcc);
     if (lane == 0) {
         if (n) atomicAdd(&stats->paths, (unsigned long long)n);
@@ -1036,10 +1063,10 @@ __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__r
     uint32_t nv = 0, nt = 0, entered = 0, own = 0;
     packetTraverse<STATS, false>(S, (ConstNodes)(uintptr_t)nodesG, (ConstTris)(uintptr_t)trisG, enqueue ? r.o : v3(0.0f), enqueue ? r.d : v3(0.0f, 0.0f, 1.0f),
                                  enqueue ? r.maxT : 0.0f, 0xFFFFFFFFu, best, nv, nt, entered, own);
-    if (enqueue) G(seg.hits)[slot] = best;
-    if (STATS && lane == 0) { // per ray: the node steps and triangle tests its lane executed (the packet's union, not the ray's own set)
-        atomicAdd(&stats->nodeVisits, (unsigned long long)nv * nEnq);
-        atomicAdd(&stats->triTests, (unsigned long long)nt * nEnq);
+    if (enqueue && fits) G(seg.hits)[slot] = best;
+    if (STATS) { // per ray: the nodes and triangles its OWN box tests reached (what the ray costs traced alone; the packet's union is the probe's business)
+        nv = waveSum(enqueue ? nv : 0u), nt = waveSum(enqueue ? nt : 0u);
+        if (lane == 0) atomicAdd(&stats->nodeVisits, (unsigned long long)nv), atomicAdd(&stats->triTests, (unsigned long long)nt);
     }
 }
 
@@ -1157,16 +1184,16 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
         const unsigned long long idx = atomicAdd(&stats->traceLaunches, 1ull); // (this thread always adds to the first copy of the counters)
         if (tbl->stepLog) {
             unsigned long long *rec = tbl->stepLog + 3ull * (idx % (unsigned long long)kStepLogCap);
-            rec[0] = lo, rec[1] = hi, rec[2] = (unsigned long long)(uint32_t)nSeg | ((unsigned long long)tbl->nInjectedNow << 32);
+            rec[0] = lo, rec[1] = hi, rec[2] = (unsigned long long)(uint32_t)nSeg | ((unsigned long long)(tbl->group & 0xFFu) << 16) | ((unsigned long long)tbl->nInjectedNow << 32);
         }
         if (tbl->hostCameraCount) { // (the packet kernel ran beside k_trace, whose report could only give these queues' capacity)
             unsigned long long sum = 0, cnt = 0;
             for (int k = tbl->primaryFromSeg; k < nSeg; ++k)
-                if (tbl->seg[k].packets == 2u) sum += *tbl->seg[k].qCountIn, ++cnt;
+                if (tbl->seg[k].packets == 2u) sum += closestCount(tbl->seg[k]), ++cnt;
             if (cnt) __hip_atomic_store(tbl->hostCameraCount, (uint32_t)(sum / cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? *tbl->seg[k].qCountIn : 0u; });
+    buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? closestCount(tbl->seg[k]) : 0u; });
     const uint32_t total = start[nSeg];
     const bool glassToo = tbl->hasGlass != 0;
     uint32_t nAccum = 0;
@@ -1200,11 +1227,14 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
         const int sLo = findStart(start, nSeg, base), sHi = findStart(start, nSeg, base + last); // (uniform over the workgroup)
         if (sLo == sHi) { // the usual case: one reservation per workgroup and list
             const SegDev &sg = tbl->seg[sLo];
+            // (a list entry is one of the queue's rays, and there are at most hitCap of those: the slots cannot run out — checked all the same)
             const uint32_t pSlot = blockReserve(cls == 0, sg.pCount, scratch);
-            if (cls == 0) G(sg.hitIdx)[pSlot] = li;
+            if (cls == 0 && pSlot < sg.hitCap) G(sg.hitIdx)[pSlot] = li;
+            if (cls == 0 && pSlot >= sg.hitCap) queueOverflow(tbl, OVF_HIT_LIST, (uint32_t)sLo, pSlot + 1u);
             if (glassToo) {
                 const uint32_t gSlot = blockReserve(cls == 1, sg.gCount, scratch);
-                if (cls == 1) G(sg.hitIdx)[sg.hitCap - 1u - gSlot] = li;
+                if (cls == 1 && gSlot < sg.hitCap) G(sg.hitIdx)[sg.hitCap - 1u - gSlot] = li;
+                if (cls == 1 && gSlot >= sg.hitCap) queueOverflow(tbl, OVF_HIT_LIST, (uint32_t)sLo, gSlot + 1u);
             }
         } else { // a batch that straddles passes: one reservation per wave, list and pass present in the wave
             unsigned long long todo = __ballot(cls >= 0);
@@ -1214,9 +1244,11 @@ __global__ __launch_bounds__(kSortBlock) void k_shade_sort(const SceneDev *__res
                 todo &= ~__ballot(mine);
                 const SegDev &sg = tbl->seg[s];
                 const uint32_t pSlot = waveReserve(mine && cls == 0, sg.pCount);
-                if (mine && cls == 0) G(sg.hitIdx)[pSlot] = li;
+                if (mine && cls == 0 && pSlot < sg.hitCap) G(sg.hitIdx)[pSlot] = li;
+                if (mine && cls == 0 && pSlot >= sg.hitCap) queueOverflow(tbl, OVF_HIT_LIST, (uint32_t)s, pSlot + 1u);
                 const uint32_t gSlot = waveReserve(mine && cls == 1, sg.gCount);
-                if (mine && cls == 1) G(sg.hitIdx)[sg.hitCap - 1u - gSlot] = li;
+                if (mine && cls == 1 && gSlot < sg.hitCap) G(sg.hitIdx)[sg.hitCap - 1u - gSlot] = li;
+                if (mine && cls == 1 && gSlot >= sg.hitCap) queueOverflow(tbl, OVF_HIT_LIST, (uint32_t)s, gSlot + 1u);
             }
         }
     }
@@ -1236,7 +1268,10 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
     const SceneDev &S = *Sp;
     stats += blockIdx.x & (kStatSlots - 1);
     const int nSeg = tbl->nSeg;
-    buildStarts(start, nSeg, [&](int k) { return tbl->seg[k].closestEnabled ? *(CLS == 0 ? tbl->seg[k].pCount : tbl->seg[k].gCount) : 0u; });
+    buildStarts(start, nSeg, [&](int k) {
+        const uint32_t listed = tbl->seg[k].closestEnabled ? *(CLS == 0 ? tbl->seg[k].pCount : tbl->seg[k].gCount) : 0u;
+        return listed < tbl->seg[k].hitCap ? listed : tbl->seg[k].hitCap;
+    });
     const uint32_t total = start[nSeg];
     constexpr bool LOD = (MODE & 1) != 0, ALL = (MODE & 2) != 0;
     uint32_t nShaded = 0, nAccum = 0;
@@ -1289,7 +1324,8 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
             const SegDev &sg = tbl->seg[sLo];
             const bool wantS = live && nee.valid;
             const uint32_t sSlot = blockReserve(wantS, sg.sCountOut, scratch);
-            if (wantS) {
+            if (wantS && sSlot >= sg.sOutCap) queueOverflow(tbl, OVF_OCCLUSION_OUT, (uint32_t)sLo, sSlot + 1u);
+            if (wantS && sSlot < sg.sOutCap) {
                 G(sg.sqOut.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
                 G(sg.sqOut.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
                 G(sg.sqOut.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
@@ -1302,7 +1338,8 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                 for (int j = 0; j < (CLS == 1 ? 1 : 3); ++j) {
                     const bool wantX = live && extra[j].valid;
                     const uint32_t sx = blockReserve(wantX, sg.sCountOut, scratch);
-                    if (wantX) {
+                    if (wantX && sx >= sg.sOutCap) queueOverflow(tbl, OVF_OCCLUSION_OUT, (uint32_t)sLo, sx + 1u);
+                    if (wantX && sx < sg.sOutCap) {
                         G(sg.sqOut.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
                         G(sg.sqOut.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
                         G(sg.sqOut.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
@@ -1311,7 +1348,8 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
             }
             const bool wantQ = live && next.valid;
             const uint32_t qSlot = blockReserve(wantQ, sg.qCountOut, scratch);
-            if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
+            if (wantQ && qSlot < sg.hitCap) storeRay(sg.qout, qSlot, next, pixel, prim);
+            if (wantQ && qSlot >= sg.hitCap) queueOverflow(tbl, OVF_CLOSEST_OUT, (uint32_t)sLo, qSlot + 1u);
         } else {
             unsigned long long todo = __ballot(live && (nee.valid || next.valid || (ALL && (extra[0].valid || extra[1].valid || extra[2].valid))));
             while (todo != 0ull) {
@@ -1321,7 +1359,8 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                 const SegDev &sg = tbl->seg[s];
                 const bool wantS = mine && nee.valid;
                 const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
-                if (wantS) {
+                if (wantS && sSlot >= sg.sOutCap) queueOverflow(tbl, OVF_OCCLUSION_OUT, (uint32_t)s, sSlot + 1u);
+                if (wantS && sSlot < sg.sOutCap) {
                     G(sg.sqOut.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
                     G(sg.sqOut.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
                     G(sg.sqOut.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
@@ -1332,7 +1371,8 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                     for (int j = 0; j < (CLS == 1 ? 1 : 3); ++j) {
                         const bool wantX = mine && extra[j].valid;
                         const uint32_t sx = waveReserve(wantX, sg.sCountOut);
-                        if (wantX) {
+                        if (wantX && sx >= sg.sOutCap) queueOverflow(tbl, OVF_OCCLUSION_OUT, (uint32_t)s, sx + 1u);
+                        if (wantX && sx < sg.sOutCap) {
                             G(sg.sqOut.A)[sx] = make_float4(hitP.x, hitP.y, hitP.z, extra[j].maxT);
                             G(sg.sqOut.B)[sx] = make_float4(extra[j].d.x, extra[j].d.y, extra[j].d.z, __uint_as_float(prim));
                             G(sg.sqOut.C)[sx] = make_float4(extra[j].value.x, extra[j].value.y, extra[j].value.z, __uint_as_float(pixel + (uint32_t)(j + 1) * framePixels));
@@ -1341,7 +1381,8 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                 }
                 const bool wantQ = mine && next.valid;
                 const uint32_t qSlot = waveReserve(wantQ, sg.qCountOut);
-                if (wantQ) storeRay(sg.qout, qSlot, next, pixel, prim);
+                if (wantQ && qSlot < sg.hitCap) storeRay(sg.qout, qSlot, next, pixel, prim);
+                if (wantQ && qSlot >= sg.hitCap) queueOverflow(tbl, OVF_CLOSEST_OUT, (uint32_t)s, qSlot + 1u);
             }
         }
     }

@@ -2,9 +2,10 @@
 //
 // Replaces what OpenRL does inside rlRenderFrame() for every ray
 // (/root/reference/Source/HeatrayRenderer/PassGenerator.cpp:386).
-// The hit is defined by the triangle test alone — (t, prim id) lexicographic minimum over
-// t in (tmin, tmax) — so it does not depend on the acceleration structure; the slab test only has
-// to be conservative (boxes are padded at build time).  While-while traversal: all lanes descend
+// The hit is defined by the triangle test alone — Möller–Trumbore AND the hit point inside the triangle's
+// half-padded bounding box (hitInTriBox below), (t, prim id) lexicographic minimum over t in (tmin, tmax) —
+// so it does not depend on the acceleration structure; the slab test only has to be conservative (boxes
+// are padded at build time).  While-while traversal: all lanes descend
 // inner nodes until each holds a leaf, then all test triangles.  The deferred-child stack lives in
 // LDS, one column per lane ([entry][lane] => bank = lane, conflict-free), with a private overflow
 // region sized for the deepest tree the builder can produce (kStackLDS + kStackOvf >= 3 x kMaxTreeLevels;
@@ -137,6 +138,27 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
     }
 }
 
+// THE HIT TEST'S SECOND HALF: a Möller–Trumbore candidate (u, v, t in range) is a hit only if its hit point
+// o + t d lies inside the triangle's own bounding box grown by `h` = half the leaf padding.  float32 Möller–Trumbore alone accepts,
+// about once in 10^9 rays, a ray that passes a SLIVER triangle at a distance (the determinant is a difference of nearly equal
+// products), and whether a traversal ever tests that triangle depends on the boxes of its tree.  With this rule it does not: every
+// conservative tree's leaf box contains the triangle's box grown by the WHOLE padding, so a hit point inside the half-grown box is
+// inside every ancestor's box with half a padding (5e-6 |diagonal|, ~50 ulp of a coordinate) to spare for the rounding of the slab
+// tests — every traversal of every tree tests the triangle and finds the same answer; and a candidate whose point lies outside is a
+// hit for nobody, brute force included.  Same operations, same order as oracle_bvh.cpp::hitInTriBox.
+HRD bool hitInTriBoxAxis(float v0, float e1, float e2, float o, float d, float t, float h) // one coordinate of it
+{
+    const float p1 = v0 + e1, p2 = v0 + e2;
+    const float lo = fmin_(fmin_(v0, p1), p2), hi = fmax_(fmax_(v0, p1), p2);
+    const float P = o + t * d;
+    return P >= lo - h && P <= hi + h;
+}
+HRD bool hitInTriBox(v3 v0, v3 e1, v3 e2, v3 o, v3 d, float t, float h)
+{
+    return hitInTriBoxAxis(v0.x, e1.x, e2.x, o.x, d.x, t, h) && hitInTriBoxAxis(v0.y, e1.y, e2.y, o.y, d.y, t, h) &&
+           hitInTriBoxAxis(v0.z, e1.z, e2.z, o.z, d.z, t, h);
+}
+
 // Per-ray constants of the slab test: 1 / d and the ray origin over d
 HRD RayK rayFrame(v3 o, float idx, float idy, float idz) { return RayK{idx, idy, idz, o.x * idx, o.y * idy, o.z * idz}; }
 
@@ -243,6 +265,7 @@ HRD void traverse(const SceneDev &S, v3 o, v3 d, float tmin, float tmax, uint32_
                 if (!(v >= 0.0f) || u + v > 1.0f) continue;
                 const float t = dot(e2, qvec) * inv;
                 if (!(t > tmin) || !(t < tmax)) continue;
+                if (!hitInTriBox(v0, e1, e2, o, d, t, S.hitPad)) continue;
                 if (ANY) {
                     if ((__float_as_uint(trr.z) & TF_NON_OCCLUDER) && alphaPasses(S, prim, u, v)) continue;
                     best.prim = prim;

@@ -89,6 +89,7 @@ struct SceneDev {
     const TexDesc *textures;
     int32_t nTris, nNodes, rootLeafCount, nMaterials, nTextures;
     float rayEps;
+    float hitPad; // half the leaf padding: a hit point lies inside its triangle's bounding box grown by this much (hr_trace.h: hitInTriBox)
     hr_lights lights;
     // sample tables
     const float2 *seq, *aperture, *seqOffsets;

@@ -151,6 +151,11 @@ bool PassGenerator::runInitJob(const RLint renderWidth, const RLint renderHeight
     hr_ctx_desc desc;
     memset(&desc, 0, sizeof(desc));
     desc.world = 1;
+    if (hr_abi_version() != HR_ABI_VERSION) { // (a library with longer structs than this layer allocates would corrupt memory silently)
+        fprintf(stderr, "PassGenerator: libhrcore speaks ABI %u, this layer was built against %u: rebuild one of them\n", hr_abi_version(), HR_ABI_VERSION);
+        return false;
+    }
+    if (const char* mb = getenv("HEATRAY_MEMORY_BUDGET_MB")) desc.memory_budget = (uint64_t)strtoull(mb, nullptr, 10) << 20;
     if (hr_ctx_create(&desc, &m_context) != HR_OK) {
         fprintf(stderr, "PassGenerator: no usable MI355X / HIP device (there is no CPU fallback)\n");
         return false;

@@ -48,6 +48,14 @@ extern "C" {
 
 typedef struct hr_ctx hr_ctx;
 
+/* Version of this interface: bumped whenever a struct grows or a signature changes (5: hr_ctx_desc.memory_budget, hr_step_record.group,
+ * hr_abi_version itself; 4 was round 4's hr_display(..., passes_shown) and the grown hr_scene_info / hr_kernel_times).  A caller compares
+ * hr_abi_version() of the library it loaded with the HR_ABI_VERSION it was compiled against BEFORE anything else and refuses a
+ * mismatch — a library that writes a longer struct than the caller allocated corrupts memory silently otherwise.  The Python
+ * binding (heatray_amd/_ffi.py) and the C++ layer (heatray_amd/host/HeatrayRenderer/PassGenerator.cpp) do. */
+#define HR_ABI_VERSION 5u
+uint32_t hr_abi_version(void);
+
 /* ------------------------------------------------------------------ context */
 
 typedef struct hr_ctx_desc {
@@ -57,6 +65,11 @@ typedef struct hr_ctx_desc {
     int32_t tile_size;  /* tile edge in pixels (0 -> 32), SURVEY §8e                        */
     void *stream;       /* hipStream_t to launch on, or NULL for the null stream           */
     uint32_t flags;     /* HR_CTX_*                                                        */
+    /* Device memory the pass pipeline may hold for rays and pass buffers, in bytes (0: no limit — 31 GB for a 1080p render of 1 M
+     * triangles at the default 16 passes per step).  Fewer passes are then injected per pipeline step: first as many as fit when
+     * every ray queue is as long as it can possibly get, later as many as the lengths the render really shows allow.  Scene,
+     * textures and the frame itself are not counted.  A budget too small for ONE pass per step fails hr_render_pass (HR_ERR_INVALID). */
+    uint64_t memory_budget;
 } hr_ctx_desc;
 
 #define HR_CTX_COLLECT_STATS 1u /* count node visits / triangle tests per pass (slower) */
@@ -111,7 +124,8 @@ typedef struct hr_mesh_desc {
 
 typedef int32_t hr_geom_id;
 
-/* replaces Buffer::create + rlVertexAttribBuffer + rlDrawElements (Mesh.cpp:29-152) */
+/* replaces Buffer::create + rlVertexAttribBuffer + rlDrawElements (Mesh.cpp:29-152).  Positions and the transform must be finite
+ * (HR_ERR_INVALID otherwise: a NaN box has no order, and the tree builders and slab tests assume one). */
 int hr_geom_add(hr_ctx *ctx, const hr_mesh_desc *desc, hr_geom_id *out);
 /* replaces Scene::removeMesh / primitive destruction (Scene.h:52) */
 int hr_geom_remove(hr_ctx *ctx, hr_geom_id id);
@@ -417,7 +431,7 @@ typedef struct hr_step_record {
     float trace_ms;
     int32_t passes_in_flight;
     int32_t passes_injected;
-    int32_t reserved;
+    int32_t group;     /* pipeline group (worker stream) the step ran on; records are sorted by start_ms, whichever group they belong to */
 } hr_step_record;
 int hr_get_step_log(hr_ctx *ctx, hr_step_record *out, int32_t capacity, int32_t *n_records);
 

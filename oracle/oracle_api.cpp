@@ -52,6 +52,7 @@ Context &contextOf(hr_ctx *ctx) { return ctx->c; } // for the probes in oracle_s
 
 extern "C" {
 
+uint32_t ora_abi_version(void) { return HR_ABI_VERSION; }
 int ora_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
 {
     if (!out) return HR_ERR_INVALID;
@@ -104,6 +105,17 @@ int ora_geom_add(hr_ctx *ctx, const hr_mesh_desc *d, hr_geom_id *out)
     if (!d || !d->positions || !d->normals || !d->indices || d->n_vertices <= 0) ORA_FAIL(ctx, HR_ERR_INVALID, "mesh needs positions, normals, indices");
     for (int i = 0; i < d->n_indices; ++i)
         if (d->indices[i] >= (uint32_t)d->n_vertices) ORA_FAIL(ctx, HR_ERR_INVALID, "index out of range");
+    {
+        const int sb = d->position_stride == 0 ? 12 : d->position_stride;
+        for (int i = 0; i < d->n_vertices; ++i) {
+            float p[3];
+            std::memcpy(p, (const char *)d->positions + (size_t)i * (size_t)sb, 12);
+            for (int k = 0; k < 3; ++k)
+                if (!(fabsf(p[k]) <= 3.0e37f)) ORA_FAIL(ctx, HR_ERR_INVALID, "vertex positions must be finite");
+        }
+        for (int k = 0; k < 16; ++k)
+            if (!(fabsf(d->world_from_entity[k]) <= 3.0e37f)) ORA_FAIL(ctx, HR_ERR_INVALID, "world_from_entity must be finite");
+    }
     Geom g;
     g.alive = true;
     g.nVerts = d->n_vertices;
@@ -133,7 +145,9 @@ int ora_geom_remove(hr_ctx *ctx, hr_geom_id id)
 }
 int ora_geom_set_transform(hr_ctx *ctx, hr_geom_id id, const float m[16])
 {
-    if (id < 0 || id >= (int)ctx->c.geoms.size() || !ctx->c.geoms[id].alive) ORA_FAIL(ctx, HR_ERR_INVALID, "bad geom id");
+    if (id < 0 || id >= (int)ctx->c.geoms.size() || !ctx->c.geoms[id].alive || !m) ORA_FAIL(ctx, HR_ERR_INVALID, "bad geom id");
+    for (int k = 0; k < 16; ++k)
+        if (!(fabsf(m[k]) <= 3.0e37f)) ORA_FAIL(ctx, HR_ERR_INVALID, "world_from_entity must be finite");
     std::memcpy(ctx->c.geoms[id].world, m, 16 * sizeof(float));
     ctx->c.committed = false;
     return HR_OK;

@@ -7,9 +7,12 @@
 // spec (SURVEY §8a row a6, §8d "binary LBVH, <= 4 tris/leaf"):
 //
 //   * the HIT is defined independently of the acceleration structure: Möller–Trumbore
-//     in the operation order below, accepted for t in (tmin, tmax), closest hit =
-//     lexicographic minimum of (t, triangle id).  A brute-force loop over all
-//     triangles (ctx.brute) gives the same answer as any conservative BVH.
+//     in the operation order below, accepted for t in (tmin, tmax) when the hit point
+//     o + t d lies inside the triangle's bounding box grown by half the leaf padding
+//     (hitInTriBox), closest hit = lexicographic minimum of (t, triangle id).  A
+//     brute-force loop over all triangles (ctx.brute) gives the same answer as any
+//     conservative BVH — also for the phantom hits float32 Möller–Trumbore produces
+//     on sliver triangles, which the box condition turns away for everybody.
 //   * the BVH here is the LBVH spec the node-visit / triangle-test figures V and T of
 //     the roofline model are counted on: 30-bit Morton codes of the triangle-AABB
 //     centres normalised by the scene AABB, stable sort, Karras radix tree,
@@ -212,6 +215,25 @@ static inline bool intersectTri(const Tri &tr, vec3 o, vec3 d, float &t, float &
     return true;
 }
 
+// The hit test's second half: a Möller–Trumbore candidate is a hit only if its hit point o + t d lies inside the
+// triangle's own bounding box grown by half the leaf padding.  float32 Möller–Trumbore alone accepts, about once in 10^9 rays, a ray
+// that passes a sliver triangle at a distance, and whether a traversal ever TESTS that triangle depends on the boxes of its tree;
+// a hit point inside the half-padded box lies inside every box a conservative tree puts around the triangle (those contain the box
+// grown by the whole padding), with half a padding to spare for the rounding of the slab tests: every traversal of every tree — and
+// the brute-force loop — gives the same answer.
+static inline bool hitInTriBoxAxis(float v0, float e1, float e2, float o, float d, float t, float h)
+{
+    const float p1 = v0 + e1, p2 = v0 + e2;
+    const float lo = fmin_(fmin_(v0, p1), p2), hi = fmax_(fmax_(v0, p1), p2);
+    const float P = o + t * d;
+    return P >= lo - h && P <= hi + h;
+}
+static inline bool hitInTriBox(const Tri &tr, vec3 o, vec3 d, float t, float h)
+{
+    return hitInTriBoxAxis(tr.v0.x, tr.e1.x, tr.e2.x, o.x, d.x, t, h) && hitInTriBoxAxis(tr.v0.y, tr.e1.y, tr.e2.y, o.y, d.y, t, h) &&
+           hitInTriBoxAxis(tr.v0.z, tr.e1.z, tr.e2.z, o.z, d.z, t, h);
+}
+
 // Reciprocal direction for the slab test only: components with |d| < 1e-20 are replaced
 // so that no infinity / NaN enters the box test (the hit itself never uses this).
 static inline float safeInv(float d)
@@ -249,6 +271,7 @@ static bool traverse(const Context &ctx, vec3 o, vec3 d, float tmin, float tmax,
             float t, u, v;
             if (!intersectTri(bvh.tris[i], o, d, t, u, v)) continue;
             if (!(t > tmin) || !(t < tmax)) continue;
+            if (!hitInTriBox(bvh.tris[i], o, d, t, ctx.hitPad)) continue;
             if (ANY) {
                 if ((ctx.attrs[prim].flags & TF_NON_OCCLUDER) && alphaPasses(ctx, prim, u, v)) continue;
                 best.prim = prim, best.t = t, best.u = u, best.v = v;
@@ -302,6 +325,7 @@ template <bool ANY> static bool bruteForce(const Context &ctx, vec3 o, vec3 d, f
         float t, u, v;
         if (!intersectTri(ctx.tris[prim], o, d, t, u, v)) continue;
         if (!(t > tmin) || !(t < tmax)) continue;
+        if (!hitInTriBox(ctx.tris[prim], o, d, t, ctx.hitPad)) continue;
         if (ANY) {
             if ((ctx.attrs[prim].flags & TF_NON_OCCLUDER) && alphaPasses(ctx, prim, u, v)) continue;
             best.prim = prim, best.t = t, best.u = u, best.v = v;

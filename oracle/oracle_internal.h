@@ -123,6 +123,7 @@ struct Context {
     std::vector<TriAttr> attrs;  // submission order
     Bvh bvh;
     float rayEps = 0.0f;
+    float hitPad = 0.0f; // half the leaf padding (oracle_bvh.cpp: hitInTriBox)
     float aabbLo[3], aabbHi[3];
     bool brute = false; // brute-force intersection instead of the BVH (validation of the traversal)
     hr_pass_stats stats{};

@@ -308,6 +308,7 @@ void commitScene(Context &ctx)
     ctx.aabbLo[0] = lo.x, ctx.aabbLo[1] = lo.y, ctx.aabbLo[2] = lo.z;
     ctx.aabbHi[0] = hi.x, ctx.aabbHi[1] = hi.y, ctx.aabbHi[2] = hi.z;
     ctx.rayEps = 1e-4f * length(hi - lo);
+    ctx.hitPad = 0.5f * (1e-5f * length(hi - lo)); // half of buildLBVH's leaf padding
     buildLBVH(ctx.tris, ctx.bvh);
     ctx.committed = true;
 }

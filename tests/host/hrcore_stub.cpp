@@ -16,6 +16,7 @@ struct hr_ctx {
 };
 
 extern "C" {
+uint32_t hr_abi_version(void) { return HR_ABI_VERSION; }
 int hr_ctx_create(const hr_ctx_desc *, hr_ctx **out) { *out = new hr_ctx(); return HR_OK; }
 int hr_ctx_destroy(hr_ctx *c) { delete c; return HR_OK; }
 const char *hr_last_error(const hr_ctx *) { return "stub"; }

@@ -21,6 +21,16 @@ def test_header_and_python_binding_agree():
     assert sorted("hr_" + s for s in ffi.ABI_SYMBOLS) == declared_functions()
 
 
+def test_abi_version_of_header_binding_library_and_oracle_agree(oracle_lib):
+    text = open(os.path.join(ROOT, "include", "hrcore.h")).read()
+    (ver,) = re.findall(r"#define HR_ABI_VERSION (\d+)u", text)
+    assert int(ver) == ffi.HR_ABI_VERSION
+    for lib, name in ((core.load_library(), "hr_abi_version"), (oracle_lib, "ora_abi_version")):
+        fn = getattr(lib, name)
+        fn.restype = ctypes.c_uint32
+        assert fn() == ffi.HR_ABI_VERSION, name
+
+
 def test_library_exports_every_declared_symbol():
     lib = core.load_library()
     for name in declared_functions():
@@ -36,7 +46,7 @@ def test_oracle_mirrors_the_abi(oracle_lib):
 
 def test_struct_sizes_match_the_c_layout():
     # sizes the C compiler produces for include/hrcore.h (x86-64 SysV); guards the ctypes mirrors
-    assert ctypes.sizeof(ffi.CtxDesc) == 32
+    assert ctypes.sizeof(ffi.CtxDesc) == 40
     assert ctypes.sizeof(ffi.MeshDesc) == 6 * 8 + 7 * 4 + 4 + 8 + 4 + 4 + 64 + 12 + 4
     assert ctypes.sizeof(ffi.Material) == 4 * 10 + 4 * 15
     assert ctypes.sizeof(ffi.Lights) == 4 + 120 + 4 + 120 + 4 + 180 + 40 + 16

@@ -2,6 +2,7 @@
 seeded inputs.  The bar is BIT-EXACT HDR buffers (the arithmetic contract of DESIGN.md §Arithmetic);
 BASELINE.json's tolerance (1e-4 relative L2) is asserted as well and reported on failure."""
 import os
+import re
 
 import numpy as np
 import pytest
@@ -1137,7 +1138,7 @@ def test_hundred_random_edit_steps_refit_and_rebuild(golden):
     assert refits >= 40 and rebuilds >= 5, (refits, rebuilds)
 
 
-def test_tree_cache_round_trip(tmp_path):
+def test_tree_cache_round_trip(tmp_path, monkeypatch):
     # hr_scene_cache: the tree of a scene is written on the first commit and read back — after a device-side content hash of the
     # meshes matched — by the next context; a changed scene misses; hits never depend on where the tree came from
     sc = scenes.triangle_soup(30000, width=32, height=32, n_materials=4)
@@ -1159,6 +1160,8 @@ def test_tree_cache_round_trip(tmp_path):
     sc.apply(b)
     assert b.scene_info().refitted == 2                                   # read, not built
     assert b.scene_info().n_nodes == a.scene_info().n_nodes
+    ia, ib = a.scene_info(), b.scene_info()                               # the file says which of the two candidate trees it holds, and their costs
+    assert (ib.builder, ib.cost_radix, ib.cost_ploc) == (ia.builder, ia.cost_radix, ia.cost_ploc) and ia.cost_radix > 0
     assert b.debug_trace(org, d).tobytes() == want.tobytes()
     b.set_transform(0, scenes._translate(0.01, 0.0, 0.0))                 # a cached tree refits like a built one
     b.commit()
@@ -1174,6 +1177,20 @@ def test_tree_cache_round_trip(tmp_path):
     o2 = oracle_lib.engine()
     sc2.apply(o2)
     assert c2.debug_trace(org, d).tobytes() == o2.debug_trace(org, d).tobytes()
+    # the builder options are part of the key: a file made by one builder is not served to a context that asks for the other
+    for tune, builder in (("ploc=2", 1), ("ploc=0", 0)):
+        monkeypatch.setenv("HR_TUNE", tune)
+        e1 = core.create_engine()
+        e1.set_scene_cache(path)
+        sc2.apply(e1)
+        assert e1.scene_info().refitted == 0 and e1.scene_info().builder == builder     # (built: the file was the other builder's)
+        e2 = core.create_engine()
+        e2.set_scene_cache(path)
+        sc2.apply(e2)
+        assert e2.scene_info().refitted == 2 and e2.scene_info().builder == builder     # ... and now it is this one's
+        assert e2.debug_trace(org, d).tobytes() == o2.debug_trace(org, d).tobytes()
+        e1.close(), e2.close()
+    monkeypatch.delenv("HR_TUNE")
     path.write_bytes(path.read_bytes()[:1000])                            # a truncated file is ignored
     c3 = core.create_engine()
     c3.set_scene_cache(path)
@@ -1216,7 +1233,7 @@ def test_tree_cache_rejects_damaged_files_and_keys_are_stable(tmp_path):
         t.close()
     fresh(True)                       # same scene, recycled memory: the key still matches
     assert path.read_bytes() == good  # (a hit does not rewrite the file)
-    header = 8 + 4 + 4 + 8 + 6 * 4 + 65 * 4
+    header = 8 + 4 + 4 + 8 + 6 * 4 + 65 * 4 + 2 * 4   # (CacheHeader, version 4: ... levelStart[65], the two candidates' costs)
     header += (-header) % 8           # the 64-bit checksum is 8-byte aligned
     sum_off = header
     payload_off = header + 8
@@ -1365,8 +1382,10 @@ def test_a_slow_caller_does_not_wait_for_a_batch_to_fill(golden):
         assert buf.tobytes() == o.readback().tobytes()
 
 
-def test_step_log_resolved_counter_and_the_kernels_own_clock(golden):
+@pytest.mark.parametrize("tune", ["", "groups=2", "groups=2,batch=1"])
+def test_step_log_resolved_counter_and_the_kernels_own_clock(golden, monkeypatch, tune):
     # hr_get_step_log / hr_frame_passes_resolved / hr_kernel_times.trace_clock_*: the pipeline's own account of itself
+    monkeypatch.setenv("HR_TUNE", tune)
     sc = scenes.triangle_soup(20000, width=320, height=192, bounces=4, passes=64, env=True)
     g = core.create_engine(time_kernels=True)
     sc.apply(g, lut=golden["multiscatter_lut"], tables=host_tables(sc))
@@ -1383,7 +1402,8 @@ def test_step_log_resolved_counter_and_the_kernels_own_clock(golden):
     kt = g.kernel_times()
     assert len(log) == kt["trace"][1] == kt["trace_clock"][1] >= sc.options.max_ray_depth + 2
     starts = [r[0] for r in log]
-    assert starts[0] == 0.0 and (starts == sorted(starts) or "groups=2" in os.environ.get("HR_TUNE", ""))  # (two pipeline groups append in the order their steps END)
+    assert starts[0] == 0.0 and starts == sorted(starts)      # (sorted by the library: with two pipeline groups the records arrive in the order the steps END)
+    assert {r[4] for r in log} <= set(range(3))
     assert sum(r[3] for r in log) == 3 * batch + 1                         # every pass was injected by exactly one step
     assert max(r[2] for r in log) <= 3 * batch + 1 and all(r[1] > 0 for r in log)
     # the launch durations by the device clock agree with the HIP events around the same launches (events include the launch's edges)
@@ -1391,6 +1411,76 @@ def test_step_log_resolved_counter_and_the_kernels_own_clock(golden):
     assert 0.5 * kt["trace"][0] < kt["trace_clock"][0] <= 1.05 * kt["trace"][0] + 0.05
     g.clear()
     assert g.passes_resolved() == 0 and g.step_log() == []
+    g.close()
+
+
+def test_memory_budget_bounds_the_batch_and_the_frame_stays_the_same(golden):
+    # hr_ctx_desc.memory_budget: fewer passes per pipeline step — first as many as fit with every queue at its longest, more once a full
+    # pipeline has shown the real lengths —, same frame; a budget below one pass per step is refused.
+    import torch
+    sc = scenes.triangle_soup(20000, width=640, height=360, bounces=4, passes=96, env=True)
+    free = lambda: torch.cuda.mem_get_info()[0]
+    torch.cuda.init()
+    ref = core.create_engine()
+    sc.apply(ref, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    unlimited = ref.pass_batch(sc.options.max_ray_depth)
+    for s in range(96):
+        ref.render_pass(sc.options.pass_params(s))
+    want = ref.readback().copy()
+    ref.close()
+    budget = 600 << 20
+    f0 = free()
+    g = core.create_engine(memory_budget=budget)
+    sc.apply(g, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    f1 = free()
+    first = g.pass_batch(sc.options.max_ray_depth)
+    assert 1 <= first < unlimited
+    for s in range(96):
+        g.render_pass(sc.options.pass_params(s))
+    got = g.readback().copy()
+    later = g.pass_batch(sc.options.max_ray_depth)
+    held = f1 - free()
+    assert got.tobytes() == want.tobytes()          # (the frame never depends on the batch)
+    assert first <= later <= unlimited              # the real queue lengths allow at least what the guarantee did
+    assert held <= budget * 1.05, (held >> 20, budget >> 20)
+    g.close()
+    tiny = core.create_engine(memory_budget=8 << 20)
+    sc.apply(tiny, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    with pytest.raises(core.EngineError, match="memory_budget"):
+        tiny.render_pass(sc.options.pass_params(0))
+    tiny.close()
+
+
+@pytest.mark.parametrize("ovf,kind", [(1, "camera rays"), (2, "closest-hit queue (input)"), (3, "occlusion queue")])
+@pytest.mark.parametrize("packets", [0, 1])
+def test_a_wrong_queue_bound_is_an_error_not_a_fault(golden, monkeypatch, ovf, kind, packets):
+    # Every append to a ray queue compares its slot with the queue's capacity and every reader clamps the counter it reads
+    # (hr_render.hip: queueOverflow).  HR_TUNE ovf= hands the kernels HALF (an eighth) of what a bound should be — the mistake that
+    # was a memory fault in round 4 —: rays are dropped, the device reports the queue, and the calls that hand work back fail with it.
+    monkeypatch.setenv("HR_TUNE", f"ovf={ovf},packets={packets}")
+    sc = scenes.triangle_soup(20000, width=320, height=192, bounces=4, passes=64, env=True, room=True)
+    g = core.create_engine()
+    sc.apply(g, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    for s in range(24):
+        g.render_pass(sc.options.pass_params(s))
+    with pytest.raises(core.EngineError, match=re.escape("ray queue overflow: " + kind)):
+        g.readback()
+    with pytest.raises(core.EngineError, match="ray queue overflow"):
+        g.synchronize()
+    g.clear()                                   # the frame starts afresh, and so does the report
+    g.synchronize()
+    assert float(np.abs(g.readback()).max()) == 0.0
+    g.render_pass(sc.options.pass_params(0))    # ... and the next pass overflows again (the knob is still set)
+    with pytest.raises(core.EngineError, match="ray queue overflow"):
+        g.readback()
+    g.close()
+    # without the knob the same render reports nothing
+    monkeypatch.setenv("HR_TUNE", f"packets={packets}")
+    g = core.create_engine()
+    sc.apply(g, lut=golden["multiscatter_lut"], tables=host_tables(sc))
+    for s in range(24):
+        g.render_pass(sc.options.pass_params(s))
+    g.readback(), g.synchronize()
     g.close()
 
 
