@@ -170,7 +170,10 @@ def _short_kernel(name):
     return n.split("<")[0]
 
 
-PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES"]),
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+              # VALU wave-instructions by issue class (the SQ block has eight slots per pass): plain f32 add / mul / fma issue at the double rate,
+              # transcendentals at a quarter, everything else (conversions, min / max, compares, integer and bit-field work) at the single rate
+              ("sq", ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_THREAD_CYCLES_VALU"]),
               # busy cycles of the two units that bind k_trace: the texture addresser of a CU, and the VALUs
               ("units", ["TA_TA_BUSY_sum", "GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "TA_FLAT_READ_WAVEFRONTS_sum"]))
 
@@ -682,6 +685,14 @@ def main():
                             "avg_launch_ms_source": "HIP events on the kernel's stream" if time_kernels else "device clock read inside k_trace (no events on the stream)",
                             "avg_launch_ms_device_clock": trace_clock[0] / max(trace_clock[1], 1),
                             "kernel_time_over_wall_time": sum(v[0] for v in kt.values()) / (wall_s * 1e3)}
+                if pmc and not pmc.get("failed") and kt_own.get("FETCH_SIZE") is not None and kt_own.get("WRITE_SIZE") is not None and trace_clock[1]:
+                    # the dominant kernel ALONE, as SURVEY 8(d) words it: k_trace's own counter bytes per launch / its own average launch duration
+                    own_bytes = (kt_own["FETCH_SIZE"] * 1024.0 / max(kt_own.get("launches_FETCH_SIZE", n_trace), 1) + kt_own["WRITE_SIZE"] * 1024.0 / max(kt_own.get("launches_WRITE_SIZE", n_trace), 1))
+                    own_ms = trace_clock[0] / trace_clock[1]
+                    roofline["frac_k_trace"] = own_bytes / (own_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                    roofline["k_trace_alone"] = {"bytes_per_launch": own_bytes, "avg_launch_ms": own_ms, "gbs": own_bytes / (own_ms * 1e-3) / 1e9,
+                                                 "definition": "k_trace's own FETCH_SIZE + WRITE_SIZE (KiB -> bytes) per launch of the counter passes' timed region / the average k_trace launch "
+                                                               "of THIS run's timed region by the kernel's own device clock / 8 TB/s; Infinity-Cache hits included (an upper bound of HBM bytes)"}
                 if per_ray_all:
                     roofline["all_kernels_frac"] = per_ray_all * run_rays / wall_s / 1e9 / HBM_PEAK_GBS
                 if valu_per_ray:
@@ -706,17 +717,34 @@ def main():
                         n_xcd = 8.0   # GRBM_GUI_ACTIVE is reported summed over the XCDs; TA counters over the CUs; SQ_ACTIVE_* in quad-cycles
                         n_cus = float(getattr(torch.cuda.get_device_properties(dev), "multi_processor_count", 256))
                         cyc = ku["GRBM_GUI_ACTIVE"] / n_xcd
+                        # VALU busy: SQ_ACTIVE_INST_VALU charges every VALU wave-instruction one quad-cycle whatever it is (it equals
+                        # SQ_INSTS_VALU to 0.3 %), and x 4 read as "busy cycles" exceeded 1 for the FMA-heavy packet kernel.  The
+                        # instructions are priced by issue class instead, with the costs tools/calib_ops.hip measured on a saturated SIMD
+                        # (cycles per wave64 instruction at the kernel's ~2.3 GHz): f32 add / mul / fma 2.3 (double rate), transcendentals 8,
+                        # everything else 4 — the classes come from the SQ's typed instruction counters of the same counter pass.
+                        def valu_busy_of(kd):
+                            n = kd.get("SQ_INSTS_VALU", 0.0)
+                            fast = kd.get("SQ_INSTS_VALU_ADD_F32", 0.0) + kd.get("SQ_INSTS_VALU_MUL_F32", 0.0) + kd.get("SQ_INSTS_VALU_FMA_F32", 0.0)
+                            trans = kd.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+                            if not n or not kd.get("GRBM_GUI_ACTIVE"):
+                                return None
+                            issue = 2.3 * fast + 8.0 * trans + 4.0 * max(n - fast - trans, 0.0)
+                            return {"busy": issue / (n_cus * 4.0) / (kd["GRBM_GUI_ACTIVE"] / n_xcd), "wave_instructions": n, "double_rate_share": fast / n, "transcendental_share": trans / n,
+                                    "cycles_per_instruction": issue / n,
+                                    "lane_utilisation": (kd["SQ_THREAD_CYCLES_VALU"] / (64.0 * n)) if kd.get("SQ_THREAD_CYCLES_VALU") else None}
+                        vb = {kn: valu_busy_of(kd) for kn, kd in pmc["kernels"].items() if kn in ("k_trace", "k_raygen_packets", "k_shade_hit", "k_shade_sort")}
                         roofline["units"] = {
                             "kernel": "k_trace", "kernel_cycles": cyc,
                             "note": None if not camera_packets[0] else "camera rays travel as packets in k_raygen_packets (per_kernel): VALU-bound, addressers idle — the complement of "
                                     "k_trace, beside which it runs on a second stream in the timed run; the counter passes serialise the two, so each line describes its kernel alone",
                             "per_kernel": {kn: {"cycles": kd["GRBM_GUI_ACTIVE"] / n_xcd, "ta_busy": kd.get("TA_TA_BUSY_sum", 0.0) / n_cus / (kd["GRBM_GUI_ACTIVE"] / n_xcd),
-                                                "valu_busy": kd.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_cus * 4.0) / (kd["GRBM_GUI_ACTIVE"] / n_xcd)}
-                                           for kn, kd in pmc["kernels"].items() if kn in ("k_trace", "k_raygen_packets") and kd.get("GRBM_GUI_ACTIVE")},
+                                                "valu_busy": (vb.get(kn) or {}).get("busy"), "valu": vb.get(kn)}
+                                           for kn, kd in pmc["kernels"].items() if kn in ("k_trace", "k_raygen_packets", "k_shade_hit", "k_shade_sort") and kd.get("GRBM_GUI_ACTIVE")},
                             "ta_busy": ku["TA_TA_BUSY_sum"] / n_cus / cyc,
-                            "valu_busy": ku.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (n_cus * 4.0) / cyc,
+                            "valu_busy": (vb.get("k_trace") or {}).get("busy"),
                             "ta_wave_loads_per_ray": ku.get("TA_FLAT_READ_WAVEFRONTS_sum", 0.0) / pmc["passes"]["units"]["rays"],
-                            "definition": "busy cycles of the CU's texture addresser (TA_TA_BUSY_sum / CUs) and of the VALUs (SQ_ACTIVE_INST_VALU x 4 / SIMDs) "
+                            "definition": "busy cycles of the CU's texture addresser (TA_TA_BUSY_sum / CUs) and of the VALUs (wave-instructions priced by issue class: "
+                                          "2.3 cycles x f32 add/mul/fma + 8 x transcendentals + 4 x the rest, / SIMDs; costs measured by tools/calib_ops.hip) "
                                           "over the cycles k_trace ran (GRBM_GUI_ACTIVE / 8 XCDs), summed over the k_trace launches of the TIMED region of a counter pass "
                                           "that runs this command's own configuration (wake-up, warm-up, same step count: a warm device): "
                                           "the two units that bind the kernel (scattered 16-B-per-lane loads cost one TA cycle per lane and instruction, "

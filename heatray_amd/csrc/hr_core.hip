@@ -197,7 +197,12 @@ struct hr_ctx {
     // injected per step (budgetBatch): first by what a batch needs when every queue is as long as it can get, then — once a full
     // pipeline has shown the real lengths — by what it was seen to need (rayBytesSeen / batchSeen), with a fifth on top.
     unsigned long long memBudget = 0;
-    double rayBytesPerPassSeen = 0.0; // arena + scratch bytes (with their headroom) per pass of a step's batch, largest seen with the pipeline full
+    // ray memory a pass needs at stage s of its life — what a step carves for it in the arena / in scratch —, the largest per-pass average
+    // seen so far (0: that stage has not been seen since the last resize / commit: it counts as long as it can possibly get)
+    double stageArenaSeen[kMaxBounceSlots] = {0}, stageScratchSeen[kMaxBounceSlots] = {0};
+    bool stageSeen[kMaxBounceSlots] = {false};
+    int tuneShadowProbe = 0;  // HR_TUNE="sprobe=1|2" (measurement): walk the occlusion queues of the first bounce (1) / of every stage (2) as packets of 64 consecutive rays and print their union factor when the context goes
+    unsigned long long *dShadowProbe = nullptr;
     int tuneOverflowTest = 0;          // HR_TUNE="ovf=1|2|3": TEST ONLY — halve one bound so that a queue overflows (1: camera rays, 2: a stage's closest-hit bound, 3: occlusion rays)
 
     // Mesh blocks come out of an arena of 64 MB chunks (bump allocation inside a chunk): a hipMalloc per submesh is a device-wide
@@ -538,7 +543,7 @@ static void freeQueues(hr_ctx *c)
     }
     c->nSlotsAllocated = 0;
     c->queueCapacity = 0;
-    c->rayBytesPerPassSeen = 0.0; // (memory budget: back to the guarantee until a full pipeline has been seen again)
+    std::memset(c->stageSeen, 0, sizeof(c->stageSeen)); // (memory budget: back to the guarantee until the stages have been seen again)
 }
 
 // how many passes may be in flight: a slot holds a pass buffer (four partial sums once HR_ESTIMATOR_ALL_LIGHTS has been used); the rays
@@ -622,7 +627,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs), get("ovf=", c->tuneOverflowTest);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs), get("ovf=", c->tuneOverflowTest), get("sprobe=", c->tuneShadowProbe);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -690,6 +695,14 @@ int hr_ctx_destroy(hr_ctx *c)
                 c->dbgGrowths, (double)c->dbgGrowBytes / 1048576.0, c->dbgWaits, c->dbgWaitSpun, (double)c->dbgWaitNs * 1e-6);
     drainPipeline(c);
     hipStreamSynchronize(c->stream);
+    if (c->dShadowProbe) {
+        unsigned long long t[4] = {0, 0, 0, 0};
+        hipDeviceSynchronize();
+        hipMemcpy(t, c->dShadowProbe, sizeof(t), hipMemcpyDeviceToHost);
+        fprintf(stderr, "shadow probe (%s): %llu occlusion rays in %llu packets of 64 consecutive queue entries: union factor U = %.3f, %.1f child boxes entered per ray\n",
+                c->tuneShadowProbe == 2 ? "every stage" : "first bounce", t[3], t[2], t[1] ? (double)t[0] / (double)t[1] : 0.0, t[3] ? (double)t[1] / (double)t[3] : 0.0);
+        hipFree(c->dShadowProbe);
+    }
     if (c->probeStream) hipStreamSynchronize(c->probeStream), hipStreamDestroy(c->probeStream);
     if (c->evProbeA) hipEventDestroy(c->evProbeA);
     if (c->evProbeB) hipEventDestroy(c->evProbeB);
@@ -1436,7 +1449,7 @@ int hr_scene_commit(hr_ctx *c)
     HIP_TRY(c, hipEventSynchronize(cs.e1));
     hipEventElapsedTime(&c->info.build_ms, cs.e0, cs.e1);
     c->committed = true;
-    c->rayBytesPerPassSeen = 0.0; // (memory budget: another scene, other queue lengths)
+    std::memset(c->stageSeen, 0, sizeof(c->stageSeen)); // (memory budget: another scene, other queue lengths)
     c->probeCountdown = 0; // (packet selector: another tree)
     c->sceneDirty = true;
     c->texDensityStale = true;
@@ -2161,14 +2174,27 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             needArena += rayQueueBytes(boundIn[k]) + shadowQueueBytes((size_t)boundIn[k] * kS);
         }
     }
-    if (c->memBudget && n > 0) {
-        // what a pass of the batch costs in ray memory, seen with this group's pipeline full (as many generations in flight as a pass has
-        // stages): the regions' sizes this step asks for, with the headroom ensureRegion adds, over the passes per generation
-        const int S = stagesOf(c, c->slots[order[0]].pp);
-        if (n >= S && c->slots[order[0]].step >= S - 2) {
-            const double perPass = (4.0 / 3.0) * (2.0 * (double)(needArena > G.arenaHighWater ? needArena : G.arenaHighWater) + (double)needScratch) / ((double)n / (double)S);
-            if (perPass > c->rayBytesPerPassSeen) c->rayBytesPerPassSeen = perPass;
+    if (c->memBudget) { // what this step carves per pass and stage (budgetBytesPerPass)
+        double sumA[kMaxBounceSlots] = {0}, sumS[kMaxBounceSlots] = {0};
+        int cnt[kMaxBounceSlots] = {0};
+        for (int k = 0; k < n; ++k) {
+            const hr_ctx::PassSlot &ps = c->slots[order[k]];
+            const int st = ps.step < kMaxBounceSlots ? ps.step : kMaxBounceSlots - 1;
+            const bool closest = c->hasPassthrough || ps.step < ps.nIter;
+            cnt[st]++;
+            if (ps.step == 0) sumS[st] += (double)rayQueueBytes(P);
+            if (closest) {
+                sumS[st] += (double)(align256((size_t)boundIn[k] * hitRecordSize()) + align256((size_t)boundIn[k] * 4));
+                sumA[st] += (double)(rayQueueBytes(boundIn[k]) + shadowQueueBytes((size_t)boundIn[k] * kS));
+            }
         }
+        for (int st = 0; st < kMaxBounceSlots; ++st)
+            if (cnt[st]) {
+                const double a = sumA[st] / cnt[st], sc = sumS[st] / cnt[st];
+                c->stageArenaSeen[st] = (c->stageSeen[st] && c->stageArenaSeen[st] > a) ? c->stageArenaSeen[st] : a;
+                c->stageScratchSeen[st] = (c->stageSeen[st] && c->stageScratchSeen[st] > sc) ? c->stageScratchSeen[st] : sc;
+                c->stageSeen[st] = true;
+            }
     }
     hr_ctx::Group::Region &arena = G.arena[stepIdx & 1ull];
     {
@@ -2319,6 +2345,19 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         else
             launchRaygen(cfg, c->dScene, dTbl, segs, fr, c->dStats);
     }
+    if (c->tuneShadowProbe) { // measurement only: the coherence of the occlusion rays this step's k_trace is about to trace
+        if (!c->dShadowProbe) {
+            HIP_TRY(c, hipMalloc(&c->dShadowProbe, 64));
+            HIP_TRY(c, hipMemsetAsync(c->dShadowProbe, 0, 64, G.stream));
+        }
+        SegList sl{};
+        uint32_t most = 0;
+        for (int k = 0; k < n; ++k) {
+            const hr_ctx::PassSlot &ps = c->slots[order[k]];
+            if (ps.step >= 1 && (c->tuneShadowProbe == 2 || ps.step == 1) && sl.n < kMaxBatch) sl.seg[sl.n++] = k, most = tbl.seg[k].sInCap > most ? tbl.seg[k].sInCap : most;
+        }
+        launchShadowProbe(G.stream, c->dScene, c->nodes, c->tris, dTbl, sl, most, c->dShadowProbe);
+    }
     if (forked) HIP_TRY(c, hipEventRecord(G.evJoin, G.streamB));
     if (timing)
         c->timeNext(HR_KERNEL_TRACE, G.stream);
@@ -2435,17 +2474,20 @@ static bool packetsInUse(const hr_ctx *c) { return c->tunePackets == 1 || (c->tu
 
 // hr_ctx_desc::memory_budget: how many passes per step fit.  A pass of the batch holds, over the `stages` steps of its life, a pass buffer
 // (S + 2 of them per batch pass are kept: the pipeline's depth and the resolve lag), its camera rays and hit records (scratch), and
-// what each of its closest-hit stages emits (arena: two halves, each with a third of headroom).  Before a full pipeline has been
-// seen, every queue counts as long as it can possibly get (one ray per owned pixel at every stage: the guarantee); afterwards the
-// largest per-pass figure seen, plus a fifth.
+// what each of its closest-hit stages emits (arena: two halves, each with a third of headroom).  A stage that has not been seen yet
+// counts as long as it can possibly get (one ray per owned pixel: the guarantee); a stage that has, by the largest per-pass average a
+// step carved for it, plus a tenth.  All stages of a batch are in flight at once (one generation per stage), so the sum over the
+// stages is what one more pass per step costs.
 static double budgetBytesPerPass(const hr_ctx *c, int stages)
 {
     const double P = (double)(c->queueCapacity ? c->queueCapacity : 1u), kS = c->allLightsUsed ? 4.0 : 1.0;
     const double fb = (double)c->W * c->H * 16.0 * (c->allLightsUsed ? 4.0 : 1.0);
-    const double closestStages = (double)(stages - 1);
-    const double worstRays = (4.0 / 3.0) * (P * 64.0 + closestStages * P * 20.0) + 2.0 * (4.0 / 3.0) * closestStages * P * (64.0 + 48.0 * kS);
-    const double rays = c->rayBytesPerPassSeen > 0.0 ? 1.2 * c->rayBytesPerPassSeen : worstRays;
-    return (double)c->nGroups * ((double)(stages + 2) * fb + rays);
+    double arena = 0.0, scratch = 0.0;
+    for (int st = 0; st + 1 < stages && st < kMaxBounceSlots; ++st) { // (the last stage traces occlusion rays only)
+        arena += c->stageSeen[st] ? 1.1 * c->stageArenaSeen[st] : P * (64.0 + 48.0 * kS);
+        scratch += c->stageSeen[st] ? 1.1 * c->stageScratchSeen[st] : P * 20.0 + (st == 0 ? P * 64.0 : 0.0);
+    }
+    return (double)c->nGroups * ((double)(stages + 2) * fb + (4.0 / 3.0) * (2.0 * arena + scratch));
 }
 static int budgetBatch(const hr_ctx *c, int stages)
 {
@@ -2482,6 +2524,11 @@ static int drainPipeline(hr_ctx *c)
             const int share = ((int)c->pendingInject.size() + idleGroups - 1) / (idleGroups > 0 ? idleGroups : 1);
             n = share < 1 ? 1 : share;
         }
+        // With the camera rays as packets a step injects WHOLE launches of kMaxBatch passes where it can: a remainder goes in one step later,
+        // where its (smaller, less coherent) packets run beside the k_trace that carries the first launches' first bounce instead of
+        // lengthening the step that has nothing beside it.  A 1/8 shard's 20 passes as 16, then 4: 0.304 -> 0.294 ms/step; as 12 + 8,
+        // 10 + 10, 8 + 8 + 4 (each of them smaller packets all round): 0.307 - 0.323 (profiles/r5g_burst_pmin.txt).
+        if (packetsInUse(c) && n > kMaxBatch && n % kMaxBatch) n -= n % kMaxBatch;
         int perGroup = batch * stages;
         int rc = injectBatch(c, n, perGroup);
         if (rc) return rc;

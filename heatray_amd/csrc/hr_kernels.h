@@ -142,6 +142,8 @@ void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *n
                          const FrameDev &fr, Stats *stats, bool uniformParams); // segs.n: a power of two; uniformParams: the passes differ in sample_index only
 int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, int passesLog2, const FrameDev &fr,
                       unsigned long long *probe);
+void launchShadowProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const StepTable *tbl, const SegList &segs, uint32_t maxRays,
+                       unsigned long long *probe); // measurement only (HR_TUNE sprobe=)
 void launchShade(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, Stats *stats);
 void launchDebugTrace(const LaunchCfg &cfg, const SceneDev *S, int n, const float *o, const float *d, const float *tmax, const int *skip,
                       int anyHit, hr_hit *out);

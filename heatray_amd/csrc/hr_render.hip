@@ -89,7 +89,7 @@ enum OverflowKind : uint32_t { OVF_CAMERA = 1, OVF_CLOSEST_IN = 2, OVF_OCCLUSION
 __device__ __attribute__((noinline)) void queueOverflow(const StepTable *tbl, uint32_t kind, uint32_t seg, uint32_t count)
 {
     uint32_t *h = tbl->hostOverflow;
-    if (!h) return;
+    if (!h || __hip_atomic_load(&h[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return; // (the FIRST report stays: what follows from it — a clamped reader downstream — would only hide it)
     __hip_atomic_store(&h[1], (uint32_t)tbl->seqValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&h[2], seg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&h[3], count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1104,6 +1104,34 @@ __global__ __launch_bounds__(kPacketBlock) void k_packet_probe(const SceneDev *_
         __threadfence();
         atomicAdd(&probe[2], 1ull);
     }
+}
+
+// MEASUREMENT ONLY (HR_TUNE sprobe=1|2; VERDICT r4 item 6: "packets beyond the camera"): how coherent are the OCCLUSION rays of a queue, taken 64
+// consecutive entries at a time as they lie there?  Same four totals as k_packet_probe, for the occlusion queues of the table entries listed
+// (closest-hit semantics up to each ray's own tmax: an any-hit packet could end earlier, so the packet's share is an upper bound).
+__global__ __launch_bounds__(kPacketBlock) void k_shadow_probe(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodesG, const Tri *__restrict__ trisG,
+                                                              const StepTable *__restrict__ tbl, SegList segs, unsigned long long *probe)
+{
+    const SceneDev &S = *Sp;
+    const SegDev &sg = tbl->seg[segs.seg[blockIdx.y]];
+    const uint32_t n = occlusionCount(sg), i = blockIdx.x * 64u + threadIdx.x;
+    if (blockIdx.x * 64u >= n) return;
+    const bool active = i < n;
+    float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 1, 0);
+    if (active) a = G(sg.sqIn.A)[i], b = G(sg.sqIn.B)[i];
+    HitRec best;
+    uint32_t nv = 0, nt = 0, entered = 0, own = 0;
+    packetTraverse<false, true>(S, (ConstNodes)(uintptr_t)nodesG, (ConstTris)(uintptr_t)trisG, v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), active ? a.w : 0.0f,
+                                active ? __float_as_uint(b.w) : 0xFFFFFFFFu, best, nv, nt, entered, own);
+    const uint32_t nRays = (uint32_t)__popcll(__ballot(active));
+    own = waveSum(active ? own : 0u);
+    if (laneId() == 0 && nRays)
+        atomicAdd(&probe[0], (unsigned long long)entered * nRays), atomicAdd(&probe[1], (unsigned long long)own), atomicAdd(&probe[2], 1ull), atomicAdd(&probe[3], (unsigned long long)nRays);
+}
+void launchShadowProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const StepTable *tbl, const SegList &segs, uint32_t maxRays, unsigned long long *probe)
+{
+    if (segs.n <= 0 || maxRays == 0) return;
+    hipLaunchKernelGGL(k_shadow_probe, dim3((maxRays + 63u) / 64u, segs.n), dim3(kPacketBlock), 0, stream, S, nodes, tris, tbl, segs, probe);
 }
 
 // ------------------------------------------------------------------------------------------- shade

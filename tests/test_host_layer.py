@@ -107,6 +107,39 @@ def test_reference_viewer_compiles_unchanged_against_the_layer(tmp_path):
     assert out.returncode == 0, out.stderr[-4000:]
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout (build container only)")
+def test_reference_viewer_links_against_the_layer(tmp_path):
+    # One step past "compiles": the viewer's OBJECT file, built from the reference's own HeatrayRenderer.cpp in the overlay tree, names
+    # (as undefined symbols) every function of PassGenerator / Scene / Lighting / materials / lights it calls; each of them must be
+    # DEFINED by the layer built against the same glm the viewer uses (make GLM=/root/reference/3rdParty) — same manglings, same
+    # argument types.  (VERDICT r4 did this by hand: 22 symbols.)  What remains undefined outside those classes is the application's
+    # own (imgui, GL, glfw, the loaders): outside the boundary.
+    ov = _overlay_tree(tmp_path)
+    stubs = os.path.join(ROOT, "tests", "host", "viewer_stubs")
+    amp = ov / "HeatrayRenderer" / "Scene" / "AssimpMeshProvider.h"
+    amp.unlink()
+    os.symlink(os.path.join(stubs, "AssimpMeshProvider.h"), amp)
+    obj = tmp_path / "HeatrayRenderer.o"
+    cmd = ["g++", "-std=c++20", "-O0", "-c", "-DGLEW_NO_GLU", "-I" + str(ov), "-I" + str(ov / "HeatrayRenderer"), "-I" + stubs,
+           "-I" + os.path.join(ROOT, "include"), "-I/root/reference/3rdParty", str(ov / "HeatrayRenderer" / "HeatrayRenderer.cpp"), "-o", str(obj)]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=ov)
+    assert out.returncode == 0, out.stderr[-4000:]
+    lib = tmp_path / "libheatrayhost_glm.so"
+    out = subprocess.run(["make", "-C", HOST, "GLM=/root/reference/3rdParty", "OUT=" + str(lib)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-4000:]
+    und = subprocess.run(["nm", "-u", "-C", str(obj)], capture_output=True, text=True, check=True).stdout
+    defined = subprocess.run(["nm", "-D", "--defined-only", "-C", str(lib)], capture_output=True, text=True, check=True).stdout
+    have = {l.split(None, 2)[2].strip() for l in defined.splitlines() if len(l.split(None, 2)) == 3}
+    import re
+    ours = re.compile(r"^(PassGenerator|Scene|Mesh|Lighting|Material|PhysicallyBasedMaterial|GlassMaterial|Light|DirectionalLight|PointLight|SpotLight|EnvironmentLight|"
+                      r"openrl::\w+)::")
+    wanted = [l.split(None, 1)[1].strip() for l in und.splitlines() if len(l.split(None, 1)) == 2]
+    wanted = [w for w in wanted if ours.match(w) or any(w.startswith(p) for p in ("vtable for ", "typeinfo for ")) and ours.match(w.split(" for ", 1)[1] + "::")]
+    assert len(wanted) >= 15, wanted                      # (the viewer really does call into the layer: 22 symbols when this was written)
+    missing = [w for w in wanted if w not in have]
+    assert not missing, missing
+
+
 def test_polygon_aperture_is_uniform_on_the_polygon():
     import numpy as np
     from heatray_amd import host

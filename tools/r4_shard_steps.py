@@ -18,4 +18,4 @@ e.flush(); e.synchronize()
 el = time.perf_counter() - t0
 print("20 passes: %.3f ms (%.4f ms/step)" % (el * 1e3, el * 1e3 / 20))
 print("kernel ms", {k: (round(v[0], 3), v[1]) if isinstance(v, tuple) and len(v) == 2 else v for k, v in e.kernel_times().items()})
-for r in e.step_log(): print("  step start %.3f ms  k_trace %.3f ms  in flight %d injected %d" % r)
+for r in e.step_log(): print("  step start %.3f ms  k_trace %.3f ms  in flight %d injected %d" % r[:4])
