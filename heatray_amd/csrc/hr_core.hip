@@ -129,6 +129,7 @@ struct hr_ctx {
         hipStream_t stream = nullptr;
         StepTable *dTables = nullptr;   // ring of device step tables
         StepTable *hTables = nullptr;   // pinned staging ring
+        StepTable *dTablesHost = nullptr; // ... as the device addresses it
         hipEvent_t tableCopied[4] = {nullptr, nullptr, nullptr, nullptr};
         bool tableUsed[4] = {false, false, false, false};
         unsigned long long stepCounter = 0;
@@ -201,6 +202,7 @@ struct hr_ctx {
     // seen so far (0: that stage has not been seen since the last resize / commit: it counts as long as it can possibly get)
     double stageArenaSeen[kMaxBounceSlots] = {0}, stageScratchSeen[kMaxBounceSlots] = {0};
     bool stageSeen[kMaxBounceSlots] = {false};
+    int tuneTableKernel = 1;  // HR_TUNE="tblk=0": the step table goes to the device by hipMemcpyAsync instead of a fetch kernel reading its pinned entry (0.2-0.7 % slower: profiles/r5k_table_fetch.txt)
     int tuneShadowProbe = 0;  // HR_TUNE="sprobe=1|2" (measurement): walk the occlusion queues of the first bounce (1) / of every stage (2) as packets of 64 consecutive rays and print their union factor when the context goes
     unsigned long long *dShadowProbe = nullptr;
     int tuneOverflowTest = 0;          // HR_TUNE="ovf=1|2|3": TEST ONLY — halve one bound so that a queue overflows (1: camera rays, 2: a stage's closest-hit bound, 3: occlusion rays)
@@ -627,7 +629,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs), get("ovf=", c->tuneOverflowTest), get("sprobe=", c->tuneShadowProbe);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs), get("ovf=", c->tuneOverflowTest), get("sprobe=", c->tuneShadowProbe), get("tblk=", c->tuneTableKernel);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;
@@ -651,7 +653,8 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
                        hipEventCreateWithFlags(&G.evFork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&G.evJoin, hipEventDisableTiming) == hipSuccess;
         }
         groupsOk = groupsOk && hipMalloc(&G.dTables, sizeof(StepTable) * kTableRing) == hipSuccess;
-        groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess;
+        groupsOk = groupsOk && hipHostMalloc((void **)&G.hTables, sizeof(StepTable) * kTableRing, hipHostMallocDefault) == hipSuccess &&
+                   hipHostGetDevicePointer((void **)&G.dTablesHost, G.hTables, 0) == hipSuccess;
         groupsOk = groupsOk && hipEventCreateWithFlags(&G.evUser, hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.tableCopied[k], hipEventDisableTiming) == hipSuccess;
         for (int k = 0; k < kTableRing; ++k) groupsOk = groupsOk && hipEventCreateWithFlags(&G.statusEv[k], hipEventDisableTiming) == hipSuccess;
@@ -2025,6 +2028,10 @@ static int packetLog2(const hr_ctx *c);
 static bool packetsInUse(const hr_ctx *c);
 static int macroStep(hr_ctx *c, int g, int nInject)
 {
+    static const bool dbgT = getenv("HR_DEBUG_STEPTIMES") != nullptr;
+    auto nowUs = [] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3; };
+    const double tA = dbgT ? nowUs() : 0.0;
+    double tB = 0, tC = 0, tD = 0, tE = 0;
     hr_ctx::Group &G = c->groups[g];
     const LaunchCfg cfg = c->cfg(G.stream);
     FrameDev fr = c->frame;
@@ -2108,6 +2115,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             for (int k = 0; k < nEndedEarly; ++k) endedEarly[k]->finalEv = owner->evFinal;
         }
     }
+    if (dbgT) tB = nowUs();
     // table of the group's in-flight passes, oldest first
     int order[kMaxSlots], n = 0;
     for (int i = 0; i < kMaxSlots; ++i)
@@ -2164,6 +2172,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             boundIn[k] = b;
         }
     }
+    if (dbgT) tC = nowUs();
     size_t needArena = 0, needScratch = 0;
     for (int k = 0; k < n; ++k) {
         const hr_ctx::PassSlot &ps = c->slots[order[k]];
@@ -2301,7 +2310,12 @@ static int macroStep(hr_ctx *c, int g, int nInject)
     tbl.hostOverflow = c->dOverflowHost;
     StepTable *dTbl = G.dTables + ring;
     const size_t tblBytes = offsetof(StepTable, seg) + (size_t)n * sizeof(SegDev);
-    HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, tblBytes, hipMemcpyHostToDevice, G.stream));
+    if (dbgT) tD = nowUs();
+    if (c->tuneTableKernel)
+        launchFetchTable(G.stream, G.dTablesHost + ring, dTbl, (tblBytes + 15) & ~(size_t)15);
+    else
+        HIP_TRY(c, hipMemcpyAsync(dTbl, &tbl, tblBytes, hipMemcpyHostToDevice, G.stream));
+    if (dbgT) tE = nowUs();
     HIP_TRY(c, hipEventRecord(G.tableCopied[ring], G.stream));
     G.tableUsed[ring] = true;
     if (c->pending.size() > 8192) c->drainTimes();
@@ -2418,6 +2432,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             G.statusOrder[ring][i] = (c->slots[i].active && c->slots[i].group == g) ? c->slots[i].order + 1ull : 0ull;
     }
     HIP_TRY(c, hipGetLastError());
+    if (dbgT) fprintf(stderr, "step %llu (inject %d): begin %.1f us | injected +%.1f | counts known +%.1f | table built +%.1f | copy enqueued +%.1f | launched +%.1f\n", stepIdx, nInject, tA, tB - tA, tC - tB, tD - tC, tE - tD, nowUs() - tE);
     return resolveReady(c);
 }
 

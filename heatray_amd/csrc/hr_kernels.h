@@ -133,6 +133,7 @@ struct CounterList {
     Counters *ctr[kMaxBatch];
 };
 void launchZeroCounters(const LaunchCfg &cfg, const CounterList &list);
+void launchFetchTable(hipStream_t stream, const void *hostMapped, void *dst, size_t bytes);
 void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl, const SegList &segs, const FrameDev &fr, Stats *stats);
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &bufs);
 void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *frame, float *packed, int unpack, float *full);

@@ -213,6 +213,17 @@ __global__ __launch_bounds__(256) void k_zero_counters(CounterList list)
     uint32_t *w = reinterpret_cast<uint32_t *>(list.ctr[blockIdx.x]);
     for (uint32_t i = threadIdx.x; i < sizeof(Counters) / 4; i += 256) w[i] = 0u;
 }
+// The step table comes to the device by a kernel that reads its pinned host entry (hr_core.hip: Group::hTables), 16 bytes per thread
+__global__ __launch_bounds__(256) void k_fetch_table(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+void launchFetchTable(hipStream_t stream, const void *hostMapped, void *dst, size_t bytes)
+{
+    const uint32_t n16 = (uint32_t)((bytes + 15) / 16);
+    hipLaunchKernelGGL(k_fetch_table, dim3((n16 + 255u) / 256u), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(hostMapped), reinterpret_cast<uint4 *>(dst), n16);
+}
 void launchZeroCounters(const LaunchCfg &cfg, const CounterList &list)
 {
     if (list.n > 0) hipLaunchKernelGGL(k_zero_counters, dim3(list.n), dim3(256), 0, cfg.stream, list);

@@ -404,7 +404,9 @@ typedef struct hr_pass_stats {
  * packet per wave (one node fetch and one stack for 64 rays; ray generation and this traversal are then one kernel, timed under
  * HR_KERNEL_RAYGEN — where rays walk far it runs BESIDE k_trace on a second stream, and that bucket holds only the time it outlasts
  * k_trace); the probe runs beside the pipeline after a commit, a resize, a change of camera and every 64th batch.
- * The hits — and so the image — are the same bits either way. */
+ * The hits — and so the image — are the same bits either way, by construction: whether a ray hits a triangle is decided by the
+ * triangle test alone (Moeller-Trumbore plus "the hit point lies in the triangle's half-padded box"), never by which
+ * triangles a traversal happens to test; HR_TUNE packets=0|1 pins the mode all the same. */
 #define HR_KERNEL_RAYGEN 0  /* ray generation; with camera_packets, the camera rays' traversal too */
 #define HR_KERNEL_TRACE 1   /* closest-hit + occlusion traversal (one kernel) */
 #define HR_KERNEL_SHADE 2
