@@ -12,6 +12,7 @@
 //              so no reliance on cross-XCD visibility)
 //   emit     : subtrees of <= 4 triangles collapse into leaves; 64-byte two-box nodes
 #include "hr_kernels.h"
+#include <cstring>
 #include "hr_texture.h"
 
 #include <vector>
@@ -652,6 +653,103 @@ __global__ __launch_bounds__(256) void k_refit4(Node4 *__restrict__ nodes, Box6 
     blockAreaAdd(area, consts); // tree-quality heuristic: sum of node areas
 }
 
+// ---- the 32-byte nodes of k_trace (hr_types.h: Node32)
+// biased exponent of the grid's cell along an axis of extent `ext`: the power of two with 256 cells > ext (so every frame origin is one of
+// 256 grid points: a byte), kept inside the normal range with room for the scale exponents on both sides
+HRD uint32_t gridCellExponent(float ext)
+{
+    const uint32_t e = (__float_as_uint(ext) >> 23) & 0xFFu; // ext < 2^(e - 126)
+    const uint32_t c = e > 7u ? e - 7u : 0u;                  // 2^(c - 127) * 256 = 2^(e - 126) > ext
+    return c < 24u ? 24u : (c > 230u ? 230u : c);
+}
+void gridOf(const SceneConsts &k, float gridLo[3], float gridCell[3], uint32_t gridCellExp[3])
+{
+    for (int a = 0; a < 3; ++a) {
+        // (node boxes reach one leaf padding beyond the scene's bounds: the grid starts two paddings below them)
+        gridLo[a] = k.lo[a] - 2.0f * k.pad;
+        uint32_t bits;
+        const float ext = (k.hi[a] + 2.0f * k.pad) - gridLo[a];
+        std::memcpy(&bits, &ext, 4);
+        const uint32_t e = (bits >> 23) & 0xFFu, c0 = e > 7u ? e - 7u : 0u, c = c0 < 24u ? 24u : (c0 > 230u ? 230u : c0);
+        gridCellExp[a] = c;
+        const uint32_t cb = c << 23;
+        std::memcpy(&gridCell[a], &cb, 4);
+    }
+}
+__global__ __launch_bounds__(256) void k_encode32(const Node4 *__restrict__ nodes, const Box6 *__restrict__ nodeBox, const Tri *__restrict__ tris, uint32_t nNodes,
+                                                  const SceneConsts *__restrict__ consts, Node32 *__restrict__ out, int *__restrict__ leafKeys, SceneDev *__restrict__ scene)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float gLo[3], cell[3], invCell[3];
+    uint32_t cexp[3];
+    for (int k = 0; k < 3; ++k) {
+        gLo[k] = consts->lo[k] - 2.0f * consts->pad; // (as gridOf on the host: same operations)
+        cexp[k] = gridCellExponent((consts->hi[k] + 2.0f * consts->pad) - gLo[k]);
+        cell[k] = __uint_as_float(cexp[k] << 23), invCell[k] = __uint_as_float((254u - cexp[k]) << 23);
+    }
+    if (i == 0 && scene)
+        for (int k = 0; k < 3; ++k) scene->gridLo[k] = gLo[k], scene->gridCell[k] = cell[k], scene->gridCellExp[k] = cexp[k];
+    if (i >= nNodes) return;
+    const float pad = consts->pad;
+    const Node4 nd = nodes[i];
+    const uint32_t meta = __float_as_uint(nd.a.w);
+    const int nInner = (int)((meta >> 24) & 7u), nValid = (int)(meta >> 27);
+    const uint32_t innerBase = nd.c.z;
+    const int leafKey = (int)nd.c.w;
+    Box6 cb[4];
+    Box6 nb;
+    for (int k = 0; k < 3; ++k) nb.lo[k] = __builtin_inff(), nb.hi[k] = -__builtin_inff();
+    for (int c = 0; c < nValid; ++c) {
+        if (c < nInner) {
+            cb[c] = nodeBox[innerBase + (uint32_t)c];
+        } else {
+            v3 bl, bh;
+            triBounds(tris[~(leafKey + c)], bl, bh);
+            cb[c].lo[0] = bl.x - pad, cb[c].lo[1] = bl.y - pad, cb[c].lo[2] = bl.z - pad;
+            cb[c].hi[0] = bh.x + pad, cb[c].hi[1] = bh.y + pad, cb[c].hi[2] = bh.z + pad;
+        }
+        for (int k = 0; k < 3; ++k) nb.lo[k] = fmin_(nb.lo[k], cb[c].lo[k]), nb.hi[k] = fmax_(nb.hi[k], cb[c].hi[k]);
+    }
+    // frame: the grid point at or below the node's lower corner (the same float expression k_trace evaluates) and, per axis, the smallest
+    // power-of-two number of cells from there that holds the node: hi <= origin + 255 * scale with scale = cell * 2^(e - 8)
+    uint32_t g[3], e[3];
+    float origin[3];
+    for (int k = 0; k < 3; ++k) {
+        const float f = floor_((nb.lo[k] - gLo[k]) * invCell[k]);
+        g[k] = (uint32_t)fmin_(fmax_(f, 0.0f), 255.0f);
+        origin[k] = __builtin_fmaf((float)g[k], cell[k], gLo[k]);
+        if (origin[k] > nb.lo[k] && g[k] > 0u) g[k] -= 1u, origin[k] = __builtin_fmaf((float)g[k], cell[k], gLo[k]); // (the rounding of the sum)
+        e[k] = 0u;
+        while (e[k] < 15u && nb.hi[k] - origin[k] > 255.0f * __uint_as_float((cexp[k] + e[k] - 8u) << 23)) ++e[k];
+    }
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        const float inv = __uint_as_float((254u - (cexp[k] + e[k] - 8u)) << 23); // 1 / scale
+        for (int c = 0; c < 4; ++c) {
+            uint32_t lo8 = 255u, hi8 = 0u; // no child: inverted planes, never entered
+            if (c < nValid) {
+                const float fl = floor_((cb[c].lo[k] - origin[k]) * inv);
+                const float fh = __builtin_ceilf((cb[c].hi[k] - origin[k]) * inv);
+                lo8 = (uint32_t)fmin_(fmax_(fl, 0.0f), 255.0f);
+                hi8 = (uint32_t)fmin_(fmax_(fh, 0.0f), 255.0f);
+            }
+            qlo[k] |= lo8 << (8 * c);
+            qhi[k] |= hi8 << (8 * c);
+        }
+    }
+    Node32 o;
+    o.p = make_uint4(qlo[0], qlo[1], qlo[2], qhi[0]);
+    o.q = make_uint4(qhi[1], qhi[2], (innerBase & 0x01FFFFFFu) | ((uint32_t)nInner << 25) | (e[0] << 28), g[0] | (g[1] << 8) | (g[2] << 16) | (e[1] << 24) | (e[2] << 28));
+    out[i] = o;
+    leafKeys[i] = leafKey; // (the one word of Node4 k_trace still needs: a compact array that stays in L2)
+}
+void encodeNodes32(hipStream_t st, const BuildResult &tree, const SceneConsts *consts, SceneDev *scene)
+{
+    const uint32_t n = tree.nNodes > 0 ? (uint32_t)tree.nNodes : 0u;
+    if (!tree.nodes32 && n) return;
+    hipLaunchKernelGGL(k_encode32, dim3(n ? (n + 255) / 256 : 1), dim3(256), 0, st, tree.nodes, tree.nodeBox, tree.tris, n, consts, tree.nodes32, tree.leafKeys, scene);
+}
+
 void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts)
 {
     (void)nTris;
@@ -993,7 +1091,7 @@ static int buildPLOC(hipStream_t st, const Box6 *leafBox, uint32_t n, int radius
 int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3], const float hi[3], float pad, const SceneConsts *dConsts,
               BuildResult *out, const BuildOptions &opt)
 {
-    out->nodes = nullptr, out->tris = nullptr, out->nodeBox = nullptr, out->slotOfPrim = nullptr;
+    out->nodes = nullptr, out->nodes32 = nullptr, out->leafKeys = nullptr, out->tris = nullptr, out->nodeBox = nullptr, out->slotOfPrim = nullptr;
     out->nNodes = 0, out->rootLeafCount = 0, out->levels = 0, out->triSlots = 0;
     out->builder = 0, out->costRadix = out->costPloc = 0.0f;
     for (uint32_t &v : out->levelStart) v = 0;
@@ -1111,6 +1209,8 @@ int buildLBVH(hipStream_t st, const Tri *trisPrim, uint32_t n, const float lo[3]
         HR_CHECK(hipMalloc(&finalTris, sizeof(Tri) * (size_t)n));
         int *binOf = nullptr;
         HR_CHECK(hipMalloc(&out->nodes, sizeof(Node4) * (size_t)nMax));
+        HR_CHECK(hipMalloc(&out->nodes32, sizeof(Node32) * (size_t)nMax));
+        HR_CHECK(hipMalloc(&out->leafKeys, sizeof(int) * (size_t)nMax));
         HR_CHECK(hipMalloc(&out->nodeBox, sizeof(Box6) * (size_t)nMax));
         HR_CHECK(hipMalloc(&binOf, 4ull * nMax));
         uint32_t levelStart = 0, levelEnd = 1;

@@ -565,7 +565,7 @@ static void slotBudget(hr_ctx *c)
 
 static void freeTree(hr_ctx *c)
 {
-    hipFree(c->tree.nodes), hipFree(c->tree.tris), hipFree(c->tree.nodeBox), hipFree(c->tree.slotOfPrim);
+    hipFree(c->tree.nodes), hipFree(c->tree.nodes32), hipFree(c->tree.leafKeys), hipFree(c->tree.tris), hipFree(c->tree.nodeBox), hipFree(c->tree.slotOfPrim);
     c->tree = BuildResult{};
     c->nodes = nullptr, c->tris = nullptr, c->treeTris = 0;
 }
@@ -1266,7 +1266,7 @@ static bool loadTree(hr_ctx *c, unsigned long long key, uint32_t nTris, BuildRes
         ok = ok && payloadChecksum(buf.data(), buf.size()) == h.payloadSum;
         ok = ok && cachedTreeIsSane(h, buf.data(), reinterpret_cast<const uint32_t *>(buf.data() + nb + bb));
         if (ok) {
-            ok = hipMalloc(&br.nodes, nb) == hipSuccess && hipMalloc(&br.nodeBox, bb) == hipSuccess && hipMalloc(&br.slotOfPrim, sb) == hipSuccess &&
+            ok = hipMalloc(&br.nodes, nb) == hipSuccess && hipMalloc(&br.nodes32, (size_t)h.nNodes * sizeof(Node32)) == hipSuccess && hipMalloc(&br.leafKeys, (size_t)h.nNodes * sizeof(int)) == hipSuccess && hipMalloc(&br.nodeBox, bb) == hipSuccess && hipMalloc(&br.slotOfPrim, sb) == hipSuccess &&
                  hipMalloc(&br.tris, sizeof(Tri) * (size_t)h.triSlots) == hipSuccess;
             ok = ok && hipMemcpy(br.nodes, buf.data(), nb, hipMemcpyHostToDevice) == hipSuccess &&
                  hipMemcpy(br.nodeBox, buf.data() + nb, bb, hipMemcpyHostToDevice) == hipSuccess &&
@@ -1276,7 +1276,7 @@ static bool loadTree(hr_ctx *c, unsigned long long key, uint32_t nTris, BuildRes
     }
     fclose(f);
     if (!ok) {
-        hipFree(br.nodes), hipFree(br.nodeBox), hipFree(br.slotOfPrim), hipFree(br.tris);
+        hipFree(br.nodes), hipFree(br.nodes32), hipFree(br.leafKeys), hipFree(br.nodeBox), hipFree(br.slotOfPrim), hipFree(br.tris);
         return false;
     }
     br.nNodes = (int32_t)h.nNodes, br.levels = (int32_t)h.levels, br.rootLeafCount = (int32_t)h.rootLeafCount, br.triSlots = h.triSlots;
@@ -1322,7 +1322,7 @@ struct CommitScratch {
     {
         if (e0) hipEventDestroy(e0);
         if (e1) hipEventDestroy(e1);
-        if (!keepBuild) hipFree(br.nodes), hipFree(br.tris), hipFree(br.nodeBox), hipFree(br.slotOfPrim);
+        if (!keepBuild) hipFree(br.nodes), hipFree(br.nodes32), hipFree(br.leafKeys), hipFree(br.tris), hipFree(br.nodeBox), hipFree(br.slotOfPrim);
     }
 };
 } // namespace
@@ -1364,7 +1364,7 @@ int hr_scene_commit(hr_ctx *c)
         gd.push_back(d);
     }
     std::memset(&c->info, 0, sizeof(c->info));
-    c->hScene.nodes = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
+    c->hScene.nodes = nullptr, c->hScene.nodes32 = nullptr, c->hScene.leafKeys = nullptr, c->hScene.tris = nullptr, c->hScene.attrs = nullptr, c->hScene.attrsExt = nullptr;
     c->hScene.nTris = 0, c->hScene.nNodes = 0, c->hScene.rootLeafCount = 0, c->hScene.rayEps = 0.0f, c->hScene.hitPad = 0.0f;
     if (nTris == 0) {
         freeTree(c);
@@ -1383,6 +1383,7 @@ int hr_scene_commit(hr_ctx *c)
             launchAssemble(c->stream, c->dG, (int)gd.size(), nTris, c->tree.tris, c->tree.slotOfPrim, c->attrs, ext, c->dScratch);
             launchSceneConsts(c->stream, c->dScratch, c->dConsts, nullptr);
             refitLBVH(c->stream, c->tree, nTris, c->dConsts);
+            encodeNodes32(c->stream, c->tree, c->dConsts, nullptr); // (k_trace's copy of the nodes: every frame is re-encoded, the grid moves with the bounds)
             launchTriAreaSum(c->stream, c->tree.tris, c->tree.triSlots, c->dConsts);
             HIP_TRY(c, hipMemcpyAsync(c->hConsts, c->dConsts, sizeof(SceneConsts), hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1422,10 +1423,11 @@ int hr_scene_commit(hr_ctx *c)
                 if (brc != 0) FAIL(c, HR_ERR_DEVICE, brc == 3 ? "LBVH refit did not reach the root" : "LBVH build failed");
                 if (!c->cachePath.empty()) saveTree(c, key, nTris, cs.br);
             }
+            encodeNodes32(c->stream, cs.br, c->dConsts, nullptr); // (built or read from the cache: k_trace's 32-byte copy of the nodes)
             // the traversal stack holds at most 3 entries per level of inner nodes (hr_trace.h)
             if (3 * cs.br.levels > kStackLDS + kStackOvf) FAIL(c, HR_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
             if (cs.br.triSlots >= (1u << 28)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: triangle slots do not fit a 28-bit leaf reference");
-            if ((unsigned long long)cs.br.nNodes >= (1ull << 26)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: k_trace addresses nodes by a 32-bit byte offset (2^26 nodes of 64 bytes)");
+            if ((unsigned long long)cs.br.nNodes >= (1ull << 25)) FAIL(c, HR_ERR_UNSUPPORTED, "scene too large: a 32-byte node holds its children's base index in 25 bits (2^25 nodes, ~95 M triangles)");
             freeTree(c);
             c->tree = cs.br, cs.keepBuild = true;
             c->treeTris = nTris;
@@ -1437,7 +1439,8 @@ int hr_scene_commit(hr_ctx *c)
         }
         const SceneConsts &k = *c->hConsts;
         c->nodes = c->tree.nodes, c->tris = c->tree.tris;
-        c->hScene.nodes = c->nodes, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = ext;
+        c->hScene.nodes = c->nodes, c->hScene.nodes32 = c->tree.nodes32, c->hScene.leafKeys = c->tree.leafKeys, c->hScene.tris = c->tris, c->hScene.attrs = c->attrs, c->hScene.attrsExt = ext;
+        gridOf(k, c->hScene.gridLo, c->hScene.gridCell, c->hScene.gridCellExp);
         c->hScene.nTris = (int)nTris, c->hScene.nNodes = c->tree.nNodes, c->hScene.rootLeafCount = c->tree.rootLeafCount;
         c->hScene.rayEps = k.eps; // 1e-4 |diagonal|, SURVEY §8a a6
         c->hScene.hitPad = 0.5f * k.pad; // (hr_trace.h: hitInTriBox)
@@ -2400,7 +2403,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
             if (c->tuneCorunBlocks > 0) blocks = c->tuneCorunBlocks;
             if (blocks < ct.traceBlocksPerCU) ct.traceBlocksPerCU = blocks;
         }
-        launchTrace(ct, c->dScene, c->nodes, c->tris, dTbl, c->dStats);
+        launchTrace(ct, c->dScene, c->tree.leafKeys, c->tree.nodes32, c->tris, dTbl, c->dStats);
     }
     if (forked) { // (the bucket HR_KERNEL_TRACE stays k_trace's own launch; what the packet kernel beside it runs longer is booked as ray generation)
         c->timeNext(HR_KERNEL_RAYGEN, G.stream);

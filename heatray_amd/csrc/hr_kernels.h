@@ -138,7 +138,7 @@ void launchRaygen(const LaunchCfg &cfg, const SceneDev *S, const StepTable *tbl,
 void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &bufs);
 void launchPackOwned(const LaunchCfg &cfg, const FrameDev &fr, const float *frame, float *packed, int unpack, float *full);
 void launchDisplay(const LaunchCfg &cfg, const FrameDev &fr, const hr_display_params &P, int format, void *out);
-void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats);
+void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const int *leafKeys, const Node32 *nodes32, const Tri *tris, StepTable *tbl, Stats *stats);
 void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, const StepTable *tbl, const SegList &segs,
                          const FrameDev &fr, Stats *stats, bool uniformParams); // segs.n: a power of two; uniformParams: the passes differ in sample_index only
 int launchPacketProbe(hipStream_t stream, const SceneDev *S, const Node4 *nodes, const Tri *tris, const hr_pass_params &pp, int passesLog2, const FrameDev &fr,
@@ -184,6 +184,8 @@ struct SceneConsts {
 static const int kMaxLevels = 64;
 struct BuildResult {
     Node4 *nodes;
+    Node32 *nodes32;      // the same nodes in 32 bytes (k_trace), made by encodeNodes32 after every build / refit
+    int *leafKeys;        // Node4::c.w of every node, compact (k_trace finds a leaf child's triangle through it)
     Tri *tris;            // leaf order
     Box6 *nodeBox;        // float box of every node (a refit passes child boxes upwards through it)
     uint32_t *slotOfPrim; // prim id -> position in `tris`
@@ -211,6 +213,10 @@ int buildLBVH(hipStream_t st, const Tri *trisPrimOrder, uint32_t nTris, const fl
 // Refit: the tree keeps its topology; every node's child boxes are recomputed bottom-up from the triangles in `tree.tris`
 // (already moved by launchAssemble) and re-quantised.  Level by level, no host synchronisation.
 void refitLBVH(hipStream_t st, const BuildResult &tree, uint32_t nTris, SceneConsts *consts);
+// Node32 of every node from its Node4 (children, counts), the node boxes and the triangles; also writes the grid into *scene (device) when given.
+// The grid is a function of the scene bounds in *consts: gridOf() gives the host the same numbers.
+void encodeNodes32(hipStream_t st, const BuildResult &tree, const SceneConsts *consts, SceneDev *scene);
+void gridOf(const SceneConsts &k, float gridLo[3], float gridCell[3], uint32_t gridCellExp[3]);
 // order-independent 64-bit digest of a device buffer, added to *out (device)
 void launchMipChain(hipStream_t st, const TexDesc &t, int nLevels, float *mips);
 void launchTexLodScale(hipStream_t st, TexDesc *table, int n);

@@ -142,9 +142,10 @@ HRD bool ownedPixel(const FrameDev &fr, uint32_t gid, int &x, int &y)
 // pushes nothing, then a hit record, then the miss shader in k_shade_sort — a queue slot (64 B), a record and three kernels' worth
 // of loads for a ray whose fate is already known (with the benchmark's camera — SURVEY 8d: distance 3 x the scene's radius, 50 mm lens
 // — that is three camera rays in four).  Its defaultPrimitive's shader runs right here (the sample was just set to zero: same single
-// addition as later), and it still counts as a closest-hit ray: it WAS traced, by the test below.  EXACTLY the traversal's own
-// decision: rootMissed() is the slab test of nodeStep4 on the root's frame box (planes q = 0 and 255), every child plane lies inside
-// it and fma is monotone in q, so a ray it rejects is rejected by all four children of the root.
+// addition as later), and it still counts as a closest-hit ray: it WAS traced, by the test below.  A decision no traversal can
+// contradict: rootMissed() is the slab test on the frame box of the root's 64-byte node (planes q = 0 and 255), which contains the padded
+// box of every triangle of the scene; a ray that misses it can hit nothing (a hit point lies inside its triangle's half-padded box, hr_trace.h),
+// whichever copy of the tree — the packet kernel's 64-byte nodes, k_trace's 32-byte ones — it would have walked.
 struct CameraLane {
     Ray r;
     uint32_t pixel;
@@ -376,9 +377,16 @@ __device__ __attribute__((noinline)) void reportQueueLengths(const StepTable *tb
     if (threadIdx.x == 0) __hip_atomic_store(tbl->hostSeq, tbl->seqValue, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// the slab test's per-ray constants for the 32-byte nodes k_trace walks (the grid is folded into them: hr_trace.h)
+HRD RayK traceFrame(const SceneDev &S, v3 o, v3 d)
+{
+    const float idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
+    return rayFrame32(S, o, idx, idy, idz);
+}
+
 template <bool STATS>
-__global__ __launch_bounds__(kTraceBlock, 5) void k_trace(const SceneDev *__restrict__ Sp, const Node4 *__restrict__ nodes, const Tri *__restrict__ tris,
-                                                  StepTable *__restrict__ tbl, Stats *stats)
+__global__ __launch_bounds__(kTraceBlock, 5) void k_trace(const SceneDev *__restrict__ Sp, const int *__restrict__ leafKeys, const Node32 *__restrict__ nodes32,
+                                                  const Tri *__restrict__ tris, StepTable *__restrict__ tbl, Stats *stats)
 {
     __shared__ int stack[kTraceWaves][kStackLDS][64];
     __shared__ uint32_t segStart[2 * kMaxSegs + 1];
@@ -534,10 +542,9 @@ __global__ __launch_bounds__(kTraceBlock, 5) void k_trace(const SceneDev *__rest
                     }
                     o = v3(a.x, a.y, a.z), d = v3(b.x, b.y, b.z);
                     tmax = a.w, tlim = a.w;
-                    idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
                     {
-                        const RayK f = rayFrame(o, idx, idy, idz);
-                        oix = f.oix, oiy = f.oiy, oiz = f.oiz;
+                        const RayK f = traceFrame(S, o, d);
+                        idx = f.idx, idy = f.idy, idz = f.idz, oix = f.oix, oiy = f.oiy, oiz = f.oiz;
                     }
                     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
                     sp = 0;
@@ -604,10 +611,9 @@ __global__ __launch_bounds__(kTraceBlock, 5) void k_trace(const SceneDev *__rest
                     item = sItem, segIdx = sSeg, local = sLocal, slot = sSlot, skipPrim = sSkip;
                     o = v3(sox, soy, soz), d = v3(sdx, sdy, sdz);
                     tmax = sTmax, tlim = sTlim;
-                    idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
                     {
-                        const RayK f = rayFrame(o, idx, idy, idz);
-                        oix = f.oix, oiy = f.oiy, oiz = f.oiz;
+                        const RayK f = traceFrame(S, o, d);
+                        idx = f.idx, idy = f.idy, idz = f.idz, oix = f.oix, oiy = f.oiy, oiz = f.oiz;
                     }
                     best.prim = kMissPrim, best.t = tmax, best.u = 0.0f, best.v = 0.0f;
                     sp = 0, pend = 0, cur = given;
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(kTraceBlock, 5) void k_trace(const SceneDev *__rest
                 ++mySteps;
 #endif
                 const RayK rk{idx, idy, idz, oix, oiy, oiz};
-                nodeStep4(nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
+                nodeStep32(nodes32, cur, sp, stackLane, ovf, rk, tmin, tlim); // (two loads per visit: hr_trace.h)
             }
             // a lane that reached a leaf postpones it and keeps descending (speculative traversal); with a leaf already
             // postponed it is blocked until the wave runs the triangle phase
@@ -670,7 +676,12 @@ __global__ __launch_bounds__(kTraceBlock, 5) void k_trace(const SceneDev *__rest
 #endif
             if (pend != 0) {
                 const int enc = ~pend;
-                const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
+                // a leaf child of node `enc >> 2` in slot 3 - (enc & 3) (hr_trace.h: nodeStep32): its triangle's index is ~(leafKeys[node] + slot),
+                // Node4::c.w of that node in a compact array that stays in L2 (a root leaf — a scene of at most four triangles, no nodes at
+                // all — keeps the (first, count) form).  Read HERE, in front of the triangle's loads: reading it where the leaf is put aside
+                // (six more load sites in the unrolled node steps) measured 2-5 % slower (profiles/r5_node32_ab.txt)
+                int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
+                if (rootRef >= 0) first = ~(leafKeys[enc >> 2] + (3 - (enc & 3))), count = 1;
                 pend = 0;
                 for (int k = 0; k < count; ++k) {
                     const Tri &tr = tris[first + k];
@@ -1479,13 +1490,13 @@ void launchResolve(const LaunchCfg &cfg, const FrameDev &fr, const PassBufList &
     hipLaunchKernelGGL(k_resolve, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, cfg.stream, fr, bufs);
 }
 
-void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, StepTable *tbl, Stats *stats)
+void launchTrace(const LaunchCfg &cfg, const SceneDev *S, const int *leafKeys, const Node32 *nodes32, const Tri *tris, StepTable *tbl, Stats *stats)
 {
     const int grid = cfg.numCUs * cfg.traceBlocksPerCU * (kBlock / kTraceBlock); // traceBlocksPerCU counts 256-thread workgroups
     if (cfg.collectStats)
-        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
+        hipLaunchKernelGGL(k_trace<true>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, leafKeys, nodes32, tris, tbl, stats);
     else
-        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, nodes, tris, tbl, stats);
+        hipLaunchKernelGGL(k_trace<false>, dim3(grid), dim3(kTraceBlock), 0, cfg.stream, S, leafKeys, nodes32, tris, tbl, stats);
 }
 
 void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *nodes, const Tri *tris, const StepTable *tbl, const SegList &segs,

@@ -71,27 +71,37 @@ HRD void cswap(uint32_t &a, uint32_t &b)
     a = lo, b = hi;
 }
 
-// One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that
-// is hit and push the others farthest first (so the nearer one pops first); pop when nothing is hit.
-HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim)
+// One step at the 4-wide node `cur`: slab-test the four quantised child boxes, continue with the nearest child that is hit and push the
+// others farthest first (so the nearer one pops first); pop when nothing is hit.  On the 32-byte node (hr_types.h: Node32): TWO loads per
+// visit.  The frame's origin is a point of the scene's 256^3 grid, gridLo + g * cell, and the scale cell * 2^(e - 8) with an exponent per
+// axis; the grid is folded into the ray's constants once per ray (rayFrame32: cell / d and (o - gridLo) / d), so that a visit decodes
+//   t = q * (2^(e - 8) * cell/d) + (g * cell/d - (o - gridLo)/d)
+// with 24 v_cvt_f32_ubyteN + 24 FMAs for the planes (as on the 64-byte node the packet kernel reads), three more conversions for the grid
+// bytes and a few integer instructions for the packed exponents.  A leaf child's reference is ~(4 * node + 3 - slot): the triangle's index
+// is ~(leafKeys[node] + slot), read when the leaf is tested.
+HRD RayK rayFrame32(const SceneDev &S, v3 o, float idx, float idy, float idz)
 {
-    // (a 32-bit byte offset from the wave-uniform base: one shift, and the load takes base + offset itself; node indices are < 2^26)
-    const Node4 &n = *reinterpret_cast<const Node4 *>(reinterpret_cast<const char *>(nodes) + (size_t)((uint32_t)cur << 6));
-    const float4 a = n.a;
-    const uint4 qb = n.b, qc = n.c;
-    const uint32_t meta = __float_as_uint(a.w);
-    const uint32_t nInner = (meta >> 24) & 7u, nValid = meta >> 27;
-    const int innerBase = (int)qc.z, leafKey = (int)qc.w;
-    // t = (origin + q * scale - o) / d = q * (scale / d) + (origin / d - o / d)
-    const float bx = __uint_as_float((meta & 0xFFu) << 23) * rk.idx;
-    const float by = __uint_as_float(((meta >> 8) & 0xFFu) << 23) * rk.idy;
-    const float bz = __uint_as_float(((meta >> 16) & 0xFFu) << 23) * rk.idz;
-    const float ax = __builtin_fmaf(a.x, rk.idx, -rk.oix), ay = __builtin_fmaf(a.y, rk.idy, -rk.oiy), az = __builtin_fmaf(a.z, rk.idz, -rk.oiz);
+    return RayK{S.gridCell[0] * idx, S.gridCell[1] * idy, S.gridCell[2] * idz, (o.x - S.gridLo[0]) * idx, (o.y - S.gridLo[1]) * idy, (o.z - S.gridLo[2]) * idz};
+}
+HRD void nodeStep32(const Node32 *__restrict__ nodes, int &cur, int &sp, int *stackLane, int *ovf, const RayK &rk, float tmin, float tlim)
+{
+    // (a 32-bit byte offset from the wave-uniform base: one shift, and the load takes base + offset itself; node indices are < 2^25)
+    const Node32 &n = *reinterpret_cast<const Node32 *>(reinterpret_cast<const char *>(nodes) + (size_t)((uint32_t)cur << 5));
+    const uint4 qp = n.p, qq = n.q;
+    const uint32_t w6 = qq.z, w7 = qq.w;
+    const uint32_t nInner = (w6 >> 25) & 7u;
+    const int innerBase = (int)(w6 & 0x01FFFFFFu), leafKey = ~(int)(((uint32_t)cur << 2) | 3u);
+    // 2^(e - 8) per axis: the biased exponent e + 119 goes straight into the float's exponent field
+    const float bx = rk.idx * __uint_as_float(((w6 >> 28) << 23) + (119u << 23));
+    const float by = rk.idy * __uint_as_float((((w7 >> 24) & 15u) << 23) + (119u << 23));
+    const float bz = rk.idz * __uint_as_float(((w7 >> 28) << 23) + (119u << 23));
+    const float ax = __builtin_fmaf((float)byteOf(w7, 0), rk.idx, -rk.oix), ay = __builtin_fmaf((float)byteOf(w7, 1), rk.idy, -rk.oiy),
+                az = __builtin_fmaf((float)byteOf(w7, 2), rk.idz, -rk.oiz);
     // the sign of the direction decides which quantised plane is the entry and which the exit plane of each slab
     // (chosen once per node on whole dwords: byte j belongs to child j)
-    const uint32_t nX = rk.idx < 0.0f ? qb.w : qb.x, fX = rk.idx < 0.0f ? qb.x : qb.w;
-    const uint32_t nY = rk.idy < 0.0f ? qc.x : qb.y, fY = rk.idy < 0.0f ? qb.y : qc.x;
-    const uint32_t nZ = rk.idz < 0.0f ? qc.y : qb.z, fZ = rk.idz < 0.0f ? qb.z : qc.y;
+    const uint32_t nX = rk.idx < 0.0f ? qp.w : qp.x, fX = rk.idx < 0.0f ? qp.x : qp.w;
+    const uint32_t nY = rk.idy < 0.0f ? qq.x : qp.y, fY = rk.idy < 0.0f ? qp.y : qq.x;
+    const uint32_t nZ = rk.idz < 0.0f ? qq.y : qp.z, fZ = rk.idz < 0.0f ? qp.z : qq.y;
     uint32_t key[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -101,7 +111,7 @@ HRD void nodeStep4(const Node4 *__restrict__ nodes, int &cur, int &sp, int *stac
         const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));
         const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tlim));
         // entry distance (>= tmin >= 0, so its bits order like the value) with the child slot in the two low bits
-        key[c] = (tn <= tf && (uint32_t)c < nValid) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+        key[c] = (tn <= tf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu; // (a slot without a child has inverted planes)
     }
     // sorting network: ascending entry distance, misses (0xFFFFFFFF) last
     cswap(key[0], key[1]), cswap(key[2], key[3]), cswap(key[0], key[2]), cswap(key[1], key[3]), cswap(key[1], key[2]);
@@ -233,17 +243,19 @@ HRD void traverse(const SceneDev &S, v3 o, v3 d, float tmin, float tmax, uint32_
         cur = 0;
     const float idx = safeInv(d.x), idy = safeInv(d.y), idz = safeInv(d.z);
     float tlim = tmax; // shrinks to the closest hit so far (closest-hit rays only)
-    const RayK rk = rayFrame(o, idx, idy, idz);
+    const RayK rk = rayFrame32(S, o, idx, idy, idz);
+    const bool rootLeaf = S.rootLeafCount > 0;
     while (cur != kSentinel) {
         // ---- inner nodes: descend until this lane holds a leaf (cur < 0) or runs out of work
         while (cur >= 0 && cur != kSentinel) {
             if (STATS) ++nodeVisits;
-            nodeStep4(S.nodes, cur, sp, stackLane, ovf, rk, tmin, tlim);
+            nodeStep32(S.nodes32, cur, sp, stackLane, ovf, rk, tmin, tlim);
         }
-        // ---- leaf: 1..4 triangles
+        // ---- leaf: one triangle (a root leaf: 1..4), found through the node's leaf key (k_trace does the same)
         if (cur < 0) {
             const int enc = ~cur;
-            const int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
+            int first = enc & 0x0FFFFFFF, count = (enc >> 28) + 1;
+            if (!rootLeaf) first = ~(S.leafKeys[enc >> 2] + (3 - (enc & 3))), count = 1;
             bool done = false;
             for (int k = 0; k < count; ++k) {
                 const Tri &tr = S.tris[first + k];

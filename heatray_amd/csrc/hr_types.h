@@ -25,6 +25,20 @@ struct alignas(64) Node4 {
 };
 
 
+// The same 4-wide node in 32 bytes = TWO dwordx4 loads, for k_trace (the texture addresser — one lane per cycle per load instruction
+// whatever its width — is what binds that kernel on long walks; the packet kernel reads Node4 through the scalar cache and keeps it):
+//   p = (qlo.x[4], qlo.y[4], qlo.z[4], qhi.x[4])   q = (qhi.y[4], qhi.z[4], w6, w7)      byte j of a plane dword belongs to child j
+//   w6 = innerBase | nInner << 25 | ex << 28            w7 = gx | gy << 8 | gz << 16 | ey << 24 | ez << 28
+// The frame is origin + q * scale with origin_k = gridLo_k + g_k * cell_k on a scene-wide 256^3 grid of power-of-two cells
+// (SceneDev::grid*) and scale_k = cell_k * 2^(e_k - 8), an exponent per axis (flat nodes of a mesh keep tight planes across their thin
+// side): 8-bit planes as in Node4 (the cheap v_cvt_f32_ubyteN decode, which also unpacks the grid bytes), a frame of 2^e_k cells
+// per axis.  A slot without a child holds the inverted planes lo = 255, hi = 0 and can never be entered (no child count needed).
+// Children and their order are Node4's; a leaf child's triangle is found through Node4::c.w of the same node when the leaf is tested
+// (its reference on the stack is ~(4 * node + 3 - slot)).  innerBase has 25 bits: 33 M nodes, ~95 M triangles (checked at commit).
+struct alignas(32) Node32 {
+    uint4 p, q;
+};
+
 // World-space triangle in BVH leaf order, 48 bytes = three dwordx4 loads:
 //   p = (v0.x v0.y v0.z e1.x)  q = (e1.y e1.z e2.x e2.y)  r = (e2.z, prim id, flags, -)
 struct alignas(16) Tri {
@@ -82,6 +96,8 @@ static const int kEnvRowGuide = 256, kEnvColGuide = 64; // buckets of the guide 
 // ---- per-scene constant block (device copy) ---------------------------------------------------
 struct SceneDev {
     const Node4 *nodes;
+    const Node32 *nodes32; // the same tree for k_trace (hr_build.hip: encodeNodes32)
+    const int *leafKeys;   // Node4::c.w of every node, compact: the way from a Node32 leaf child to its triangle
     const Tri *tris;
     const TriAttr *attrs;
     const TriAttrExt *attrsExt; // may be null
@@ -89,6 +105,8 @@ struct SceneDev {
     const TexDesc *textures;
     int32_t nTris, nNodes, rootLeafCount, nMaterials, nTextures;
     float rayEps;
+    float gridLo[3], gridCell[3]; // frame grid of the 32-byte nodes: origin = gridLo + g * gridCell (power-of-two cells, 256 per axis cover the scene)
+    uint32_t gridCellExp[3];      // biased exponent of gridCell
     float hitPad; // half the leaf padding: a hit point lies inside its triangle's bounding box grown by this much (hr_trace.h: hitInTriBox)
     hr_lights lights;
     // sample tables
