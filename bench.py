@@ -226,6 +226,18 @@ def pmc_legs(args, keep_dir=None):
         start = min(gens) if gens else first
         res["passes"][name] = {"rays": cj["extra"]["rays"], "steps": cj["steps"], "warmup": cj["warmup"], "counters": ctrs, "k_trace_launches_counted": n_trace,
                                "dispatches_in_process": len({r_[0] for r_ in rows}), "dispatches_counted": len({r_[0] for r_ in rows if r_[0] >= start})}
+        # the same dispatches' durations by the profiler's timestamps (kernel trace of the same pass): what the counters of this pass are
+        # normalised with where a busy FRACTION is wanted (cycle counters of another pass would bring that pass's clock with them)
+        for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    try:
+                        did = int(row["Dispatch_Id"])
+                    except (KeyError, ValueError):
+                        continue
+                    if did >= start:
+                        kk = res["kernels"].setdefault(_short_kernel(row["Kernel_Name"]), {})
+                        kk["duration_ns_" + name] = kk.get("duration_ns_" + name, 0.0) + float(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
         for disp_id, k, ctr, val in rows:
             if disp_id < start:
                 continue
@@ -719,20 +731,33 @@ def main():
                         cyc = ku["GRBM_GUI_ACTIVE"] / n_xcd
                         # VALU busy: SQ_ACTIVE_INST_VALU charges every VALU wave-instruction one quad-cycle whatever it is (it equals
                         # SQ_INSTS_VALU to 0.3 %), and x 4 read as "busy cycles" exceeded 1 for the FMA-heavy packet kernel.  The
-                        # instructions are priced by issue class instead, with the costs tools/calib_ops.hip measured on a saturated SIMD
-                        # (cycles per wave64 instruction at the kernel's ~2.3 GHz): f32 add / mul / fma 2.3 (double rate), transcendentals 8,
-                        # everything else 4 — the classes come from the SQ's typed instruction counters of the same counter pass.
-                        def valu_busy_of(kd):
+                        # instructions are priced by issue class instead — the SQ's typed instruction counters of the same counter pass give
+                        # the classes — with the LOWEST cost tools/calib_ops.hip measured for a class on a saturated SIMD (ns per wave64
+                        # instruction: f32 add / mul / fma 0.94, transcendentals 3.41, everything else 1.71; profiles/r4u_calib_ops.json), over
+                        # the SIMD-time the kernel had in THAT pass (its dispatches' durations by the profiler's timestamps x 4 SIMDs x CUs):
+                        # a lower bound of the issue time the instructions need, so the fraction cannot exceed 1.
+                        # (the typed counters know f32 add / mul / fma and transcendentals; of the REST — conversions, min / max, compares, integer
+                        # and bit work — a kernel-specific share still issues at the double rate (v_mov, v_and, v_add_u32, v_cndmask_e32): taken from
+                        # the kernel's own ISA, tools/valu_mix.py -> profiles/r5_valu_mix.json; 0 when that file is missing: the rest at the single rate)
+                        try:
+                            mix = json.load(open(os.path.join(ROOT, "profiles", "r5_valu_mix.json")))["kernels"]
+                        except (OSError, ValueError, KeyError):
+                            mix = {}
+
+                        def valu_busy_of(kd, kn=""):
                             n = kd.get("SQ_INSTS_VALU", 0.0)
                             fast = kd.get("SQ_INSTS_VALU_ADD_F32", 0.0) + kd.get("SQ_INSTS_VALU_MUL_F32", 0.0) + kd.get("SQ_INSTS_VALU_FMA_F32", 0.0)
                             trans = kd.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-                            if not n or not kd.get("GRBM_GUI_ACTIVE"):
+                            dur = kd.get("duration_ns_sq", 0.0)
+                            if not n or not dur:
                                 return None
-                            issue = 2.3 * fast + 8.0 * trans + 4.0 * max(n - fast - trans, 0.0)
-                            return {"busy": issue / (n_cus * 4.0) / (kd["GRBM_GUI_ACTIVE"] / n_xcd), "wave_instructions": n, "double_rate_share": fast / n, "transcendental_share": trans / n,
-                                    "cycles_per_instruction": issue / n,
+                            share = float(mix.get(kn, {}).get("double_rate_share_of_rest", 0.0))
+                            issue_ns = 0.9375 * fast + 3.4082 * trans + (0.9375 * share + 1.7121 * (1.0 - share)) * max(n - fast - trans, 0.0)
+                            return {"busy": issue_ns / (n_cus * 4.0) / dur, "wave_instructions": n, "double_rate_share": fast / n, "transcendental_share": trans / n,
+                                    "double_rate_share_of_rest_static": share,
+                                    "ns_per_instruction": issue_ns / n, "kernel_ms_in_the_counter_pass": dur * 1e-6,
                                     "lane_utilisation": (kd["SQ_THREAD_CYCLES_VALU"] / (64.0 * n)) if kd.get("SQ_THREAD_CYCLES_VALU") else None}
-                        vb = {kn: valu_busy_of(kd) for kn, kd in pmc["kernels"].items() if kn in ("k_trace", "k_raygen_packets", "k_shade_hit", "k_shade_sort")}
+                        vb = {kn: valu_busy_of(kd, kn) for kn, kd in pmc["kernels"].items() if kn in ("k_trace", "k_raygen_packets", "k_shade_hit", "k_shade_sort")}
                         roofline["units"] = {
                             "kernel": "k_trace", "kernel_cycles": cyc,
                             "note": None if not camera_packets[0] else "camera rays travel as packets in k_raygen_packets (per_kernel): VALU-bound, addressers idle — the complement of "
@@ -743,8 +768,10 @@ def main():
                             "ta_busy": ku["TA_TA_BUSY_sum"] / n_cus / cyc,
                             "valu_busy": (vb.get("k_trace") or {}).get("busy"),
                             "ta_wave_loads_per_ray": ku.get("TA_FLAT_READ_WAVEFRONTS_sum", 0.0) / pmc["passes"]["units"]["rays"],
-                            "definition": "busy cycles of the CU's texture addresser (TA_TA_BUSY_sum / CUs) and of the VALUs (wave-instructions priced by issue class: "
-                                          "2.3 cycles x f32 add/mul/fma + 8 x transcendentals + 4 x the rest, / SIMDs; costs measured by tools/calib_ops.hip) "
+                            "definition": "ta_busy: busy cycles of the CU's texture addresser (TA_TA_BUSY_sum / CUs) over the cycles the kernel ran; "
+                                          "valu_busy: VALU wave-instructions priced by issue class (0.94 ns x f32 add/mul/fma + 3.41 x transcendentals + 1.71 x the rest, of which the "
+                                          "kernel's static share of double-rate integer / move instructions at 0.94: costs from tools/calib_ops.hip, classes from the SQ's typed "
+                                          "counters and tools/valu_mix.py) over the kernel's SIMD-time in the same counter pass; cycles: "
                                           "over the cycles k_trace ran (GRBM_GUI_ACTIVE / 8 XCDs), summed over the k_trace launches of the TIMED region of a counter pass "
                                           "that runs this command's own configuration (wake-up, warm-up, same step count: a warm device): "
                                           "the two units that bind the kernel (scattered 16-B-per-lane loads cost one TA cycle per lane and instruction, "

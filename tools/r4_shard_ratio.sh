@@ -4,7 +4,7 @@ K=${1:-20}
 best() { # args of bench.py
   local b=999
   for i in 1 2 3; do
-    v=$(python bench.py --quick --steps $K --warmup 5 "$@" 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+    v=$(python bench.py --quick --parity-seconds 0 --steps $K --warmup 5 "$@" 2>/dev/null | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
     b=$(python -c "print(min($b, $v))")
   done
   echo $b

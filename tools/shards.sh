@@ -3,7 +3,7 @@
 # (emulation: no collective); prints ms/step per rank and the max, which bounds the N = W job.
 W="$1"; STEPS="$2"; TUNE="$3"
 for r in $(seq 0 $((W-1))); do
-  HR_TUNE="$TUNE" python bench.py --quick --steps $STEPS --shard-of $W --shard-rank $r > gpurun_out/sh.json 2> gpurun_out/sh.err || { echo "rank $r failed"; tail -3 gpurun_out/sh.err; exit 1; }
+  HR_TUNE="$TUNE" python bench.py --quick --parity-seconds 0 --warmup 5 --steps $STEPS --shard-of $W --shard-rank $r > gpurun_out/sh.json 2> gpurun_out/sh.err || { echo "rank $r failed"; tail -3 gpurun_out/sh.err; exit 1; }
   python - $r <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/sh.json"))

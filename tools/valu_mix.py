@@ -58,14 +58,20 @@ def main():
         if start is None:
             continue
         counts = {"fast": 0, "slow": 0, "trans": 0}
+        fast_f32 = 0  # of the fast ones: f32 add / sub / mul / fma — what the SQ's typed counters (SQ_INSTS_VALU_{ADD,MUL,FMA}_F32) see as a class of their own
         for l in text[start + 1:]:
             if "s_endpgm" in l:
                 break
             c = classify(l)
             if c:
                 counts[c] += 1
+                if c == "fast" and re.match(r"\s+v_(fma|fmac|mul|add|sub|subrev|mac|madak|madmk|fmaak|fmamk)_f32", l):
+                    fast_f32 += 1
         n = sum(counts.values())
-        res["kernels"][name] = {**counts, "valu_instructions": n, "cycles_per_instruction": sum(COST[k] * v for k, v in counts.items()) / max(n, 1)}
+        rest = n - fast_f32 - counts["trans"]
+        res["kernels"][name] = {**counts, "fast_f32": fast_f32, "valu_instructions": n, "cycles_per_instruction": sum(COST[k] * v for k, v in counts.items()) / max(n, 1),
+                                # of the instructions the typed counters leave in the "rest" class, the share that still issues at the double rate (v_mov, v_and, v_add_u32 ...)
+                                "double_rate_share_of_rest": (counts["fast"] - fast_f32) / max(rest, 1)}
     json.dump(res, open(out_path, "w"), indent=1)
     for k, v in res["kernels"].items():
         print(f"{k:18s} {v['valu_instructions']:6d} VALU instructions: fast {v['fast']}, slow {v['slow']}, trans {v['trans']} -> {v['cycles_per_instruction']:.2f} cycles each")
