@@ -1329,11 +1329,11 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
         const uint32_t i = base + threadIdx.x;
         const bool live = i < total;
         const int sI = live ? findStart(start, nSeg, i) : 0;
-        Ray nee, next;
-        ExtraRay extra[3];
+        Ray next;
+        ExtraRay nee, extra[3]; // (occlusion rays in their compact form: direction, range, the value their light's shader adds; they start at the hit point)
         nee.valid = next.valid = extra[0].valid = extra[1].valid = extra[2].valid = false;
         uint32_t pixel = 0, prim = 0xFFFFFFFFu;
-        v3 neeValue(0.0f), hitP(0.0f);
+        v3 hitP(0.0f);
         if (live) {
             const SegDev &sg = tbl->seg[sI];
             const uint32_t j = i - start[sI];
@@ -1363,8 +1363,7 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                 sh.glass(in, sf, h.t, M, nee, next, extra[0]);
             else
                 sh.physicallyBased(in, sf, M, nee, next, extra[0], extra[1], extra[2]);
-            if (nee.valid) nee.valid = sh.lightShaderValue(nee, neeValue);
-            if (ALL) hitP = sf.P; // (where the additional occlusion rays start)
+            hitP = sf.P; // (where the occlusion rays start)
             nAccum += sh.nAccum;
         }
         // the emitted rays leave through compacted appends to the pass's queues
@@ -1376,9 +1375,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
             const uint32_t sSlot = blockReserve(wantS, sg.sCountOut, scratch);
             if (wantS && sSlot >= sg.sOutCap) queueOverflow(tbl, OVF_OCCLUSION_OUT, (uint32_t)sLo, sSlot + 1u);
             if (wantS && sSlot < sg.sOutCap) {
-                G(sg.sqOut.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                G(sg.sqOut.A)[sSlot] = make_float4(hitP.x, hitP.y, hitP.z, nee.maxT);
                 G(sg.sqOut.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-                G(sg.sqOut.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+                G(sg.sqOut.C)[sSlot] = make_float4(nee.value.x, nee.value.y, nee.value.z, __uint_as_float(pixel));
             }
             if (ALL) {
                 // each extra ray adds to a partial sum of its own (no two rays of a launch may write one pixel): partial sum j + 1 lies
@@ -1411,9 +1410,9 @@ __global__ __launch_bounds__(kShadeBlock, HR_HIT_MINBLOCKS) void k_shade_hit(con
                 const uint32_t sSlot = waveReserve(wantS, sg.sCountOut);
                 if (wantS && sSlot >= sg.sOutCap) queueOverflow(tbl, OVF_OCCLUSION_OUT, (uint32_t)s, sSlot + 1u);
                 if (wantS && sSlot < sg.sOutCap) {
-                    G(sg.sqOut.A)[sSlot] = make_float4(nee.o.x, nee.o.y, nee.o.z, nee.maxT);
+                    G(sg.sqOut.A)[sSlot] = make_float4(hitP.x, hitP.y, hitP.z, nee.maxT);
                     G(sg.sqOut.B)[sSlot] = make_float4(nee.d.x, nee.d.y, nee.d.z, __uint_as_float(prim));
-                    G(sg.sqOut.C)[sSlot] = make_float4(neeValue.x, neeValue.y, neeValue.z, __uint_as_float(pixel));
+                    G(sg.sqOut.C)[sSlot] = make_float4(nee.value.x, nee.value.y, nee.value.z, __uint_as_float(pixel));
                 }
                 if (ALL) {
                     const uint32_t framePixels = (uint32_t)((sg.passbufB - sg.passbuf) >> 2);

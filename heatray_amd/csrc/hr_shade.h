@@ -380,10 +380,13 @@ template <int MODE> struct ShaderT {
         r.valid = true;
         return r;
     }
-    static HRD void emit(const Ray &r, Ray &nee, Ray &next)
+    // emitRay(): a continuation ray travels whole; of an occlusion ray only what its queue entry needs is kept — direction, range and the
+    // value its light's shader adds when nothing is in the way, evaluated right here (an occlusion ray starts at the hit point like every ray
+    // a vertex emits): a third of the registers of a Ray across the rest of the shader
+    HRD void emit(const Ray &r, ExtraRay &nee, Ray &next) const
     {
         if (r.occlusionTest)
-            nee = r;
+            keep(r, nee);
         else
             next = r;
     }
@@ -396,7 +399,7 @@ template <int MODE> struct ShaderT {
         return v3(1.0f) + Cspec * ms;
     }
     HRD void indirectDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float optionalLightSampleProbability, v2 rand,
-                                   const m3 &frame, int missKind, Ray &nee, Ray &next) const // :25-50
+                                   const m3 &frame, int missKind, ExtraRay &nee, Ray &next) const // :25-50
     {
         v3 dir = cosineWeightedSample(rand.x, rand.y);
         v3 O = mul(frame, dir);
@@ -488,7 +491,7 @@ template <int MODE> struct ShaderT {
         return v3(ce * sa, se, -(ce * ca));
     }
     // which: 0 = the vertex's environment sample; 1, 2 = the extra ones HR_ESTIMATOR_ALL_LIGHTS takes at a camera ray's hit (own sequence values)
-    HRD void envMisDiffuse(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee,
+    HRD void envMisDiffuse(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float envProbability, v2 rand, const m3 &frame, ExtraRay &nee,
                            Ray &next, int which = 0) const
     {
         const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
@@ -520,7 +523,7 @@ template <int MODE> struct ShaderT {
         }
     }
     HRD void envMisSpecular(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
-                            float sampleProbability, float envProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next, int which = 0) const
+                            float sampleProbability, float envProbability, v2 rand, const m3 &frame, ExtraRay &nee, Ray &next, int which = 0) const
     {
         const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5 + 2 * which, pp.sample_index + in.sequenceIndexOffset);
         // the map's row variable is stratified over the vertex's samples (sample j of n draws it from the j-th n-th of [0, 1): the
@@ -563,7 +566,7 @@ template <int MODE> struct ShaderT {
     // (`ls` = computeLightSample(N, lightProbability, P), lightSampling.rlsl:11-161: evaluated by the caller, once for whichever lobe the
     // vertex samples, so that the light pick — a loop over up to fifteen lights — exists and runs once per wave, not once per lobe)
     HRD void directDiffuseSample(const Ray &in, v3 P, v3 N, v3 Cdiff, float sampleProbability, float lightProbability, v2 rand, const m3 &frame,
-                                 const LightSample &ls, Ray &nee, Ray &next) const // :52-98
+                                 const LightSample &ls, ExtraRay &nee, Ray &next) const // :52-98
     {
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
             float NdotO = dot(N, ls.dir);
@@ -594,7 +597,7 @@ template <int MODE> struct ShaderT {
     }
     HRD void indirectSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
                                     float sampleProbability, float optionalLightSampleProbability, v2 rand, const m3 &frame, int missKind,
-                                    Ray &nee, Ray &next) const // :100-151
+                                    ExtraRay &nee, Ray &next) const // :100-151
     {
         v3 localSpaceI = mulT(frame, I);
         v3 H = mul(frame, sampleVisibleGGX(localSpaceI, rand.x, rand.y, roughnessAlpha));
@@ -639,7 +642,7 @@ template <int MODE> struct ShaderT {
         return specular;
     }
     HRD void directSpecularSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 Cspec, float roughnessAlpha, int lut, float roughness,
-                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, const LightSample &ls, Ray &nee,
+                                  float sampleProbability, float lightProbability, v2 rand, const m3 &frame, const LightSample &ls, ExtraRay &nee,
                                   Ray &next) const // :153-220
     {
         if ((ls.type != LIGHT_TYPE_ENVIRONMENT) && (lightProbability > 0.0f)) {
@@ -705,7 +708,7 @@ template <int MODE> struct ShaderT {
     }
 
     // ---- physicallyBased.rlsl:55-331 ----
-    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, ExtraRay &nee2, ExtraRay &nee3, ExtraRay &nee4)
+    HRD void physicallyBased(const Ray &inRay, const Surface &sf, const HR_GLOBAL hr_material &M, ExtraRay &nee, Ray &next, ExtraRay &nee2, ExtraRay &nee3, ExtraRay &nee4)
     {
         Ray in = inRay;
         const uint32_t F = M.flags;
@@ -862,7 +865,8 @@ template <int MODE> struct ShaderT {
                                                 ? 1
                                                 : ((u <= (diffuseProbability + clearCoatProbability + specularProbability)) ? 2 : 3));
                         if (lobe == 3) continue;
-                        Ray out, unusedNext;
+                        ExtraRay out;
+                        Ray unusedNext;
                         out.valid = false;
                         if (lobe == 0) {
                             if (mis)
@@ -884,9 +888,9 @@ template <int MODE> struct ShaderT {
                         if (j == 0)
                             nee = out;
                         else if (j == 1)
-                            keep(out, nee3);
+                            nee3 = out;
                         else
-                            keep(out, nee4);
+                            nee4 = out;
                     }
                 }
             } else if (probability.x <= (diffuseProbability + clearCoatProbability + specularProbability)) {
@@ -916,7 +920,7 @@ template <int MODE> struct ShaderT {
             }
             v2 rand = getSequenceValue(in.sequenceID + in.depth + 3, si);
             v2 probability = getSequenceValue(in.sequenceID + in.depth + 4, si);
-            Ray dummyNee;
+            ExtraRay dummyNee;
             dummyNee.valid = false;
             if (probability.x <= diffuseProbability) {
                 indirectDiffuseSample(in, sf.P, N, Cdiff, diffuseProbability, 1.0f, rand, frame, MISS_NONE, dummyNee, next);
@@ -933,7 +937,7 @@ template <int MODE> struct ShaderT {
     // ---- glass.rlsl ----
     HRD void indirectSpecularGlassSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 weight, v3 baseColor, float roughnessAlpha,
                                          float materialRoughnessAlpha, float optionalLightSampleProbability, v2 rand, const m3 &frame, int missKind,
-                                         Ray &nee, Ray &next) const // :47-81
+                                         ExtraRay &nee, Ray &next) const // :47-81
     {
         v3 localSpaceI = mulT(frame, I);
         v3 H = mul(frame, sampleVisibleGGX(localSpaceI, rand.x, rand.y, roughnessAlpha));
@@ -965,7 +969,7 @@ template <int MODE> struct ShaderT {
     // table, half the time each, balance heuristic; BRDF x cos as glass.rlsl:104-109 has it for an analytic light (D G2 / (4 N.I) x
     // baseColor), lobe density D G1 / (4 N.I); selection variable: sequence ID + depth + 5.  Same operations as the oracle's.
     HRD void envMisGlass(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 weight, v3 baseColor, float roughnessAlpha, float envProbability, v2 rand,
-                         const m3 &frame, Ray &nee, Ray &next) const
+                         const m3 &frame, ExtraRay &nee, Ray &next) const
     {
         const v2 sel = getSequenceValue(in.sequenceID + in.depth + 5, pp.sample_index + in.sequenceIndexOffset);
         v3 O, H;
@@ -999,7 +1003,7 @@ template <int MODE> struct ShaderT {
         }
     }
     HRD void directSpecularGlassSample(const Ray &in, v3 P, v3 N, v3 I, float NdotI, v3 weight, v3 baseColor, float roughnessAlpha,
-                                       float materialRoughnessAlpha, float lightProbability, v2 rand, const m3 &frame, Ray &nee, Ray &next,
+                                       float materialRoughnessAlpha, float lightProbability, v2 rand, const m3 &frame, ExtraRay &nee, Ray &next,
                                        ExtraRay &nee2) const // :83-129
     {
         const bool both = allLights(); // HR_ESTIMATOR_ALL_LIGHTS: an analytic light (-> nee2) AND the environment (-> nee), not one of them
@@ -1048,7 +1052,7 @@ template <int MODE> struct ShaderT {
                                             MISS_ENV, nee, next);
         }
     }
-    HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, Ray &nee, Ray &next, ExtraRay &nee2) // :138-280
+    HRD void glass(const Ray &in, const Surface &sf, float hitT, const HR_GLOBAL hr_material &M, ExtraRay &nee, Ray &next, ExtraRay &nee2) // :138-280
     {
         const uint32_t F = M.flags;
         const bool hasTextures = (F & (HR_MF_HAS_BASE_COLOR_TEXTURE | HR_MF_HAS_METALLIC_ROUGHNESS_TEXTURE | HR_MF_HAS_NORMALMAP)) != 0;
@@ -1148,7 +1152,7 @@ template <int MODE> struct ShaderT {
                     weight = weight / probability;
                 }
                 rand = getSequenceValue(in.sequenceID + in.depth + 4, si);
-                Ray dummyNee;
+                ExtraRay dummyNee;
                 dummyNee.valid = false;
                 indirectSpecularGlassSample(in, sf.P, N, I, NdotI, weight, baseColor, roughnessAlpha, M.roughness_alpha, 1.0f, rand, frame, MISS_NONE,
                                             dummyNee, next);

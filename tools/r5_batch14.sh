@@ -1,0 +1,15 @@
+#!/bin/bash
+mkdir -p gpurun_out
+step() { local lim=$1 log=$2; shift 2; timeout -k 10 $lim "$@" > gpurun_out/$log 2>&1; local rc=$?; echo "[$log] rc=$rc"; tail -3 gpurun_out/$log; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIME LIMIT: batch ends"; exit 1; fi; }
+step 800 r5u_gpu_suite.log python -m pytest tests -m gpu -x -q
+run() { local label=$1 wl=$2 k=$3 lib=$4
+  for i in 1 2 3; do
+    v=$(HR_BENCH_TIME_KERNELS=1 HRCORE_LIB=$lib timeout -k 10 300 python bench.py --quick --parity-seconds 0 --workload $wl --steps $k --warmup 5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); k=d['extra']['kernel_ms_rank0']; print(round(d['value'],1), 'shade ms', round(k['shade'],3))")
+    echo "[$label] $wl $k passes: $v" >> gpurun_out/r5u_compact_nee.txt
+  done
+}
+for wl in c3 c3d c5; do for k in 20 128; do
+  run before $wl $k $PWD/build_variants/libhrcore_prev.so
+  run compact-nee+frame $wl $k ""
+done; done
+cat gpurun_out/r5u_compact_nee.txt
