@@ -153,12 +153,12 @@ class Hit(C.Structure):
 HIT_DTYPE = np.dtype([("prim", np.int32), ("t", np.float32), ("u", np.float32), ("v", np.float32)])
 
 # every symbol include/hrcore.h declares (suffix after the prefix)
-HR_ABI_VERSION = 5  # include/hrcore.h: checked against the loaded library before the first call (Engine.__init__)
+HR_ABI_VERSION = 6  # include/hrcore.h: checked against the loaded library before the first call (Engine.__init__)
 ABI_SYMBOLS = [
     "abi_version", "ctx_create", "ctx_destroy", "last_error", "ctx_set_stream", "frame_resize", "frame_bind_external",
     "frame_device_ptr", "geom_add", "geom_remove", "geom_set_transform", "scene_clear", "scene_commit",
     "scene_get_info", "texture_create", "texture_destroy", "material_set", "lights_set", "sequences_set",
-    "seq_offsets_set", "qmc_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
+    "seq_offsets_set", "qmc_generate", "aperture_generate", "sequences_generate", "seq_offsets_generate", "multiscatter_lut_generate",
     "clear", "render_pass", "flush", "get_stats", "get_kernel_times", "readback", "synchronize", "debug_trace",
     "display", "display_readback", "frame_passes_resolved", "get_step_log", "readback_progressive", "frame_packed_slots", "frame_pack_owned", "frame_unpack",
     "frame_pass_batch", "interactive_blocks_set", "scene_cache",
@@ -337,6 +337,12 @@ class Engine:
         out = np.empty((count, 2), dtype=np.float32)
         self._call("qmc_generate", C.c_int32(mode), C.c_uint32(sequence_index), C.c_uint32(count),
                    C.c_int32(int(radial)), _ptr(out))
+        return out
+
+    def aperture_generate(self, bokeh, sequence_index, count):
+        """One aperture table as PassGenerator.cpp:653-676 makes it: radialSobol or randomPolygonal(5 / 6 / 8 edges, seed = sequence)."""
+        out = np.empty((count, 2), dtype=np.float32)
+        self._call("aperture_generate", C.c_int32(bokeh), C.c_uint32(sequence_index), C.c_uint32(count), _ptr(out))
         return out
 
     def generate_sequences(self, sample_mode=HR_SAMPLE_SOBOL, bokeh=HR_BOKEH_CIRCULAR, length=32):

@@ -12,6 +12,7 @@
 //              so no reliance on cross-XCD visibility)
 //   emit     : subtrees of <= 4 triangles collapse into leaves; 64-byte two-box nodes
 #include "hr_kernels.h"
+#include "hr_tables.h"
 #include <cstring>
 #include "hr_texture.h"
 
@@ -1616,6 +1617,159 @@ void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count,
 {
     if (count == 0) return;
     hipLaunchKernelGGL(k_qmc, dim3((count + 255) / 256), dim3(256), 0, st, mode, sequenceIndex, count, out);
+}
+
+// ---------------------------------------------------------------- tables of the sequential generators
+// util::uniformRandomFloats (edges == 0) and util::randomPolygonal (edges = 5 / 6 / 8) — Random.h:113-130, 293-355; arithmetic in hr_tables.h.
+// One workgroup per sequence: MT19937's state lives in LDS, seeded by one lane (a 623-step chain), twisted by 208 lanes in three rounds
+// (word i needs words i+1 and i+397 from before the twist for i < 227 and word i-227 from after it: a round of 208 < 227 words never reads a
+// word of its own round after it was written) and tempered 624 draws at a time.  uniformRandomFloats maps draw 2s / 2s+1 to sample s, in parallel;
+// randomPolygonal consumes a data-dependent number of draws per sample (Lemire's rejection for the fan triangle, a rejection loop for the
+// barycentrics), so one lane walks the block of draws with the four-state machine of the serial loop.  The polygon's vertices come from the
+// host (cosf / sinf of the platform's libm, the same calls the reference makes: like radialSobol's disk mapping in hr_scene.inl).
+struct PolyVerts { float x[8], y[8]; };
+static constexpr int kMtRound = 208; // 3 x 208 = 624
+__global__ __launch_bounds__(256) void k_mt_tables(uint32_t seed0, uint32_t count, uint32_t edges, PolyVerts verts, float2 *__restrict__ outBase,
+                                                   size_t stride)
+{
+    __shared__ uint32_t st[kMtN], draws[kMtN];
+    __shared__ uint32_t sDone;
+    const uint32_t tid = threadIdx.x;
+    float2 *out = outBase + (size_t)blockIdx.x * stride;
+    if (tid == 0) {
+        uint32_t v = seed0 + blockIdx.x;
+        st[0] = v;
+        for (uint32_t i = 1; i < (uint32_t)kMtN; ++i) st[i] = v = mtSeedNext(v, i);
+        sDone = 0;
+    }
+    __syncthreads();
+    uint32_t done = 0, phase = 0; // (lane 0's: samples finished; 0 = fan triangle, first draw, 1 = its retries, 2 = alpha, 3 = beta)
+    MtIntDraw pick{edges, 0u, 0ull};
+    float alpha = 0.0f;
+    for (uint32_t drawBase = 0;; drawBase += (uint32_t)kMtN) {
+        for (int r = 0; r < 3; ++r) {
+            const uint32_t i = (uint32_t)(r * kMtRound) + tid;
+            uint32_t w = 0;
+            if (tid < (uint32_t)kMtRound) w = mtTwist(st[i], st[(i + 1) % kMtN], st[(i + kMtM) % kMtN]);
+            __syncthreads();
+            if (tid < (uint32_t)kMtRound) st[i] = w;
+            __syncthreads();
+        }
+        for (uint32_t k = tid; k < (uint32_t)kMtN; k += 256) draws[k] = mtTemper(st[k]);
+        __syncthreads();
+        if (edges == 0) {
+            float *o = reinterpret_cast<float *>(out);
+            for (uint32_t k = tid; k < (uint32_t)kMtN; k += 256) {
+                const uint64_t g = (uint64_t)drawBase + k;
+                if (g < 2ull * count) o[g] = mtCanonical(draws[k]);
+            }
+            if ((uint64_t)drawBase + kMtN >= 2ull * count) break;
+        } else {
+            if (tid == 0) {
+                for (int k = 0; k < kMtN && done < count; ++k) {
+                    const uint32_t u = draws[k];
+                    if (phase < 2) {
+                        phase = pick.accept(u, phase == 0) ? 2u : 1u;
+                    } else if (phase == 2) {
+                        alpha = mtCanonical(u), phase = 3;
+                    } else {
+                        const float beta = mtCanonical(u);
+                        if (alpha + beta > 1.0f) {
+                            phase = 2;
+                            continue;
+                        }
+                        const float gamma = 1.0f - (alpha + beta);
+                        const int t0 = pick.value(), t1 = (t0 + 1) % (int)edges;
+                        const float vx = 0.0f * alpha + verts.x[t0] * beta + verts.x[t1] * gamma; // (the fan's centre is vertex 0 of every triangle)
+                        const float vy = 0.0f * alpha + verts.y[t0] * beta + verts.y[t1] * gamma;
+                        out[done++] = make_float2((vx + 1.0f) * 0.5f, (vy + 1.0f) * 0.5f);
+                        phase = 0;
+                    }
+                }
+                sDone = done;
+            }
+            __syncthreads();
+            if (sDone >= count) break;
+        }
+    }
+}
+void launchMtTables(hipStream_t st, uint32_t seed0, int nSeq, uint32_t count, uint32_t edges, const float *vx, const float *vy, float2 *out, size_t stride)
+{
+    if (count == 0 || nSeq <= 0) return;
+    PolyVerts v{};
+    for (uint32_t i = 0; i < edges && i < 8u; ++i) v.x[i] = vx[i], v.y[i] = vy[i];
+    hipLaunchKernelGGL(k_mt_tables, dim3((uint32_t)nSeq), dim3(256), 0, st, seed0, count, edges, v, out, stride);
+}
+
+// util::blueNoise (BlueNoise.h:52-88): point i is the best of 30 hashed candidates, "best" = furthest from its nearest earlier point.  The
+// candidates do not depend on the points (a hash of a running seed), so one launch makes them all; the choice is sequential over the points
+// and parallel inside a point: a workgroup per sequence, 30 groups of 32 lanes — a group per candidate, a lane per 32nd earlier point —
+// min over squared distances (the square root is monotone, it is taken once per candidate), then one lane picks the first candidate whose
+// nearest distance exceeds the running maximum, as the serial loop does.  15 n^2 distance tests per sequence of n points.
+static constexpr int kBlueCandidates = 30, kBlueLds = 8192;
+__global__ __launch_bounds__(256) void k_blue_candidates(int32_t seq0, uint32_t nSeq, uint32_t count, float2 *__restrict__ cand, float2 *__restrict__ outBase, size_t stride)
+{
+    const uint32_t perSeq = (count - 1u) * (uint32_t)kBlueCandidates + 1u; // (entry 0: the first point itself)
+    const uint64_t gid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t s = (uint32_t)(gid / perSeq), k = (uint32_t)(gid % perSeq);
+    if (s >= nSeq) return;
+    const uint32_t seed = blueSeed(seq0 + (int32_t)s) + 2u * k;
+    const float2 p = make_float2(blueRandom(seed), blueRandom(seed + 1u));
+    if (k == 0)
+        outBase[(size_t)s * stride] = p;
+    else
+        cand[(size_t)s * (perSeq - 1u) + (k - 1u)] = p;
+}
+template <bool LDS>
+__global__ __launch_bounds__(1024) void k_blue_noise(uint32_t count, const float2 *__restrict__ candBase, float2 *__restrict__ outBase, size_t stride)
+{
+    __shared__ float2 ptsLds[LDS ? kBlueLds : 1];
+    __shared__ float nearest[32];
+    float2 *out = outBase + (size_t)blockIdx.x * stride;
+    const float2 *cand = candBase + (size_t)blockIdx.x * (count - 1u) * kBlueCandidates;
+    float2 *pts = LDS ? ptsLds : out;
+    const uint32_t tid = threadIdx.x, g = tid >> 5, l = tid & 31u;
+    if (LDS && tid == 0) ptsLds[0] = out[0];
+    __syncthreads();
+    const float diag = sqrt_(1.0f * 1.0f + 1.0f * 1.0f);
+    for (uint32_t i = 1; i < count; ++i) {
+        if (g < (uint32_t)kBlueCandidates) {
+            const float2 c = cand[(size_t)(i - 1u) * kBlueCandidates + g];
+            float m = 3.0e38f;
+            for (uint32_t j = l; j < i; j += 32u) {
+                const float2 p = pts[j];
+                const float dx = p.x - c.x, dy = p.y - c.y;
+                m = fmin_(m, dx * dx + dy * dy);
+            }
+#pragma unroll
+            for (int sh = 16; sh > 0; sh >>= 1) m = fmin_(m, __shfl_xor(m, sh));
+            if (l == 0) nearest[g] = fmin_(diag, sqrt_(m));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float furthest = 0.0f;
+            int best = -1;
+            for (int c = 0; c < kBlueCandidates; ++c)
+                if (nearest[c] > furthest) furthest = nearest[c], best = c;
+            const float2 p = best < 0 ? make_float2(0.0f, 0.0f) : cand[(size_t)(i - 1u) * kBlueCandidates + best];
+            pts[i] = p;
+            if (LDS) out[i] = p;
+        }
+        __syncthreads();
+    }
+}
+// cand: scratch of nSeq * (count - 1) * 30 points
+void launchBlueNoise(hipStream_t st, int32_t seq0, int nSeq, uint32_t count, float2 *out, size_t stride, float2 *cand)
+{
+    if (count == 0 || nSeq <= 0) return;
+    const uint64_t total = (uint64_t)nSeq * ((uint64_t)(count - 1u) * kBlueCandidates + 1u);
+    hipLaunchKernelGGL(k_blue_candidates, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, seq0, (uint32_t)nSeq, count, cand, out, stride);
+    int dev = 0, ldsMax = 0; // (the LDS copy of the points is 64 KB + the candidates' row: more than a gfx9 before gfx950 gives one workgroup)
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ldsMax, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) ldsMax = 0;
+    if (count <= (uint32_t)kBlueLds && (size_t)ldsMax >= sizeof(float2) * kBlueLds + 256)
+        hipLaunchKernelGGL(k_blue_noise<true>, dim3((uint32_t)nSeq), dim3(1024), 0, st, count, cand, out, stride);
+    else
+        hipLaunchKernelGGL(k_blue_noise<false>, dim3((uint32_t)nSeq), dim3(1024), 0, st, count, cand, out, stride);
 }
 
 // ------------------------------------------------------------------------------ multiscatter LUT

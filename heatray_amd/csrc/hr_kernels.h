@@ -231,6 +231,11 @@ void launchEnvTable(hipStream_t st, const TexDesc &tex, float *lum, float *dil, 
                     uint32_t *maxBits, float *rowCdf, float *colCdf, float *prob, float *meanLum);
 
 void launchQmc(hipStream_t st, int mode, uint32_t sequenceIndex, uint32_t count, float2 *out);
+// the sequential generators (hr_tables.h): nSeq tables of `count` points, table s at out + s * stride.  edges == 0: util::uniformRandomFloats
+// with seed seed0 + s, else util::randomPolygonal over the polygon (vx, vy)[edges]; launchBlueNoise: util::blueNoise of sequence seq0 + s,
+// cand = scratch of nSeq * (count - 1) * 30 points
+void launchMtTables(hipStream_t st, uint32_t seed0, int nSeq, uint32_t count, uint32_t edges, const float *vx, const float *vy, float2 *out, size_t stride);
+void launchBlueNoise(hipStream_t st, int32_t seq0, int nSeq, uint32_t count, float2 *out, size_t stride, float2 *cand);
 void launchMultiscatterLUT(hipStream_t st, const float2 *sobol4096, float *out128x128);
 
 } // namespace hr

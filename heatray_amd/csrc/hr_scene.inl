@@ -630,42 +630,115 @@ static void radialOnHost(float2 *p, size_t count)
     }
 }
 
-int hr_qmc_generate(hr_ctx *c, int32_t mode, uint32_t seqIndex, uint32_t count, int32_t radial, float *out)
+// the fan polygon of randomPolygonal (Random.h:299-306): `edges` vertices on the unit circle, by the platform's cosf / sinf like the
+// reference's own call (same reasoning as radialOnHost: 5 to 8 values, once per table)
+static void polygonOnHost(uint32_t edges, float *vx, float *vy)
 {
-    ENTER(c);
-    if (mode != HR_SAMPLE_SOBOL && mode != HR_SAMPLE_HALTON && mode != HR_SAMPLE_HAMMERSLEY)
-        FAIL(c, HR_ERR_UNSUPPORTED, "sample mode has no device generator (host tables only)");
-    if (radial && mode != HR_SAMPLE_SOBOL) FAIL(c, HR_ERR_INVALID, "radial is defined for Sobol only");
-    if (count == 0 || !out) FAIL(c, HR_ERR_INVALID, "bad count / output");
-    float2 *d = nullptr;
-    HIP_TRY(c, hipMalloc(&d, (size_t)count * sizeof(float2)));
-    launchQmc(c->stream, mode, seqIndex, count, d);
+    const float two_pi = 6.28318530717958647692f;
+    const float stepSize = two_pi / (float)edges;
+    for (uint32_t i = 0; i < edges; ++i) {
+        const float theta = stepSize * (float)i;
+        vx[i] = cosf(theta), vy[i] = sinf(theta);
+    }
+}
+static uint32_t bokehEdges(int32_t bokeh) { return bokeh == HR_BOKEH_PENTAGON ? 5u : bokeh == HR_BOKEH_HEXAGON ? 6u : bokeh == HR_BOKEH_OCTAGON ? 8u : 0u; }
+
+// nSeq tables of `count` sample points (sequences seq0 .. seq0 + nSeq - 1) into d + s * stride, every mode of PassGenerator.h:100-106 on the
+// device: the closed-form sequences by index (k_qmc), the std:: tables and the blue-noise points by their serial algorithms (hr_tables.h)
+static int sampleTablesOnDevice(hr_ctx *c, int32_t mode, uint32_t seq0, int nSeq, uint32_t count, float2 *d, size_t stride)
+{
+    if (mode == HR_SAMPLE_RANDOM) {
+        launchMtTables(c->stream, seq0, nSeq, count, 0, nullptr, nullptr, d, stride);
+    } else if (mode == HR_SAMPLE_BLUE_NOISE) {
+        float2 *cand = nullptr;
+        if (count > 1) HIP_TRY(c, hipMalloc(&cand, (size_t)nSeq * (count - 1u) * 30u * sizeof(float2)));
+        launchBlueNoise(c->stream, (int32_t)seq0, nSeq, count, d, stride, cand);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream); // (the scratch is freed here, so the launches must be done)
+        if (cand) hipFree(cand);
+        HIP_TRY(c, e);
+    } else {
+        for (int s = 0; s < nSeq; ++s) launchQmc(c->stream, mode, seq0 + (uint32_t)s, count, d + (size_t)s * stride);
+    }
+    HIP_TRY(c, hipGetLastError());
+    return HR_OK;
+}
+// the aperture tables of PassGenerator.cpp:653-676 likewise; the circular one still wants radialOnHost over the result
+static int apertureTablesOnDevice(hr_ctx *c, int32_t bokeh, uint32_t seq0, int nSeq, uint32_t count, float2 *d, size_t stride)
+{
+    const uint32_t edges = bokehEdges(bokeh);
+    if (edges == 0) return sampleTablesOnDevice(c, HR_SAMPLE_SOBOL, seq0, nSeq, count, d, stride);
+    float vx[8], vy[8];
+    polygonOnHost(edges, vx, vy);
+    launchMtTables(c->stream, seq0, nSeq, count, edges, vx, vy, d, stride);
+    HIP_TRY(c, hipGetLastError());
+    return HR_OK;
+}
+static bool knownSampleMode(int32_t m) { return m >= HR_SAMPLE_RANDOM && m <= HR_SAMPLE_SOBOL; }
+static bool knownBokeh(int32_t b) { return b >= HR_BOKEH_CIRCULAR && b <= HR_BOKEH_OCTAGON; }
+
+static int tableToHost(hr_ctx *c, float2 *d, uint32_t count, float *out)
+{
     hipError_t e = hipMemcpyAsync(out, d, (size_t)count * sizeof(float2), hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     hipFree(d);
     HIP_TRY(c, e);
+    return HR_OK;
+}
+
+int hr_qmc_generate(hr_ctx *c, int32_t mode, uint32_t seqIndex, uint32_t count, int32_t radial, float *out)
+{
+    ENTER(c);
+    if (!knownSampleMode(mode)) FAIL(c, HR_ERR_INVALID, "unknown sample mode");
+    if (radial && mode != HR_SAMPLE_SOBOL) FAIL(c, HR_ERR_INVALID, "radial is defined for Sobol only");
+    if (count == 0 || !out) FAIL(c, HR_ERR_INVALID, "bad count / output");
+    float2 *d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, (size_t)count * sizeof(float2)));
+    int rc = sampleTablesOnDevice(c, mode, seqIndex, 1, count, d, count);
+    if (rc) {
+        hipFree(d);
+        return rc;
+    }
+    rc = tableToHost(c, d, count, out);
+    if (rc) return rc;
     if (radial) radialOnHost(reinterpret_cast<float2 *>(out), count);
+    return HR_OK;
+}
+
+int hr_aperture_generate(hr_ctx *c, int32_t bokeh, uint32_t seqIndex, uint32_t count, float *out)
+{
+    ENTER(c);
+    if (!knownBokeh(bokeh)) FAIL(c, HR_ERR_INVALID, "unknown bokeh shape");
+    if (count == 0 || !out) FAIL(c, HR_ERR_INVALID, "bad count / output");
+    float2 *d = nullptr;
+    HIP_TRY(c, hipMalloc(&d, (size_t)count * sizeof(float2)));
+    int rc = apertureTablesOnDevice(c, bokeh, seqIndex, 1, count, d, count);
+    if (rc) {
+        hipFree(d);
+        return rc;
+    }
+    rc = tableToHost(c, d, count, out);
+    if (rc) return rc;
+    if (bokeh == HR_BOKEH_CIRCULAR) radialOnHost(reinterpret_cast<float2 *>(out), count);
     return HR_OK;
 }
 
 int hr_sequences_generate(hr_ctx *c, int32_t sampleMode, int32_t bokeh, int32_t len)
 {
     ENTER(c);
-    if (sampleMode != HR_SAMPLE_SOBOL && sampleMode != HR_SAMPLE_HALTON && sampleMode != HR_SAMPLE_HAMMERSLEY)
-        FAIL(c, HR_ERR_UNSUPPORTED, "sample mode has no device generator: upload host tables with hr_sequences_set");
-    if (bokeh != HR_BOKEH_CIRCULAR) FAIL(c, HR_ERR_UNSUPPORTED, "polygonal bokeh tables are host-generated: use hr_sequences_set");
+    if (!knownSampleMode(sampleMode)) FAIL(c, HR_ERR_INVALID, "unknown sample mode");
+    if (!knownBokeh(bokeh)) FAIL(c, HR_ERR_INVALID, "unknown bokeh shape");
     if (len <= 0) FAIL(c, HR_ERR_INVALID, "bad sequence length");
     const int nSeq = HR_NUM_RANDOM_SEQUENCES;
     int rc = setTable(c, &c->dSeq, nullptr, (size_t)nSeq * len);
     if (rc) return rc;
     rc = setTable(c, &c->dAperture, nullptr, (size_t)nSeq * len);
     if (rc) return rc;
-    for (int s = 0; s < nSeq; ++s) { // PassGenerator.cpp:614-662
-        launchQmc(c->stream, sampleMode, (uint32_t)s, (uint32_t)len, c->dSeq + (size_t)s * len);
-        launchQmc(c->stream, HR_SAMPLE_SOBOL, (uint32_t)s, (uint32_t)len, c->dAperture + (size_t)s * len);
-    }
-    HIP_TRY(c, hipGetLastError());
-    { // the aperture tables: Sobol points from the device, disk mapping on the host (see radialOnHost)
+    rc = sampleTablesOnDevice(c, sampleMode, 0, nSeq, (uint32_t)len, c->dSeq, (size_t)len); // PassGenerator.cpp:614-637
+    if (rc) return rc;
+    rc = apertureTablesOnDevice(c, bokeh, 0, nSeq, (uint32_t)len, c->dAperture, (size_t)len); // :653-676
+    if (rc) return rc;
+    if (bokeh == HR_BOKEH_CIRCULAR) { // Sobol points from the device, disk mapping on the host (see radialOnHost)
         std::vector<float2> ap((size_t)nSeq * len);
         HIP_TRY(c, hipMemcpyAsync(ap.data(), c->dAperture, ap.size() * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -251,24 +251,3 @@ class RenderOptions:
         p.estimator = int(self.estimator)
         p.texture_lod = int(self.texture_lod)
         return p
-
-
-def polygon_aperture(points_xy, n_edges):
-    """Deterministic polygonal-bokeh aperture samples (BASELINE config 5: pentagon).  The reference's
-    util::randomPolygonal (Source/Utility/Random.h:293-345) picks a fan triangle of the unit-circle polygon and a
-    uniform point inside it with std::random_device-seeded std:: distributions — not reproducible; this maps the 2-D
-    low-discrepancy points `points_xy` in [0,1)^2 (e.g. a Sobol sequence) onto the same polygon instead: x selects the
-    triangle (centre, v_k, v_k+1) and re-used fractional part + y the point (sqrt warp), all in float32."""
-    p = np.asarray(points_xy, dtype=np.float32).reshape(-1, 2)
-    n = np.float32(n_edges)
-    t = p[:, 0] * n
-    k = np.minimum(np.floor(t), n - 1).astype(np.int64)
-    u = (t - k.astype(np.float32)).astype(np.float32)
-    v = p[:, 1]
-    step = np.float32(2.0 * math.pi) / n
-    th0, th1 = step * k.astype(np.float32), step * ((k + 1) % n_edges).astype(np.float32)
-    a = np.stack([np.cos(th0), np.sin(th0)], axis=1).astype(np.float32)
-    b = np.stack([np.cos(th1), np.sin(th1)], axis=1).astype(np.float32)
-    su = np.sqrt(u).astype(np.float32)
-    w1, w2 = (su * (np.float32(1.0) - v)).astype(np.float32), (su * v).astype(np.float32)
-    return (a * w1[:, None] + b * w2[:, None]).astype(np.float32).reshape(np.asarray(points_xy).shape)

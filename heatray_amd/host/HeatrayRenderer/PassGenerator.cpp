@@ -409,23 +409,13 @@ void PassGenerator::changeEnvironment(const RenderOptions::Environment &newEnv)
     }
 }
 
-// PassGenerator.cpp:603-684 of the reference: 16 sequences x sampleCount points plus the aperture table.
-// Sobol / Halton / Hammersley with a circular aperture are generated by a HIP kernel; the modes built on
-// std:: distributions or on the sequential blue-noise algorithm use the application's own generators on
-// the host (exactly the reference's tables) and are uploaded.
+// PassGenerator.cpp:603-684 of the reference: 16 sequences x sampleCount points plus the aperture table, every sample mode and bokeh
+// shape made by HIP kernels behind hr_sequences_generate.  The tables the reference builds on <random> (kRandom and the polygonal apertures)
+// are libstdc++'s there (include/hrcore.h says which algorithms); an application that must keep another standard library's tables defines
+// HR_HOST_TABLES_FROM_RANDOM_H and gets them from its own Utility/Random.h, uploaded with hr_sequences_set.
 bool PassGenerator::generateRandomSequences(const RLint sampleCount, RenderOptions::SampleMode sampleMode, RenderOptions::BokehShape bokehShape)
 {
-    int deviceMode = -1;
-    switch (sampleMode) {
-        case RenderOptions::SampleMode::kHalton:     deviceMode = HR_SAMPLE_HALTON; break;
-        case RenderOptions::SampleMode::kHammersley: deviceMode = HR_SAMPLE_HAMMERSLEY; break;
-        case RenderOptions::SampleMode::kSobol:      deviceMode = HR_SAMPLE_SOBOL; break;
-        default: break;
-    }
-    if (deviceMode >= 0 && bokehShape == RenderOptions::BokehShape::kCircular) {
-        return HRFunc(hr_sequences_generate(m_context, deviceMode, HR_BOKEH_CIRCULAR, sampleCount));
-    }
-#if defined(HR_HOST_HAS_RANDOM_H)
+#if defined(HR_HOST_TABLES_FROM_RANDOM_H) && defined(HR_HOST_HAS_RANDOM_H)
     std::vector<glm::vec2> values((size_t)kNumRandomSequences * sampleCount), aperture(values.size());
     for (unsigned int iSequence = 0; iSequence < (unsigned int)kNumRandomSequences; ++iSequence) {
         glm::vec2* seq = &values[(size_t)iSequence * sampleCount];
@@ -446,8 +436,20 @@ bool PassGenerator::generateRandomSequences(const RLint sampleCount, RenderOptio
     }
     return HRFunc(hr_sequences_set(m_context, &values[0].x, &aperture[0].x, kNumRandomSequences, sampleCount));
 #else
-    fprintf(stderr, "PassGenerator: this sample mode / bokeh shape needs the application's Utility/Random.h tables; "
-                    "falling back to Sobol with a circular aperture\n");
-    return HRFunc(hr_sequences_generate(m_context, HR_SAMPLE_SOBOL, HR_BOKEH_CIRCULAR, sampleCount));
+    int mode = HR_SAMPLE_SOBOL, shape = HR_BOKEH_CIRCULAR;
+    switch (sampleMode) {
+        case RenderOptions::SampleMode::kRandom:     mode = HR_SAMPLE_RANDOM; break;
+        case RenderOptions::SampleMode::kHalton:     mode = HR_SAMPLE_HALTON; break;
+        case RenderOptions::SampleMode::kHammersley: mode = HR_SAMPLE_HAMMERSLEY; break;
+        case RenderOptions::SampleMode::kBlueNoise:  mode = HR_SAMPLE_BLUE_NOISE; break;
+        case RenderOptions::SampleMode::kSobol:      mode = HR_SAMPLE_SOBOL; break;
+    }
+    switch (bokehShape) {
+        case RenderOptions::BokehShape::kCircular: shape = HR_BOKEH_CIRCULAR; break;
+        case RenderOptions::BokehShape::kPentagon: shape = HR_BOKEH_PENTAGON; break;
+        case RenderOptions::BokehShape::kHexagon:  shape = HR_BOKEH_HEXAGON; break;
+        case RenderOptions::BokehShape::kOctagon:  shape = HR_BOKEH_OCTAGON; break;
+    }
+    return HRFunc(hr_sequences_generate(m_context, mode, shape, sampleCount));
 #endif
 }

@@ -111,15 +111,7 @@ class Scene:
             seq, ap, off = tables
             eng.set_sequences(seq, ap)
             eng.set_seq_offsets(off)
-        elif self.options.bokeh_shape != ffi.HR_BOKEH_CIRCULAR:
-            # polygonal bokeh: tables come from the host (the device generators cover the circular aperture only)
-            P = self.options.max_render_passes
-            edges = {ffi.HR_BOKEH_PENTAGON: 5, ffi.HR_BOKEH_HEXAGON: 6, ffi.HR_BOKEH_OCTAGON: 8}[self.options.bokeh_shape]
-            seq = np.stack([eng.qmc_generate(self.options.sample_mode, s, P) for s in range(16)])
-            ap = np.stack([host.polygon_aperture(eng.qmc_generate(ffi.HR_SAMPLE_SOBOL, s, P), edges) for s in range(16)])
-            eng.set_sequences(seq, ap)
-            eng.generate_seq_offsets()
-        else:
+        else:  # every sample mode and bokeh shape has a generator behind the C-ABI (PassGenerator.cpp:603-684)
             eng.generate_sequences(self.options.sample_mode, self.options.bokeh_shape, self.options.max_render_passes)
             eng.generate_seq_offsets()
         eng.clear()

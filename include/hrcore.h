@@ -48,12 +48,13 @@ extern "C" {
 
 typedef struct hr_ctx hr_ctx;
 
-/* Version of this interface: bumped whenever a struct grows or a signature changes (5: hr_ctx_desc.memory_budget, hr_step_record.group,
+/* Version of this interface: bumped whenever a struct grows, a signature changes or an entry point is added (6: hr_aperture_generate and
+ * device generators behind every sample mode and bokeh shape; 5: hr_ctx_desc.memory_budget, hr_step_record.group,
  * hr_abi_version itself; 4 was round 4's hr_display(..., passes_shown) and the grown hr_scene_info / hr_kernel_times).  A caller compares
  * hr_abi_version() of the library it loaded with the HR_ABI_VERSION it was compiled against BEFORE anything else and refuses a
  * mismatch — a library that writes a longer struct than the caller allocated corrupts memory silently otherwise.  The Python
  * binding (heatray_amd/_ffi.py) and the C++ layer (heatray_amd/host/HeatrayRenderer/PassGenerator.cpp) do. */
-#define HR_ABI_VERSION 5u
+#define HR_ABI_VERSION 6u
 uint32_t hr_abi_version(void);
 
 /* ------------------------------------------------------------------ context */
@@ -267,14 +268,17 @@ int hr_lights_set(hr_ctx *ctx, const hr_lights *lights);
 
 /* --------------------------------------------------------------- QMC tables */
 
-#define HR_SAMPLE_RANDOM 0     /* PassGenerator.h:103 — host tables only (std:: distributions) */
+/* Every mode and shape has a device generator.  The three that the reference builds on its C++ library's <random> (RANDOM, and the polygonal
+ * apertures) follow libstdc++'s distributions (GCC 11+; heatray_amd/csrc/hr_tables.h states them) — an application built against
+ * another standard library that wants ITS tables uploads them with hr_sequences_set. */
+#define HR_SAMPLE_RANDOM 0     /* PassGenerator.h:103 — util::uniformRandomFloats: std::mt19937 + uniform_real_distribution, Random.h:113-130 */
 #define HR_SAMPLE_HALTON 1
 #define HR_SAMPLE_HAMMERSLEY 2
-#define HR_SAMPLE_BLUE_NOISE 3 /* host tables only (sequential best-candidate) */
+#define HR_SAMPLE_BLUE_NOISE 3 /* util::blueNoise: best of 30 hashed candidates per point, BlueNoise.h:52-100 */
 #define HR_SAMPLE_SOBOL 4
 
 #define HR_BOKEH_CIRCULAR 0 /* radialSobol, Random.h:268-289 */
-#define HR_BOKEH_PENTAGON 1 /* randomPolygonal: host tables only */
+#define HR_BOKEH_PENTAGON 1 /* randomPolygonal(5 / 6 / 8 edges): std::mt19937 + uniform_int / uniform_real, Random.h:293-355 */
 #define HR_BOKEH_HEXAGON 2
 #define HR_BOKEH_OCTAGON 3
 
@@ -285,13 +289,14 @@ int hr_sequences_set(hr_ctx *ctx, const float *seq_xy, const float *aperture_xy,
 /* replaces the SequenceOffsets uniform block (PassGenerator.cpp:150-159); n vec2 */
 int hr_seq_offsets_set(hr_ctx *ctx, const float *offsets_xy, int32_t n);
 
-/* Device-side generators for the Owen-scrambled sequences
- * (util::sobol / halton / hammersley / radialSobol, Random.h:85-289).
- * out_xy (host, count vec2) may be NULL when only the device table is wanted. */
+/* Device-side generators of one table: util::sobol / halton / hammersley / blueNoise / uniformRandomFloats(seed = sequence_index)
+ * (Random.h:85-265); radial != 0 (Sobol only) = util::radialSobol (Random.h:268-289).  out_xy: host, count vec2. */
 int hr_qmc_generate(hr_ctx *ctx, int32_t mode, uint32_t sequence_index, uint32_t count, int32_t radial,
                     float *out_xy);
-/* generateRandomSequences(P, mode, bokeh) entirely on device (PassGenerator.cpp:603-684);
- * HR_ERR_UNSUPPORTED for the host-only modes above. */
+/* One aperture table: util::radialSobol (HR_BOKEH_CIRCULAR) or util::randomPolygonal(edges, count, seed = sequence_index)
+ * (Random.h:268-355), as PassGenerator.cpp:653-676 calls them.  out_xy: host, count vec2. */
+int hr_aperture_generate(hr_ctx *ctx, int32_t bokeh_shape, uint32_t sequence_index, uint32_t count, float *out_xy);
+/* generateRandomSequences(P, mode, bokeh) entirely on device (PassGenerator.cpp:603-684): every mode, every shape. */
 int hr_sequences_generate(hr_ctx *ctx, int32_t sample_mode, int32_t bokeh_shape, int32_t len);
 /* generateSequenceOffsets(W,H) on device: sobol(W*H points, sequence 0) (PassGenerator.cpp:150-159) */
 int hr_seq_offsets_generate(hr_ctx *ctx);

@@ -280,6 +280,18 @@ int ora_qmc_polygon(hr_ctx *, uint32_t edges, uint32_t seqIndex, uint32_t count,
     randomPolygonal((vec2 *)out, edges, count, seqIndex);
     return HR_OK;
 }
+// one aperture table (PassGenerator.cpp:653-676): the checker's side of hr_aperture_generate
+int ora_aperture_generate(hr_ctx *ctx, int32_t bokeh, uint32_t seqIndex, uint32_t count, float *out)
+{
+    if (!out || count == 0) ORA_FAIL(ctx, HR_ERR_INVALID, "bad count / output");
+    switch (bokeh) {
+    case HR_BOKEH_CIRCULAR: radialSobol((vec2 *)out, count, seqIndex); return HR_OK;
+    case HR_BOKEH_PENTAGON: randomPolygonal((vec2 *)out, 5, count, seqIndex); return HR_OK;
+    case HR_BOKEH_HEXAGON: randomPolygonal((vec2 *)out, 6, count, seqIndex); return HR_OK;
+    case HR_BOKEH_OCTAGON: randomPolygonal((vec2 *)out, 8, count, seqIndex); return HR_OK;
+    }
+    ORA_FAIL(ctx, HR_ERR_INVALID, "unknown bokeh shape");
+}
 // generateRandomSequences (PassGenerator.cpp:603-684)
 int ora_sequences_generate(hr_ctx *ctx, int32_t sampleMode, int32_t bokeh, int32_t len)
 {

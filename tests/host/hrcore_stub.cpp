@@ -38,6 +38,7 @@ int hr_lights_set(hr_ctx *, const hr_lights *) { return HR_OK; }
 int hr_sequences_set(hr_ctx *, const float *, const float *, int32_t, int32_t) { return HR_OK; }
 int hr_seq_offsets_set(hr_ctx *, const float *, int32_t) { return HR_OK; }
 int hr_qmc_generate(hr_ctx *, int32_t, uint32_t, uint32_t count, int32_t, float *out) { if (out) std::memset(out, 0, sizeof(float) * 2 * count); return HR_OK; }
+int hr_aperture_generate(hr_ctx *, int32_t, uint32_t, uint32_t count, float *out) { if (out) std::memset(out, 0, sizeof(float) * 2 * count); return HR_OK; }
 int hr_sequences_generate(hr_ctx *, int32_t, int32_t, int32_t) { return HR_OK; }
 int hr_seq_offsets_generate(hr_ctx *) { return HR_OK; }
 int hr_multiscatter_lut_generate(hr_ctx *c, float *out, hr_tex_id *tex) { if (out) std::memset(out, 0, sizeof(float) * 128 * 128); if (tex) *tex = c->nTextures++; return HR_OK; }

@@ -94,11 +94,67 @@ def test_device_multiscatter_lut_vs_shipped_tiff(golden, gpu):
     assert lut.tobytes() == ora_lut.tobytes(), f"{int((lut != ora_lut).sum())} texels differ from the oracle's table"
 
 
-def test_unsupported_device_generators_fail_loudly(gpu):
+def test_device_tables_of_the_serial_generators_vs_reference_golden(golden, gpu):
+    # util::uniformRandomFloats / blueNoise / randomPolygonal (Random.h:113-130, 158-165, 293-355): std::mt19937 with libstdc++'s
+    # distributions and the best-candidate blue noise as HIP kernels (hr_tables.h, k_mt_tables, k_blue_noise), against the tables the
+    # reference's own header produced (tests/golden/make_golden.py)
+    for seq in range(16):
+        assert gpu.qmc_generate(ffi.HR_SAMPLE_RANDOM, seq, 32).tobytes() == golden[f"random_p32_s{seq}"].tobytes(), seq
+        assert gpu.qmc_generate(ffi.HR_SAMPLE_BLUE_NOISE, seq, 32).tobytes() == golden[f"bluenoise_p32_s{seq}"].tobytes(), seq
+        for shape, edges in ((ffi.HR_BOKEH_PENTAGON, 5), (ffi.HR_BOKEH_HEXAGON, 6), (ffi.HR_BOKEH_OCTAGON, 8)):
+            assert gpu.aperture_generate(shape, seq, 32).tobytes() == golden[f"polygon{edges}_p32_s{seq}"].tobytes(), (edges, seq)
+        assert gpu.aperture_generate(ffi.HR_BOKEH_CIRCULAR, seq, 1024).tobytes() == golden[f"radialsobol_p1024_s{seq}"].tobytes()
+
+
+@pytest.mark.parametrize("count", [1, 2, 311, 312, 313, 5000])
+def test_device_mt_tables_across_twists(gpu, count):
+    # 624 draws per twist: 312 samples of uniformRandomFloats end exactly on a block; the polygon tables use a data-dependent number of
+    # draws per sample (about 5.3), so 5000 samples walk ~40 blocks with the rejection state carried across every boundary
+    o = oracle_lib.engine()
+    for seq in (0, 7, 15, 123456):
+        assert gpu.qmc_generate(ffi.HR_SAMPLE_RANDOM, seq, count).tobytes() == o.qmc_generate(ffi.HR_SAMPLE_RANDOM, seq, count).tobytes()
+        for shape in (ffi.HR_BOKEH_PENTAGON, ffi.HR_BOKEH_HEXAGON, ffi.HR_BOKEH_OCTAGON):
+            got, want = gpu.aperture_generate(shape, seq, count), o.aperture_generate(shape, seq, count)
+            assert got.tobytes() == want.tobytes(), (shape, seq, int((got != want).any(axis=1).argmax()))
+
+
+@pytest.mark.parametrize("count", [1, 2, 33, 700, 2500])
+def test_device_blue_noise_vs_oracle(gpu, count):
+    o = oracle_lib.engine()
+    for seq in (0, 5, 15):
+        got, want = gpu.qmc_generate(ffi.HR_SAMPLE_BLUE_NOISE, seq, count), o.qmc_generate(ffi.HR_SAMPLE_BLUE_NOISE, seq, count)
+        assert got.tobytes() == want.tobytes(), (seq, int((got != want).any(axis=1).argmax()))
+    assert (want >= 0).all() and (want <= 1).all()
+
+
+def test_device_blue_noise_beyond_the_lds_copy(gpu):
+    # more than 8192 points: the points stay in memory instead of LDS (k_blue_noise<false>); one sequence, ~1e9 distance tests for the checker
+    o = oracle_lib.engine()
+    got, want = gpu.qmc_generate(ffi.HR_SAMPLE_BLUE_NOISE, 3, 8300), o.qmc_generate(ffi.HR_SAMPLE_BLUE_NOISE, 3, 8300)
+    assert got.tobytes() == want.tobytes(), int((got != want).any(axis=1).argmax())
+
+
+@pytest.mark.parametrize("mode,shape", [(ffi.HR_SAMPLE_BLUE_NOISE, ffi.HR_BOKEH_HEXAGON), (ffi.HR_SAMPLE_RANDOM, ffi.HR_BOKEH_OCTAGON),
+                                        (ffi.HR_SAMPLE_HALTON, ffi.HR_BOKEH_PENTAGON)])
+def test_render_with_device_made_tables_of_every_kind(golden, mode, shape):
+    # generateRandomSequences(P, mode, shape) on the device, then a depth-of-field render: the frame equals the oracle's, whose tables
+    # come from its own <random> / blue-noise loops
+    sc = scenes.multi_material(64, 48, bounces=3)
+    sc.options.fstop = 2.0
+    sc.options.sample_mode, sc.options.bokeh_shape = mode, shape
+    g, o, _, _ = render_both(sc, 5, lut=golden["multiscatter_lut"], device_tables=True)
+    assert_parity(g, o, f"tables {mode}/{shape}")
+
+
+def test_unknown_table_kinds_fail_loudly(gpu):
     with pytest.raises(ffi.EngineError):
-        gpu.qmc_generate(ffi.HR_SAMPLE_BLUE_NOISE, 0, 32)
+        gpu.qmc_generate(7, 0, 32)
     with pytest.raises(ffi.EngineError):
-        gpu.generate_sequences(ffi.HR_SAMPLE_SOBOL, ffi.HR_BOKEH_PENTAGON, 32)
+        gpu.generate_sequences(ffi.HR_SAMPLE_SOBOL, 9, 32)
+    with pytest.raises(ffi.EngineError):
+        gpu.aperture_generate(-1, 0, 32)
+    with pytest.raises(ffi.EngineError):
+        gpu.qmc_generate(ffi.HR_SAMPLE_BLUE_NOISE, 0, 0)
 
 
 # ------------------------------------------------------------------------------- traversal
@@ -878,7 +934,7 @@ def test_full_size_config4_eight_shards_of_config3(golden):
 
 def test_full_size_config5_properties(golden):
     # BASELINE config 5 at full size on one GPU: 3840x2160, 16 bounces, 1M triangles, 25 % glass + 25 % clearcoat materials,
-    # f/2.8 depth of field with the PENTAGON aperture (deterministic host-side tables, host.polygon_aperture)
+    # f/2.8 depth of field with the PENTAGON aperture (util::randomPolygonal tables from the device generator)
     W, H, depth = 3840, 2160, 16
     sc = scenes.triangle_soup(1_000_000, width=W, height=H, bounces=depth, passes=32, env=True, glass_fraction=0.25, clearcoat_fraction=0.25)
     sc.options.fstop = 2.8
@@ -886,7 +942,7 @@ def test_full_size_config5_properties(golden):
     assert sum(1 for m in sc.materials.values() if m.type == ffi.HR_MAT_GLASS) == 4
     assert sum(1 for m in sc.materials.values() if m.type == ffi.HR_MAT_PBR and m.clear_coat > 0) == 4
     e = core.create_engine()
-    sc.apply(e, lut=golden["multiscatter_lut"])     # polygonal bokeh: scenes.Scene.apply builds the tables through the engine
+    sc.apply(e, lut=golden["multiscatter_lut"])
     assert e.scene_info().n_triangles == 1_000_000
     passes = 2
     for s in range(passes):
@@ -1004,7 +1060,7 @@ def test_passes_to_converge_agrees_with_the_oracle(golden):
 
 
 def test_pentagon_bokeh_dof_config5_aperture(golden):
-    # BASELINE config 5's pentagon bokeh: deterministic host-side aperture tables (host.polygon_aperture) on both engines
+    # BASELINE config 5's pentagon bokeh: util::randomPolygonal(5) tables, made by k_mt_tables on the one side and by the oracle's <random> on the other
     sc = scenes.multi_material(96, 64, bounces=4)
     sc.options.fstop = 2.8
     sc.options.bokeh_shape = ffi.HR_BOKEH_PENTAGON

@@ -140,24 +140,6 @@ def test_reference_viewer_links_against_the_layer(tmp_path):
     assert not missing, missing
 
 
-def test_polygon_aperture_is_uniform_on_the_polygon():
-    import numpy as np
-    from heatray_amd import host
-    rng = np.random.default_rng(3)
-    for edges in (5, 6, 8):
-        p = host.polygon_aperture(rng.random((200000, 2), dtype=np.float32), edges)
-        assert p.dtype == np.float32 and p.shape == (200000, 2)
-        mid = (np.arange(edges) + 0.5) * 2 * np.pi / edges                   # edge normals
-        n = np.stack([np.cos(mid), np.sin(mid)], axis=1)
-        assert (p @ n.T).max() <= np.cos(np.pi / edges) + 1e-6               # inside the polygon of Random.h:293-321
-        assert np.abs(p.mean(axis=0)).max() < 5e-3                            # centred
-        area = 0.5 * edges * np.sin(2 * np.pi / edges)
-        inner = (np.hypot(p[:, 0], p[:, 1]) < 0.5).mean()                     # uniform: disc of radius 0.5 holds pi/4 / area
-        assert abs(inner - (np.pi * 0.25) / area) < 5e-3
-    same = host.polygon_aperture(np.full((4, 2), 0.25, np.float32), 5)
-    assert (same == same[0]).all()                                             # deterministic
-
-
 @pytest.mark.parametrize("san,env", [("tsan", {"TSAN_OPTIONS": "halt_on_error=1"}),
                                      ("asan", {"ASAN_OPTIONS": "detect_leaks=1", "UBSAN_OPTIONS": "halt_on_error=1"})])
 def test_layer_threading_under_sanitizers(san, env):
