@@ -72,6 +72,16 @@ def test_std_distribution_tables_same_toolchain(golden, ora, oracle_lib):
             assert np.array_equal(out, golden[f"polygon{edges}_p32_s{seq}"])
 
 
+def test_aperture_tables_entry_point(golden, ora):
+    # ora_aperture_generate = the checker's side of hr_aperture_generate (PassGenerator.cpp:653-676)
+    for seq in range(16):
+        assert ora.aperture_generate(ffi.HR_BOKEH_CIRCULAR, seq, 1024).tobytes() == golden[f"radialsobol_p1024_s{seq}"].tobytes()
+        for shape, edges in ((ffi.HR_BOKEH_PENTAGON, 5), (ffi.HR_BOKEH_HEXAGON, 6), (ffi.HR_BOKEH_OCTAGON, 8)):
+            assert ora.aperture_generate(shape, seq, 32).tobytes() == golden[f"polygon{edges}_p32_s{seq}"].tobytes()
+    with pytest.raises(ffi.EngineError):
+        ora.aperture_generate(11, 0, 32)
+
+
 def test_sequence_offsets_table(golden, ora):
     # PassGenerator::generateSequenceOffsets: sobol(W*H, sequence 0)
     ora.resize(64, 64)
