@@ -115,6 +115,12 @@ def random_scene(seed):
     o.fstop = float(rng.choice([host.FSTOP_DISABLED, 1.4, 2.8, 8.0]))
     o.sample_mode = int(rng.choice([ffi.HR_SAMPLE_SOBOL, ffi.HR_SAMPLE_HALTON, ffi.HR_SAMPLE_HAMMERSLEY]))
     o.max_channel_value = float(F(rng.choice([math.pi, 1.0, 50.0])))
+    # round 5: the serial generators' tables too (std::mt19937 tables, blue noise, polygonal apertures: k_mt_tables / k_blue_noise against the
+    # oracle's <random>).  Drawn from a generator of their own so that the scenes of earlier campaigns keep every other parameter.
+    rng2 = np.random.default_rng(seed ^ 0x7AB1E5)
+    if rng2.random() < 0.3:
+        o.sample_mode = int(rng2.choice([ffi.HR_SAMPLE_RANDOM, ffi.HR_SAMPLE_BLUE_NOISE]))
+    o.bokeh_shape = int(rng2.choice([ffi.HR_BOKEH_CIRCULAR, ffi.HR_BOKEH_PENTAGON, ffi.HR_BOKEH_HEXAGON, ffi.HR_BOKEH_OCTAGON], p=[0.55, 0.15, 0.15, 0.15]))
     # the importance-sampled environment + MIS estimator (include/hrcore.h) on a part of the scenes (a no-op without a map)
     o.estimator = int(rng.choice([ffi.HR_ESTIMATOR_REFERENCE, ffi.HR_ESTIMATOR_ENV_MIS, ffi.HR_ESTIMATOR_ALL_LIGHTS], p=[0.5, 0.25, 0.25]))
     # mip chain + ray-cone texture lookups (include/hrcore.h) on a third of the scenes
