@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: tools/r5_batch23.sh LABEL  — in-tree library (LABEL) against build_variants/libhrcore_prev.so on c3 / c3d / c5 and a 1/8 shard
+# usage (ON THE GPU BOX): tools/ab_libs.sh LABEL — the in-tree library (LABEL) against build_variants/libhrcore_prev.so (tools/build_variant.sh prev "" on the
+# parent commit) on c3 / c3d / c5 at 20 passes, c3 at 128 and a 1/8 shard, three runs each, then the parity tests: how round 5's kernel experiments were judged
 mkdir -p gpurun_out; out=gpurun_out/r5af_$1.txt; rm -f $out
 run() { local label=$1 wl=$2 k=$3 lib=$4; shift 4
   for i in 1 2 3; do
