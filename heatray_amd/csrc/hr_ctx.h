@@ -301,6 +301,7 @@ struct hr_ctx {
     // enters (c3 76, c5 75, c3d 162: +8..13 %; c2 35: no difference; terrain 10, c1 5: k_trace is VALU-bound itself there and loses 6 %).
     int tuneCorun = 1;       // HR_TUNE="corun=0|1|2": never (the packet kernel in front of k_trace on the group's stream) / by the probe / always
     int tuneCorunMin = 50;   // HR_TUNE="cmin=N": beside k_trace when a probed camera ray enters at least N child boxes
+    int tunePacketSwizzle = 1; // HR_TUNE="pswz=0|1": k_raygen_packets deals whole 32x32 tiles to the XCDs (workgroup index -> XCD is round robin) instead of consecutive 16-pixel patches: a tile's part of the tree goes through ONE L2 (+0.3-0.7 % on c3 / c2 / c5, profiles/r5ak_packet_xcd.txt)
     int tuneCorunBlocks = 0; // HR_TUNE="cblocks=N": fix k_trace's workgroups per CU in such a step (0: 3 or 4 by the step's mix)
     int tunePacketUnion = 220; // HR_TUNE="punion=N": packets while U < N / 100 (measured break-even ~2.3: terrain at 1.97 +7..11 %, c5 at 2.07 +3..4 %)
     bool packetsOn = false;
@@ -420,7 +421,7 @@ struct hr_ctx {
     float *fb() const { return fbExternal ? fbExternal : fbInternal; }
     // tuning knobs (defaults measured on MI355X; HR_TUNE="tri=4,refill=8,blocks=6,depth=12,batch=2,groups=2" overrides for experiments)
     int tuneTri = 2, tuneRefill = 16, tuneBlocks = 5, tuneShadeBlocks = 4, tuneDepth = kMaxSlots, tuneBatch = 0, tuneFetchMax = 64, tuneFetchMin = 64, tuneStaticDeal = 256, tuneFetchPrimary = 128, tuneFetchGate = 8, tuneHeads = 5, tuneSlowMs = 4;
-    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass}; }
+    LaunchCfg cfg(hipStream_t st) const { return LaunchCfg{st, numCUs, tuneBlocks, tuneShadeBlocks, collectStats, textureLodUsed, allLightsUsed, hasGlass, tunePacketSwizzle}; }
 };
 
 #define FAIL(ctx, code, msg)  \

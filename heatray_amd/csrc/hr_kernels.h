@@ -32,6 +32,7 @@ struct LaunchCfg {
     bool textureLod; // some pass has asked for HR_TEXTURE_LOD_CONE: launch the shading kernel that carries the trilinear sampler
     bool allLights;  // some pass has asked for HR_ESTIMATOR_ALL_LIGHTS: the shading kernel that can emit two occlusion rays per vertex
     bool hasGlass;   // some material of the scene is glass: the glass shading kernel is launched too
+    int packetSwizzle = 0; // k_raygen_packets deals whole 32x32 tiles to the XCDs instead of consecutive 16-pixel patches (HR_TUNE pswz)
 };
 
 // One in-flight pass as seen by the kernels of one macro step.

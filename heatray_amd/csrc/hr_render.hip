@@ -1050,8 +1050,18 @@ __global__ __launch_bounds__(kRpBlock) void k_raygen_packets(const SceneDev *__r
     if (threadIdx.x < (uint32_t)kMaxBatch) cnt[threadIdx.x] = 0u;
     stats += blockIdx.x & (kStatSlots - 1);
     const uint32_t lane = laneId(), wave = threadIdx.x >> 6;
+    const bool swz = (passesLog2 & 256) != 0;
+    passesLog2 &= 255;
     const uint32_t nPass = 1u << passesLog2, pass = lane & (nPass - 1u), npx = 64u >> passesLog2;
-    const uint32_t m = (blockIdx.x * (uint32_t)(kRpBlock / 64) + wave) * npx + (lane >> passesLog2); // owned pixel, patches in Morton order
+    // (passesLog2 bit 8, HR_TUNE pswz=1: workgroups go to the 8 XCDs round robin by their index; dealt like this, the 1024 / pixelsPerBlock
+    // workgroups of a 32x32 tile all land on one XCD — its L2 fetches the tile's part of the tree once instead of all eight doing so)
+    uint32_t b = blockIdx.x;
+    if (swz) {
+        const uint32_t perTile = 1024u / ((uint32_t)(kRpBlock / 64) * (64u >> passesLog2)); // workgroups per tile (a power of two)
+        const uint32_t x = b & 7u, i = b >> 3;
+        b = ((i / perTile) * 8u + x) * perTile + (i % perTile);
+    }
+    const uint32_t m = (b * (uint32_t)(kRpBlock / 64) + wave) * npx + (lane >> passesLog2); // owned pixel, patches in Morton order
     const SegDev &seg = tbl->seg[segs.seg[pass]];
     hr_pass_params pp = UNIFORM ? tbl->seg[segs.seg[0]].pp : seg.pp;
     if (UNIFORM) pp.sample_index = seg.pp.sample_index;
@@ -1506,7 +1516,12 @@ void launchRaygenPackets(const LaunchCfg &cfg, const SceneDev *S, const Node4 *n
     int passesLog2 = 0;
     while ((2 << passesLog2) <= segs.n) ++passesLog2; // (the caller passes a power of two)
     const int pixelsPerBlock = (kRpBlock / 64) * (64 >> passesLog2);
-    const dim3 grid((threads + pixelsPerBlock - 1) / pixelsPerBlock);
+    dim3 grid((threads + pixelsPerBlock - 1) / pixelsPerBlock);
+    if (cfg.packetSwizzle && fr.tile == 32) { // (whole groups of 8 tiles: the kernel's ownedPixel() turns away what lies beyond the frame)
+        const uint32_t group = 8u * (1024u / (uint32_t)pixelsPerBlock);
+        grid.x = (grid.x + group - 1u) / group * group;
+        passesLog2 |= 256;
+    }
     if (cfg.collectStats && uniformParams)
         hipLaunchKernelGGL((k_raygen_packets<true, true>), grid, dim3(kRpBlock), 0, cfg.stream, S, nodes, tris, tbl, segs, passesLog2, fr, stats);
     else if (cfg.collectStats)
