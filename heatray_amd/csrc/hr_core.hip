@@ -197,7 +197,7 @@ int hr_ctx_create(const hr_ctx_desc *desc, hr_ctx **out)
         };
         get("tri=", c->tuneTri), get("refill=", c->tuneRefill), get("blocks=", c->tuneBlocks), get("depth=", c->tuneDepth);
         get("sblocks=", c->tuneShadeBlocks), get("batch=", c->tuneBatch), get("fmax=", c->tuneFetchMax), get("fmin=", c->tuneFetchMin);
-        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("pswz=", c->tunePacketSwizzle), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs), get("ovf=", c->tuneOverflowTest), get("sprobe=", c->tuneShadowProbe), get("tblk=", c->tuneTableKernel);
+        get("groups=", c->tuneGroups), get("prio=", c->tunePrio), get("refit=", c->tuneRefit), get("sdeal=", c->tuneStaticDeal), get("guard=", c->tuneGuardPct), get("ploc=", c->tunePloc), get("packets=", c->tunePackets), get("corun=", c->tuneCorun), get("cmin=", c->tuneCorunMin), get("cblocks=", c->tuneCorunBlocks), get("plog=", c->tuneProbeLog2), get("pswz=", c->tunePacketSwizzle), get("punion=", c->tunePacketUnion), get("plocr=", c->tunePlocRadius), get("fprim=", c->tuneFetchPrimary), get("fgate=", c->tuneFetchGate), get("heads=", c->tuneHeads), get("slow=", c->tuneSlowMs), get("ovf=", c->tuneOverflowTest), get("sprobe=", c->tuneShadowProbe), get("tblk=", c->tuneTableKernel);
         c->tuneBlocksSet = find("blocks=") != nullptr;
         if (c->tuneDepth < 1 || c->tuneDepth > kMaxSlots) c->tuneDepth = kMaxSlots;
         if (c->tuneGroups < 0 || c->tuneGroups > kMaxGroups) c->tuneGroups = 0;

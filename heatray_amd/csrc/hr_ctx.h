@@ -302,6 +302,7 @@ struct hr_ctx {
     int tuneCorun = 1;       // HR_TUNE="corun=0|1|2": never (the packet kernel in front of k_trace on the group's stream) / by the probe / always
     int tuneCorunMin = 50;   // HR_TUNE="cmin=N": beside k_trace when a probed camera ray enters at least N child boxes
     int tunePacketSwizzle = 1; // HR_TUNE="pswz=0|1": k_raygen_packets deals whole 32x32 tiles to the XCDs (workgroup index -> XCD is round robin) instead of consecutive 16-pixel patches: a tile's part of the tree goes through ONE L2 (+0.3-0.7 % on c3 / c2 / c5, profiles/r5ak_packet_xcd.txt)
+    int tuneProbeLog2 = -1;  // HR_TUNE="plog=N" (measurement only): the selector's probe walks packets of 2^N passes x 64 >> N pixels instead of the shape in use
     int tuneCorunBlocks = 0; // HR_TUNE="cblocks=N": fix k_trace's workgroups per CU in such a step (0: 3 or 4 by the step's mix)
     int tunePacketUnion = 220; // HR_TUNE="punion=N": packets while U < N / 100 (measured break-even ~2.3: terrain at 1.97 +7..11 %, c5 at 2.07 +3..4 %)
     bool packetsOn = false;

@@ -543,7 +543,7 @@ static int macroStep(hr_ctx *c, int g, int nInject)
         // (probeSeen holds the totals of the report the previous decision was taken on: probes never overlap, that probe was complete)
         HIP_TRY(c, hipEventRecord(c->evProbeA, G.stream));
         HIP_TRY(c, hipStreamWaitEvent(c->probeStream, c->evProbeA, 0));
-        c->probeWaves = (unsigned long long)launchPacketProbe(c->probeStream, c->dScene, c->nodes, c->tris, tbl.seg[probeSeg].pp, packetLog2(c), fr, c->dProbe);
+        c->probeWaves = (unsigned long long)launchPacketProbe(c->probeStream, c->dScene, c->nodes, c->tris, tbl.seg[probeSeg].pp, c->tuneProbeLog2 >= 0 ? c->tuneProbeLog2 : packetLog2(c), fr, c->dProbe);
         HIP_TRY(c, hipEventRecord(c->evProbeB, c->probeStream));
         c->probeGuard = true, c->probePending = true, c->probeStep = stepIdx, c->probeCountdown = kProbeEvery;
     }
